@@ -1,0 +1,47 @@
+# Build the HIP engine (gfx950) and the CPU oracle.  No cmake, no JIT cache:
+# the shared objects are built in-tree so they travel with the gpurun snapshot.
+HIPCC      ?= /opt/rocm/bin/hipcc
+CC         ?= gcc
+ARCH       ?= gfx950
+
+# -ffp-contract=off: the reference (Rust) never fuses a*b+c; hipcc defaults to
+# contract=fast.  No fast-math anywhere.  Denormals stay enabled (gfx9 default).
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
+              -fno-fast-math -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function -Iinclude
+ORCFLAGS   := -O3 -std=c11 -fPIC -ffp-contract=off -fno-fast-math \
+              -fwrapv -Wall -Wextra -D_GNU_SOURCE
+
+CSRC       := idsp_amd/csrc
+HIP_SRCS   := $(wildcard $(CSRC)/*.hip)
+HIP_OBJS   := $(HIP_SRCS:.hip=.o)
+HIP_HDRS   := $(wildcard $(CSRC)/*.h) include/idsp_hip.h
+
+LIB        := idsp_amd/lib/libidsp_hip.so
+ORACLE     := oracle/_build/libidsp_oracle.so
+# -march=native variant: built ON the machine that times it (bench.py cpu_baseline)
+ORACLE_NAT := oracle/_build/libidsp_oracle_native.so
+
+all: $(LIB) $(ORACLE)
+lib: $(LIB)
+oracle: $(ORACLE)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(HIP_OBJS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+
+$(ORACLE): oracle/idsp_oracle.c oracle/idsp_oracle.h include/idsp_hip.h
+	@mkdir -p $(dir $@)
+	$(CC) $(ORCFLAGS) -shared -o $@ oracle/idsp_oracle.c -lm -lpthread
+
+oracle-native: $(ORACLE_NAT)
+$(ORACLE_NAT): oracle/idsp_oracle.c oracle/idsp_oracle.h include/idsp_hip.h
+	@mkdir -p $(dir $@)
+	$(CC) $(ORCFLAGS) -march=native -shared -o $@ oracle/idsp_oracle.c -lm -lpthread
+
+clean:
+	rm -f $(HIP_OBJS) $(LIB) $(ORACLE) $(ORACLE_NAT)
+
+.PHONY: all lib oracle oracle-native clean

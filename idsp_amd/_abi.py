@@ -1,0 +1,137 @@
+"""ctypes view of the C ABI declared in ``include/idsp_hip.h``.
+
+The structures and prototypes below are shared by the product library
+(``libidsp_hip.so``, symbols ``idsp_*``) and — for the tests only — by its CPU
+oracle twin (``idsp_ref_*``, host pointers, no ``stream`` argument).  Nothing
+in here computes anything.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+IDSP_OK = 0
+IDSP_EINVAL = -1
+IDSP_EHIP = -2
+IDSP_ENODEV = -3
+
+FRAME_MAJOR = 0
+LANE_MAJOR = 1
+
+MAX_SECTIONS = 64
+HBF_MAX_STAGES = 5
+HBF_MAX_TAPS = 32
+LOCKIN_MAX_CASCADE = 4
+
+
+class BiquadI32(C.Structure):
+    _fields_ = [("ba", C.c_int32 * 5), ("frac", C.c_int32)]
+
+
+class BiquadClampI32(C.Structure):
+    _fields_ = [("ba", C.c_int32 * 5), ("frac", C.c_int32), ("u", C.c_int32), ("min", C.c_int32), ("max", C.c_int32)]
+
+
+class BiquadF32(C.Structure):
+    _fields_ = [("ba", C.c_float * 5)]
+
+
+class BiquadClampF32(C.Structure):
+    _fields_ = [("ba", C.c_float * 5), ("u", C.c_float), ("min", C.c_float), ("max", C.c_float)]
+
+
+class HbfCascadeF32(C.Structure):
+    _fields_ = [
+        ("stages", C.c_int32),
+        ("m", C.c_int32 * HBF_MAX_STAGES),
+        ("taps", (C.c_float * HBF_MAX_TAPS) * HBF_MAX_STAGES),
+    ]
+
+
+class LockinI32(C.Structure):
+    _fields_ = [("order", C.c_int32), ("cascade", C.c_int32), ("k", (C.c_int32 * 2) * LOCKIN_MAX_CASCADE)]
+
+
+_P = C.c_void_p
+_SZ = C.c_size_t
+_I = C.c_int
+
+# name -> (restype, argtypes) for the processing entry points; `stream` (the
+# last void*) is dropped for the oracle twins.
+_STREAM_SIG = [_P, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]  # cfg, n, state, x, y, lanes, frames, layout, stream
+_CFG_SIG = [_P, _P, _P, _P, _SZ, _SZ, _I, _P]          # cfg, state, x, y, lanes, frames, layout, stream
+
+PROCESSING = {
+    "biquad_i32_df1": _STREAM_SIG,
+    "biquad_i32_df1_clamp": _STREAM_SIG,
+    "biquad_i32_dither": _STREAM_SIG,
+    "biquad_i32_dither_clamp": _STREAM_SIG,
+    "biquad_i32_wide": _STREAM_SIG,
+    "biquad_i32_wide_clamp": _STREAM_SIG,
+    "cascade_i32_df1": _STREAM_SIG,
+    "biquad_f32_df1": _STREAM_SIG,
+    "biquad_f32_df1_clamp": _STREAM_SIG,
+    "biquad_f32_df2t": _STREAM_SIG,
+    "biquad_f32_df2t_clamp": _STREAM_SIG,
+    "cascade_f32_df1": _STREAM_SIG,
+    "hbf_dec_f32": _CFG_SIG,
+    "hbf_int_f32": _CFG_SIG,
+    "cossin_i32": [_P, _P, _SZ, _P],
+    "dds_i32": [_P, _P, _SZ, _SZ, _I, _P],
+    "lockin_i32_process": _CFG_SIG,
+    "lowpass_i32": _CFG_SIG,
+}
+
+# host-side helpers present in both libraries (same signature)
+HELPERS = {
+    "biquad_i32_from_sos": (_I, [_P, _I, _P]),
+    "biquad_f32_from_sos": (_I, [_P, _P]),
+    "biquad_f32_from_sos_f64": (_I, [_P, _P]),
+    "hbf_dec_cascade": (_I, [_I, _I, _P]),
+    "hbf_int_cascade": (_I, [_I, _I, _P]),
+    "hbf_dec_response_length": (_I, [_P]),
+    "hbf_int_response_length": (_I, [_P]),
+    "hbf_dec_state_words": (_SZ, [_P]),
+    "hbf_int_state_words": (_SZ, [_P]),
+    "lockin_state_words": (_SZ, [_P]),
+}
+
+# product-only utilities
+UTILS = {
+    "version": (_I, []),
+    "last_error": (C.c_char_p, []),
+    "device_count": (_I, []),
+    "device_set": (_I, [_I]),
+    "device_alloc": (_I, [C.POINTER(_P), _SZ]),
+    "device_free": (_I, [_P]),
+    "device_memset": (_I, [_P, _I, _SZ, _P]),
+    "device_h2d": (_I, [_P, _P, _SZ, _P]),
+    "device_d2h": (_I, [_P, _P, _SZ, _P]),
+    "stream_sync": (_I, [_P]),
+}
+
+
+def exported_names() -> list:
+    """Every symbol include/idsp_hip.h declares (without the ``idsp_`` prefix)."""
+    return sorted(list(PROCESSING) + list(HELPERS) + list(UTILS))
+
+
+def bind(lib: C.CDLL, prefix: str, *, with_stream: bool, utils: bool):
+    """Attach prototypes to `lib`; returns {short name: function}."""
+    out = {}
+    for name, sig in PROCESSING.items():
+        fn = getattr(lib, prefix + name)
+        fn.restype = _I
+        fn.argtypes = list(sig) if with_stream else list(sig[:-1])
+        out[name] = fn
+    for name, (res, args) in HELPERS.items():
+        fn = getattr(lib, prefix + name)
+        fn.restype = res
+        fn.argtypes = list(args)
+        out[name] = fn
+    if utils:
+        for name, (res, args) in UTILS.items():
+            fn = getattr(lib, prefix + name)
+            fn.restype = res
+            fn.argtypes = list(args)
+            out[name] = fn
+    return out

@@ -1,0 +1,220 @@
+// api_util.hip — library/device utilities, coefficient ingestion and the
+// built-in half-band tap sets of the C ABI (include/idsp_hip.h).  Host code
+// only; nothing here is on the per-sample path.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace idsp {
+
+char *last_error_buf()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+// float -> Q: `(v * 2^F).round()` half away from zero, then a saturating
+// `as i32` with NaN -> 0 (dsp-fixedpoint/src/num_traits_impl.rs:32-46; the
+// scale 1/DELTA is an exact power of two, lib.rs:220-224).
+int32_t to_q32(double v, int frac)
+{
+    const double s = std::round(std::ldexp(v, frac));
+    if (std::isnan(s)) return 0;
+    if (s >= 2147483647.0) return INT32_MAX;
+    if (s <= -2147483648.0) return INT32_MIN;
+    return int32_t(s);
+}
+
+// HBF_TAPS (src/hbf.rs:308-349) and HBF_TAPS_98 (src/hbf.rs:258-292); the
+// second index is the reference's tuple index (0 = lowest-rate stage).
+const int kHbfM[2][5] = {{23, 10, 5, 4, 3}, {15, 6, 3, 3, 2}};
+const float kHbfTaps[2][5][23] = {
+    {{7.60375795e-07f, -3.77494111e-06f, 1.26458559e-05f, -3.43188253e-05f, 8.10687478e-05f, -1.72971467e-04f,
+      3.40845059e-04f, -6.29522864e-04f, 1.10128831e-03f, -1.83933299e-03f, 2.95124926e-03f, -4.57290964e-03f,
+      6.87374176e-03f, -1.00656257e-02f, 1.44199840e-02f, -2.03025100e-02f, 2.82462332e-02f, -3.91128509e-02f,
+      5.44795658e-02f, -7.77002672e-02f, 1.17523452e-01f, -2.06185388e-01f, 6.34588695e-01f},
+     {-1.12811343e-05f, 1.12724671e-04f, -6.07439343e-04f, 2.31904511e-03f, -7.00322950e-03f, 1.78225473e-02f,
+      -4.01209836e-02f, 8.43315989e-02f, -1.83189521e-01f, 6.26346521e-01f},
+     {0.0007686f, -0.00768669f, 0.0386536f, -0.14002434f, 0.60828885f},
+     {-0.00261331f, 0.02476858f, -0.12112638f, 0.59897111f},
+     {0.01186105f, -0.09808109f, 0.58622005f}},
+    {{7.02144012e-05f, -2.43279582e-04f, 6.35026936e-04f, -1.39782541e-03f, 2.74613582e-03f, -4.96403839e-03f,
+      8.41806912e-03f, -1.35827601e-02f, 2.11004053e-02f, -3.19267647e-02f, 4.77024289e-02f, -7.18014345e-02f,
+      1.12942004e-01f, -2.03279594e-01f, 6.33592923e-01f},
+     {-0.00086943f, 0.00577837f, -0.02201674f, 0.06357869f, -0.16627679f, 0.61979312f},
+     {0.01414651f, -0.10439639f, 0.59026742f},
+     {0.01227974f, -0.09930782f, 0.58702834f},
+     {-0.06291796f, 0.5629161f}},
+};
+
+int hbf_fill(int tap_set, int stages, bool dec, idsp_hbf_cascade_f32 *out)
+{
+    if (!out) return fail(IDSP_EINVAL, "out is NULL");
+    if (tap_set < 0 || tap_set > 1) return fail(IDSP_EINVAL, "tap_set %d not in {0,1}", tap_set);
+    if (stages < 1 || stages > IDSP_HBF_MAX_STAGES) return fail(IDSP_EINVAL, "stages %d not in 1..5", stages);
+    std::memset(out, 0, sizeof(*out));
+    out->stages = stages;
+    for (int s = 0; s < stages; s++) {
+        // decimator: highest-rate stage (tuple index stages-1) first, src/hbf.rs:412-421;
+        // interpolator: tuple index 0 first, src/hbf.rs:503-512
+        const int t = dec ? stages - 1 - s : s;
+        out->m[s] = kHbfM[tap_set][t];
+        for (int k = 0; k < out->m[s]; k++) out->taps[s][k] = kHbfTaps[tap_set][t][k];
+    }
+    return IDSP_OK;
+}
+
+}  // namespace
+
+bool hbf_cfg_ok(const idsp_hbf_cascade_f32 *c)
+{
+    if (!c || c->stages < 1 || c->stages > IDSP_HBF_MAX_STAGES) return false;
+    for (int s = 0; s < c->stages; s++)
+        if (c->m[s] < 1 || c->m[s] > IDSP_HBF_MAX_TAPS) return false;
+    return true;
+}
+
+}  // namespace idsp
+
+using namespace idsp;
+
+extern "C" {
+
+int idsp_version(void) { return IDSP_ABI_VERSION; }
+
+const char *idsp_last_error(void) { return last_error_buf(); }
+
+int idsp_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(IDSP_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int idsp_device_set(int device)
+{
+    IDSP_HIP_TRY(hipSetDevice(device));
+    return IDSP_OK;
+}
+
+int idsp_device_alloc(void **ptr, size_t bytes)
+{
+    if (!ptr) return fail(IDSP_EINVAL, "ptr is NULL");
+    IDSP_HIP_TRY(hipMalloc(ptr, bytes));
+    return IDSP_OK;
+}
+
+int idsp_device_free(void *ptr)
+{
+    IDSP_HIP_TRY(hipFree(ptr));
+    return IDSP_OK;
+}
+
+int idsp_device_memset(void *ptr, int value, size_t bytes, void *stream)
+{
+    IDSP_HIP_TRY(hipMemsetAsync(ptr, value, bytes, as_stream(stream)));
+    return IDSP_OK;
+}
+
+int idsp_device_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream)
+{
+    IDSP_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return IDSP_OK;
+}
+
+int idsp_device_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream)
+{
+    IDSP_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return IDSP_OK;
+}
+
+int idsp_stream_sync(void *stream)
+{
+    IDSP_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return IDSP_OK;
+}
+
+// src/iir/biquad.rs:545-566 then :570-576
+int idsp_biquad_i32_from_sos(const double sos[6], int frac, idsp_biquad_i32 *out)
+{
+    if (!sos || !out) return fail(IDSP_EINVAL, "sos or out is NULL");
+    if (frac < 0 || frac > 31) return fail(IDSP_EINVAL, "frac = %d not in 0..31", frac);
+    const double a0 = 1.0 / sos[3];
+    const double ba[5] = {sos[0] * a0, sos[1] * a0, sos[2] * a0, -sos[4] * a0, -sos[5] * a0};
+    for (int i = 0; i < 5; i++) out->ba[i] = to_q32(ba[i], frac);
+    out->frac = frac;
+    return IDSP_OK;
+}
+
+int idsp_biquad_f32_from_sos(const float sos[6], idsp_biquad_f32 *out)
+{
+    if (!sos || !out) return fail(IDSP_EINVAL, "sos or out is NULL");
+    const float a0 = 1.0f / sos[3];
+    out->ba[0] = sos[0] * a0;
+    out->ba[1] = sos[1] * a0;
+    out->ba[2] = sos[2] * a0;
+    out->ba[3] = -sos[4] * a0;
+    out->ba[4] = -sos[5] * a0;
+    return IDSP_OK;
+}
+
+int idsp_biquad_f32_from_sos_f64(const double sos[6], idsp_biquad_f32 *out)
+{
+    if (!sos || !out) return fail(IDSP_EINVAL, "sos or out is NULL");
+    const double a0 = 1.0 / sos[3];
+    const double ba[5] = {sos[0] * a0, sos[1] * a0, sos[2] * a0, -sos[4] * a0, -sos[5] * a0};
+    for (int i = 0; i < 5; i++) out->ba[i] = float(ba[i]);
+    return IDSP_OK;
+}
+
+int idsp_hbf_dec_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out) { return hbf_fill(tap_set, stages, true, out); }
+int idsp_hbf_int_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out) { return hbf_fill(tap_set, stages, false, out); }
+
+// src/hbf.rs:424-448
+int idsp_hbf_dec_response_length(const idsp_hbf_cascade_f32 *cfg)
+{
+    if (!hbf_cfg_ok(cfg)) return fail(IDSP_EINVAL, "invalid hbf cascade");
+    int n = 0;
+    for (int s = 0; s < cfg->stages; s++) n = n / 2 + 2 * cfg->m[s] - 1;
+    return n;
+}
+
+// src/hbf.rs:515-539
+int idsp_hbf_int_response_length(const idsp_hbf_cascade_f32 *cfg)
+{
+    if (!hbf_cfg_ok(cfg)) return fail(IDSP_EINVAL, "invalid hbf cascade");
+    int n = 0;
+    for (int s = 0; s < cfg->stages; s++) n = (n + 2 * cfg->m[s] - 1) * 2;
+    return n;
+}
+
+size_t idsp_hbf_dec_state_words(const idsp_hbf_cascade_f32 *cfg)
+{
+    if (!hbf_cfg_ok(cfg)) return 0;
+    size_t w = 0;
+    for (int s = 0; s < cfg->stages; s++) w += size_t(3 * cfg->m[s] - 2);
+    return w;
+}
+
+size_t idsp_hbf_int_state_words(const idsp_hbf_cascade_f32 *cfg)
+{
+    if (!hbf_cfg_ok(cfg)) return 0;
+    size_t w = 0;
+    for (int s = 0; s < cfg->stages; s++) w += size_t(2 * cfg->m[s] - 1);
+    return w;
+}
+
+}  // extern "C"

@@ -1,0 +1,486 @@
+// biquad.hip — iir::Biquad / BiquadClamp / Cascade over many lanes
+// (reference: src/iir/biquad.rs; fixed-point semantics dsp-fixedpoint/src).
+//
+// Each section type is a small device functor operating on the per-lane state
+// words of include/idsp_hip.h held in registers; `Chain<Sec, N>` folds N
+// serial sections sample-major, which yields the same values as the
+// reference's stage-major slice composition (dsp-process/src/compose.rs:43-77)
+// because every section is a causal function of its own input sequence.
+//
+// Integer paths are bit-exact restatements of Rust release (wrapping)
+// arithmetic: i32 x i32 -> i64 products (v_mad_i64_i32), wrapping i64 sums,
+// arithmetic `>> F`, truncating casts.  Float paths keep the reference's
+// left-to-right association with every product and sum rounded separately
+// (the library is compiled with -ffp-contract=off; f32 denormals enabled).
+#include <type_traits>
+
+#include "lane_stream.h"
+
+namespace idsp {
+namespace {
+
+constexpr int kMaxChain = 4;    // sections fused per launch; longer chains run in passes
+constexpr int kMaxCascade = 8;  // Cascade<[Biquad; N]> shares delay lines: single launch
+
+__device__ __forceinline__ int64_t mulw(int32_t c, int32_t v) { return int64_t(c) * int64_t(v); }
+__device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return int64_t(uint64_t(a) + uint64_t(b)); }
+// low 32 bits of (acc >> f) for 0 <= f < 32: one v_alignbit_b32
+__device__ __forceinline__ int32_t shr_lo(int64_t acc, int f)
+{
+    return int32_t(__builtin_amdgcn_alignbit(uint32_t(uint64_t(acc) >> 32), uint32_t(uint64_t(acc)), uint32_t(f)));
+}
+__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// num_traits::clamp on floats: NaN input passes through
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ------------------------------------------------------------ parameter PODs
+struct SecI32 {
+    int32_t ba[5];
+    int32_t frac;
+    int32_t u, mn, mx;
+};
+struct SecF32 {
+    float ba[5];
+    float u, mn, mx;
+};
+template <class S, int N>
+struct ChainParams {
+    S sec[N];
+};
+
+// ------------------------------------------------------------ i32 sections
+// src/iir/biquad.rs:366-383 (C = Q<i32,i64,F>): acc = b0*x0 + b1*x1 + b2*x2 +
+// a1*y1 + a2*y2 in i64, y0 = (acc >> F) as i32.
+__device__ __forceinline__ int64_t sum5(const SecI32 &c, int32_t x0, int32_t x1, int32_t x2, int32_t y1, int32_t y2)
+{
+    int64_t acc = mulw(c.ba[0], x0);
+    acc = wadd(acc, mulw(c.ba[1], x1));
+    acc = wadd(acc, mulw(c.ba[2], x2));
+    acc = wadd(acc, mulw(c.ba[3], y1));
+    acc = wadd(acc, mulw(c.ba[4], y2));
+    return acc;
+}
+
+template <bool CLAMP>
+struct Df1I32 {
+    using T = int32_t;
+    using Sec = SecI32;
+    static constexpr int W = 4;  // x0 x1 y0 y1
+    static __device__ __forceinline__ int32_t step(const SecI32 &c, uint32_t (&s)[W], int32_t x0)
+    {
+        int32_t y0 = shr_lo(sum5(c, x0, int32_t(s[0]), int32_t(s[1]), int32_t(s[2]), int32_t(s[3])), c.frac);
+        if (CLAMP) y0 = clampi(int32_t(uint32_t(y0) + uint32_t(c.u)), c.mn, c.mx);  // biquad.rs:394-404
+        s[1] = s[0];
+        s[0] = uint32_t(x0);
+        s[3] = s[2];
+        s[2] = uint32_t(y0);
+        return y0;
+    }
+};
+
+// src/iir/biquad.rs:511-538 (first-order error feedback)
+template <bool CLAMP>
+struct DitherI32 {
+    using T = int32_t;
+    using Sec = SecI32;
+    static constexpr int W = 5;  // x0 x1 y0 y1 e
+    static __device__ __forceinline__ int32_t step(const SecI32 &c, uint32_t (&s)[W], int32_t x0)
+    {
+        int64_t acc = wadd(int64_t(uint64_t(s[4])), sum5(c, x0, int32_t(s[0]), int32_t(s[1]), int32_t(s[2]), int32_t(s[3])));
+        const int sh = 32 - c.frac;  // 1..32
+        const uint64_t a = uint64_t(acc) << sh;
+        // `(acc as u32) >> (32 - F)`: low word of a; F == 0 leaves a zero low word
+        s[4] = c.frac == 0 ? 0u : (uint32_t(a) >> sh);
+        int32_t y0 = int32_t(uint32_t(a >> 32));
+        if (CLAMP) y0 = clampi(int32_t(uint32_t(y0) + uint32_t(c.u)), c.mn, c.mx);
+        s[1] = s[0];
+        s[0] = uint32_t(x0);
+        s[3] = s[2];
+        s[2] = uint32_t(y0);
+        return y0;
+    }
+};
+
+// src/iir/biquad.rs:456-480 (64-bit y state)
+template <bool CLAMP>
+struct WideI32 {
+    using T = int32_t;
+    using Sec = SecI32;
+    static constexpr int W = 6;  // x0 x1 y0.lo y0.hi y1.lo y1.hi
+    static __device__ __forceinline__ int32_t step(const SecI32 &c, uint32_t (&s)[W], int32_t x0)
+    {
+        int64_t acc = mulw(c.ba[0], x0);
+        acc = wadd(acc, mulw(c.ba[1], int32_t(s[0])));
+        acc = wadd(acc, mulw(c.ba[2], int32_t(s[1])));
+        s[1] = s[0];
+        s[0] = uint32_t(x0);
+        // (y.lo as u32 as i64 * a) >> 32, then (y >> 32) as i32 as i64 * a
+        acc = wadd(acc, (int64_t(uint64_t(s[2])) * int64_t(c.ba[3])) >> 32);
+        acc = wadd(acc, mulw(int32_t(s[3]), c.ba[3]));
+        acc = wadd(acc, (int64_t(uint64_t(s[4])) * int64_t(c.ba[4])) >> 32);
+        acc = wadd(acc, mulw(int32_t(s[5]), c.ba[4]));
+        const uint64_t a = uint64_t(acc) << (32 - c.frac);
+        s[4] = s[2];
+        s[5] = s[3];
+        s[2] = uint32_t(a);
+        s[3] = uint32_t(a >> 32);
+        int32_t y0 = int32_t(s[3]);
+        if (CLAMP) {
+            y0 = clampi(int32_t(uint32_t(y0) + uint32_t(c.u)), c.mn, c.mx);
+            s[3] = uint32_t(y0);  // y[0] = (y0 << 32) | y[0] as u32
+        }
+        return y0;
+    }
+};
+
+// ------------------------------------------------------------ f32 sections
+// src/iir/biquad.rs:366-383 (C = T = A = f32)
+template <bool CLAMP>
+struct Df1F32 {
+    using T = float;
+    using Sec = SecF32;
+    static constexpr int W = 4;
+    static __device__ __forceinline__ float step(const SecF32 &c, uint32_t (&s)[W], float x0)
+    {
+        float acc = c.ba[0] * x0;
+        acc = acc + c.ba[1] * __uint_as_float(s[0]);
+        acc = acc + c.ba[2] * __uint_as_float(s[1]);
+        acc = acc + c.ba[3] * __uint_as_float(s[2]);
+        acc = acc + c.ba[4] * __uint_as_float(s[3]);
+        if (CLAMP) acc = clampf(acc + c.u, c.mn, c.mx);
+        s[1] = s[0];
+        s[0] = __float_as_uint(x0);
+        s[3] = s[2];
+        s[2] = __float_as_uint(acc);
+        return acc;
+    }
+};
+
+// src/iir/biquad.rs:418-440
+template <bool CLAMP>
+struct Df2tF32 {
+    using T = float;
+    using Sec = SecF32;
+    static constexpr int W = 2;  // s0 s1
+    static __device__ __forceinline__ float step(const SecF32 &c, uint32_t (&s)[W], float x0)
+    {
+        float y0 = __uint_as_float(s[0]) + c.ba[0] * x0;
+        if (CLAMP) y0 = clampf(y0 + c.u, c.mn, c.mx);
+        const float n0 = (__uint_as_float(s[1]) + c.ba[1] * x0) + c.ba[3] * y0;
+        const float n1 = c.ba[2] * x0 + c.ba[4] * y0;
+        s[0] = __float_as_uint(n0);
+        s[1] = __float_as_uint(n1);
+        return y0;
+    }
+};
+
+// ------------------------------------------------------------ processors
+// N independent sections in series (`[C] x [S]`, compose.rs:43-77).
+template <class Sec, int N>
+struct Chain {
+    using In = typename Sec::T;
+    using Out = typename Sec::T;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 0;
+    using Params = ChainParams<typename Sec::Sec, N>;
+    uint32_t s[N][Sec::W];
+
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int w = 0; w < Sec::W; w++) s[k][w] = st[size_t(k * Sec::W + w) * lanes + lane];
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int w = 0; w < Sec::W; w++) st[size_t(k * Sec::W + w) * lanes + lane] = s[k][w];
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) x = Sec::step(p.sec[k], s[k], x);
+        return x;
+    }
+};
+
+// `Cascade<[Biquad<C>; N]>` x `DirectForm<T, N>` (biquad.rs:339-364): the input
+// history of section k is the output history of section k-1.
+// Words: h[0..1] = x, h[2+2k..3+2k] = y[k].
+template <class T, int N>
+struct CascadeDf1 {
+    using In = T;
+    using Out = T;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 0;
+    using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32, SecI32>::type;
+    using Params = ChainParams<SecT, N>;
+    static constexpr int W = 2 + 2 * N;
+    uint32_t h[W];
+
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
+    {
+#pragma unroll
+        for (int w = 0; w < W; w++) h[w] = st[size_t(w) * lanes + lane];
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+#pragma unroll
+        for (int w = 0; w < W; w++) st[size_t(w) * lanes + lane] = h[w];
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x0)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            uint32_t *xh = &h[2 * k];
+            const uint32_t *yh = &h[2 * k + 2];
+            T y0;
+            if constexpr (std::is_same<T, float>::value) {
+                const SecF32 &c = p.sec[k];
+                float acc = c.ba[0] * x0;
+                acc = acc + c.ba[1] * __uint_as_float(xh[0]);
+                acc = acc + c.ba[2] * __uint_as_float(xh[1]);
+                acc = acc + c.ba[3] * __uint_as_float(yh[0]);
+                acc = acc + c.ba[4] * __uint_as_float(yh[1]);
+                y0 = acc;
+            } else {
+                const SecI32 &c = p.sec[k];
+                y0 = shr_lo(sum5(c, x0, int32_t(xh[0]), int32_t(xh[1]), int32_t(yh[0]), int32_t(yh[1])), c.frac);
+            }
+            xh[1] = xh[0];
+            xh[0] = __builtin_bit_cast(uint32_t, x0);
+            x0 = y0;
+        }
+        h[2 * N + 1] = h[2 * N];
+        h[2 * N] = __builtin_bit_cast(uint32_t, x0);
+        return x0;
+    }
+};
+
+// ------------------------------------------------------------ host dispatch
+template <class Sec, int N, class CfgFill>
+int run_chain_n(CfgFill fill, size_t first, void *state, const typename Sec::T *x, typename Sec::T *y,
+                size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    typename Chain<Sec, N>::Params prm;
+    for (int k = 0; k < N; k++) fill(prm.sec[k], first + k);
+    uint32_t *st = static_cast<uint32_t *>(state) + first * Sec::W * lanes;
+    return launch_stream<Chain<Sec, N>>(prm, st, x, y, lanes, frames, layout, s);
+}
+
+// n sections in passes of <= kMaxChain: the first pass reads x, later passes
+// run in place on y — literally the reference's slice composition.
+template <class Sec, class CfgFill>
+int run_chain(CfgFill fill, size_t n, void *state, const typename Sec::T *x, typename Sec::T *y,
+              size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    using T = typename Sec::T;
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+    if (n == 0) {  // empty slice: y.copy_from_slice(x), compose.rs:63-65
+        if (x != y) IDSP_HIP_TRY(hipMemcpyAsync(y, x, lanes * frames * sizeof(T), hipMemcpyDeviceToDevice, s));
+        return IDSP_OK;
+    }
+    size_t done = 0;
+    const T *src = x;
+    while (done < n) {
+        const size_t m = n - done < size_t(kMaxChain) ? n - done : size_t(kMaxChain);
+        int rc;
+        switch (m) {
+            case 1: rc = run_chain_n<Sec, 1>(fill, done, state, src, y, lanes, frames, layout, s); break;
+            case 2: rc = run_chain_n<Sec, 2>(fill, done, state, src, y, lanes, frames, layout, s); break;
+            case 3: rc = run_chain_n<Sec, 3>(fill, done, state, src, y, lanes, frames, layout, s); break;
+            default: rc = run_chain_n<Sec, 4>(fill, done, state, src, y, lanes, frames, layout, s); break;
+        }
+        if (rc) return rc;
+        done += m;
+        src = y;
+    }
+    return IDSP_OK;
+}
+
+template <class T, int N, class CfgFill>
+int run_cascade_n(CfgFill fill, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    typename CascadeDf1<T, N>::Params prm;
+    for (int k = 0; k < N; k++) fill(prm.sec[k], size_t(k));
+    return launch_stream<CascadeDf1<T, N>>(prm, state, x, y, lanes, frames, layout, s);
+}
+
+template <class T, class CfgFill>
+int run_cascade(CfgFill fill, size_t n, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout,
+                hipStream_t s)
+{
+    if (n < 1 || n > size_t(kMaxCascade)) return fail(IDSP_EINVAL, "cascade sections n = %zu not in 1..%d", n, kMaxCascade);
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+    switch (n) {
+        case 1: return run_cascade_n<T, 1>(fill, state, x, y, lanes, frames, layout, s);
+        case 2: return run_cascade_n<T, 2>(fill, state, x, y, lanes, frames, layout, s);
+        case 3: return run_cascade_n<T, 3>(fill, state, x, y, lanes, frames, layout, s);
+        case 4: return run_cascade_n<T, 4>(fill, state, x, y, lanes, frames, layout, s);
+        case 5: return run_cascade_n<T, 5>(fill, state, x, y, lanes, frames, layout, s);
+        case 6: return run_cascade_n<T, 6>(fill, state, x, y, lanes, frames, layout, s);
+        case 7: return run_cascade_n<T, 7>(fill, state, x, y, lanes, frames, layout, s);
+        default: return run_cascade_n<T, 8>(fill, state, x, y, lanes, frames, layout, s);
+    }
+}
+
+int check_frac(int frac, size_t k)
+{
+    // `const { assert!(F >= 0 && F < 32) }` biquad.rs:448-450,513-515
+    if (frac < 0 || frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, frac);
+    return IDSP_OK;
+}
+
+struct FillI32 {
+    const idsp_biquad_i32 *c;
+    void operator()(SecI32 &d, size_t k) const
+    {
+        for (int i = 0; i < 5; i++) d.ba[i] = c[k].ba[i];
+        d.frac = c[k].frac;
+        d.u = 0;
+        d.mn = INT32_MIN;
+        d.mx = INT32_MAX;
+    }
+};
+struct FillClampI32 {
+    const idsp_biquad_clamp_i32 *c;
+    void operator()(SecI32 &d, size_t k) const
+    {
+        for (int i = 0; i < 5; i++) d.ba[i] = c[k].ba[i];
+        d.frac = c[k].frac;
+        d.u = c[k].u;
+        d.mn = c[k].min;
+        d.mx = c[k].max;
+    }
+};
+struct FillF32 {
+    const idsp_biquad_f32 *c;
+    void operator()(SecF32 &d, size_t k) const
+    {
+        for (int i = 0; i < 5; i++) d.ba[i] = c[k].ba[i];
+        d.u = 0.f;
+        d.mn = -__builtin_inff();
+        d.mx = __builtin_inff();
+    }
+};
+struct FillClampF32 {
+    const idsp_biquad_clamp_f32 *c;
+    void operator()(SecF32 &d, size_t k) const
+    {
+        for (int i = 0; i < 5; i++) d.ba[i] = c[k].ba[i];
+        d.u = c[k].u;
+        d.mn = c[k].min;
+        d.mx = c[k].max;
+    }
+};
+
+template <class Sec, class Cfg, class Fill>
+int entry_i32(const Cfg *cfg, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+              int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    for (size_t k = 0; k < n; k++)
+        if ((rc = check_frac(cfg[k].frac, k))) return rc;
+    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+template <class Sec, class Cfg, class Fill>
+int entry_f32(const Cfg *cfg, size_t n, void *state, const float *x, float *y, size_t lanes, size_t frames,
+              int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+}  // namespace
+}  // namespace idsp
+
+using namespace idsp;
+
+extern "C" {
+
+int idsp_biquad_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
+                        size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_i32<Df1I32<false>, idsp_biquad_i32, FillI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_i32_df1_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x,
+                              int32_t *y, size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_i32<Df1I32<true>, idsp_biquad_clamp_i32, FillClampI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_i32_dither(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
+                           size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_i32<DitherI32<false>, idsp_biquad_i32, FillI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_i32_dither_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x,
+                                 int32_t *y, size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_i32<DitherI32<true>, idsp_biquad_clamp_i32, FillClampI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_i32_wide(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_i32<WideI32<false>, idsp_biquad_i32, FillI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_i32_wide_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x,
+                               int32_t *y, size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_i32<WideI32<true>, idsp_biquad_clamp_i32, FillClampI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_cascade_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (n > size_t(kMaxCascade)) return fail(IDSP_EINVAL, "cascade sections n = %zu > %d", n, kMaxCascade);
+    for (size_t k = 0; k < n; k++)
+        if ((rc = check_frac(cfg[k].frac, k))) return rc;
+    return run_cascade<int32_t>(FillI32{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+int idsp_biquad_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
+                        size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f32<Df1F32<false>, idsp_biquad_f32, FillF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_f32_df1_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state, const float *x, float *y,
+                              size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f32<Df1F32<true>, idsp_biquad_clamp_f32, FillClampF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_f32_df2t(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f32<Df2tF32<false>, idsp_biquad_f32, FillF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_f32_df2t_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state, const float *x, float *y,
+                               size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f32<Df2tF32<true>, idsp_biquad_clamp_f32, FillClampF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    return run_cascade<float>(FillF32{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// common.h — shared host-side plumbing of libidsp_hip.so (error reporting,
+// argument checks, launch geometry).  gfx950 only; no CPU fallback exists in
+// this library: every processing entry point launches a HIP kernel or fails.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "idsp_hip.h"
+
+namespace idsp {
+
+// thread-local last-error text (include/idsp_hip.h: idsp_last_error)
+char *last_error_buf();
+int fail(int code, const char *fmt, ...);
+
+#define IDSP_HIP_TRY(expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return ::idsp::fail(IDSP_EHIP, "%s: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Checks shared by every lane-streaming entry point (the reference's
+// debug_assert / const-assert preconditions, reported instead of aborting).
+inline int check_stream_args(const void *cfg, size_t n, const void *state, const void *x,
+                             const void *y, size_t lanes, size_t frames, int layout)
+{
+    if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)
+        return fail(IDSP_EINVAL, "layout %d is neither IDSP_FRAME_MAJOR nor IDSP_LANE_MAJOR", layout);
+    if (n > IDSP_MAX_SECTIONS) return fail(IDSP_EINVAL, "n = %zu sections > IDSP_MAX_SECTIONS", n);
+    if (n && !cfg) return fail(IDSP_EINVAL, "cfg is NULL");
+    if (lanes && n && !state) return fail(IDSP_EINVAL, "state is NULL");
+    if (lanes && frames && (!x || !y)) return fail(IDSP_EINVAL, "x or y is NULL");
+    if (lanes > (size_t(1) << 31) || frames > (size_t(1) << 40))
+        return fail(IDSP_EINVAL, "lanes/frames out of range");
+    return IDSP_OK;
+}
+
+inline int launch_status()
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(IDSP_EHIP, "kernel launch: %s", hipGetErrorString(e));
+    return IDSP_OK;
+}
+
+}  // namespace idsp

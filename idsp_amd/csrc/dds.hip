@@ -1,0 +1,305 @@
+// dds.hip — cossin(), the Accu phase-accumulator DDS, Lowpass<N> and the
+// Lockin mixer over many lanes (reference: src/cossin.rs, src/accu.rs,
+// src/lowpass.rs, src/lockin.rs, src/complex.rs).  All integer, bit-exact.
+//
+// cossin's 128-entry LUT (512 B) is staged once per workgroup into LDS from
+// the compile-time table; per-lane gathers then cost an LDS read instead of a
+// divergent constant-memory fetch.  Everything after the gather is ~40 VALU
+// ops in registers, fused in the lock-in kernel with the mixer and the
+// lowpass cascade so a phase never touches memory.
+#include "cossin_table.h"
+#include "lane_stream.h"
+
+namespace idsp {
+namespace {
+
+__device__ const uint32_t d_cossin_table[1 << kCossinDepth] = {
+#define T8(i) kCossinTable[i], kCossinTable[i + 1], kCossinTable[i + 2], kCossinTable[i + 3], \
+              kCossinTable[i + 4], kCossinTable[i + 5], kCossinTable[i + 6], kCossinTable[i + 7]
+    T8(0),  T8(8),  T8(16), T8(24), T8(32), T8(40), T8(48),  T8(56),
+    T8(64), T8(72), T8(80), T8(88), T8(96), T8(104), T8(112), T8(120)
+#undef T8
+};
+
+struct Cplx {
+    int32_t re, im;
+};
+static_assert(sizeof(Cplx) == 8, "Complex<i32> is [re, im]");
+
+// src/cossin.rs:14-67
+__device__ __forceinline__ Cplx cossin_dev(int32_t phase_in, const uint32_t *lut)
+{
+    constexpr int kAlign = 32 - 16 - 1;  // ALIGN_MSB
+    uint32_t octant = uint32_t(phase_in);
+    uint32_t ph = uint32_t(phase_in);
+    if (octant & (1u << 29)) ph = ~ph;  // phase = pi/4 - phase
+    ph = (ph << 3) >> (32 - kCossinDepth - kAlign);
+    const uint32_t lookup = lut[ph >> kAlign];
+    int32_t p = int32_t(ph & ((1u << kAlign) - 1u)) - (1 << (kAlign - 1));
+    constexpr int32_t kPi4 = 51471;  // (FRAC_PI_4 * 65536.0) as i32
+    const int32_t dphi = (p * kPi4) >> 16;
+    int32_t c = int32_t(lookup & 0xffffu) + (1 << 16);
+    int32_t s = int32_t(lookup >> 16);
+    const int32_t dcos = (s * dphi) >> kCossinDepth;
+    const int32_t dsin = (c * dphi) >> (kCossinDepth + 1);
+    c = int32_t(uint32_t(c) << (kAlign - 1)) - dcos;
+    s = int32_t(uint32_t(s) << kAlign) + dsin;
+    octant ^= octant >> 1;
+    if (octant & (1u << 29)) {
+        const int32_t t = c;
+        c = s;
+        s = t;
+    }
+    if (octant & (1u << 30)) c = int32_t(0u - uint32_t(c));
+    if (octant & (1u << 31)) s = int32_t(0u - uint32_t(s));
+    return Cplx{c, s};
+}
+
+__device__ __forceinline__ void fill_cossin(uint32_t *sh, int tid, int nthreads)
+{
+    for (int i = tid; i < (1 << kCossinDepth); i += nthreads) sh[i] = d_cossin_table[i];
+}
+
+// i32::saturating_sub
+__device__ __forceinline__ int32_t sat_sub(int32_t a, int32_t b)
+{
+    const int64_t d = int64_t(a) - int64_t(b);
+    return d > INT32_MAX ? INT32_MAX : (d < INT32_MIN ? INT32_MIN : int32_t(d));
+}
+
+// src/lowpass.rs:47-78; all i64 arithmetic wraps.
+template <int N>
+__device__ __forceinline__ int32_t lowpass_step(const int32_t (&k)[2], uint64_t (&s)[N], int32_t x)
+{
+    uint64_t d = uint64_t(int64_t(sat_sub(x, int32_t(uint32_t(s[0] >> 32)))) * int64_t(k[0]));
+    int32_t y;
+    if constexpr (N == 1) {
+        s[0] += d;
+        y = int32_t(uint32_t(s[0] >> 32));
+        s[0] += d;
+    } else {
+        d += uint64_t(int64_t(int32_t(uint32_t(s[1] >> 32))) * int64_t(k[1]));
+        s[1] += d;
+        s[0] += s[1];
+        y = int32_t(uint32_t(s[0] >> 32));
+        s[0] += s[1];
+        s[1] += d;
+    }
+    return y;
+}
+
+struct LpParams {
+    int32_t k[IDSP_LOCKIN_MAX_CASCADE][2];
+};
+
+template <int N, int K>
+struct LpBank {
+    uint64_t s[K][N];
+    __device__ __forceinline__ void load(const uint32_t *st, size_t lanes, size_t lane, int word0)
+    {
+#pragma unroll
+        for (int c = 0; c < K; c++)
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const size_t w = size_t(word0 + (c * N + j) * 2);
+                s[c][j] = uint64_t(st[w * lanes + lane]) | (uint64_t(st[(w + 1) * lanes + lane]) << 32);
+            }
+    }
+    __device__ __forceinline__ void store(uint32_t *st, size_t lanes, size_t lane, int word0) const
+    {
+#pragma unroll
+        for (int c = 0; c < K; c++)
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const size_t w = size_t(word0 + (c * N + j) * 2);
+                st[w * lanes + lane] = uint32_t(s[c][j]);
+                st[(w + 1) * lanes + lane] = uint32_t(s[c][j] >> 32);
+            }
+    }
+    // `[Lowpass<N>; K]` array composition (dsp-process/src/compose.rs:84-93)
+    __device__ __forceinline__ int32_t step(const LpParams &p, int32_t x)
+    {
+#pragma unroll
+        for (int c = 0; c < K; c++) x = lowpass_step<N>(p.k[c], s[c], x);
+        return x;
+    }
+};
+
+// ------------------------------------------------------------- processors
+template <int N, int K>
+struct LowpassProc {
+    using In = int32_t;
+    using Out = int32_t;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 0;
+    using Params = LpParams;
+    LpBank<N, K> b;
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane) { b.load(st, lanes, lane, 0); }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane) { b.store(st, lanes, lane, 0); }
+    __device__ __forceinline__ Out step(const Params &p, In x) { return b.step(p, x); }
+};
+
+// Accu (src/accu.rs:34-41, pre-increment) -> Complex::from_angle (src/complex.rs:237-240)
+struct DdsProc {
+    using In = int32_t;  // unused
+    using Out = Cplx;
+    static constexpr bool HAS_IN = false;
+    static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    struct Params {
+        int32_t unused;
+    };
+    const uint32_t *lut;
+    uint32_t acc, inc;
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
+    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
+    {
+        acc = st[lane];
+        inc = st[lanes + lane];
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane) { st[lane] = acc; }
+    __device__ __forceinline__ Out step(const Params &, In)
+    {
+        acc += inc;
+        return cossin_dev(int32_t(acc), lut);
+    }
+};
+
+// src/lockin.rs:30-39 -> :17-27.  Mixer `x * Q32<32>` =
+// ((q as i64 * x as i64) >> 32) as i32 (dsp-fixedpoint/src/lib.rs:449-456).
+template <int N, int K>
+struct LockinProc {
+    using In = int32_t;
+    using Out = Cplx;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    using Params = LpParams;
+    const uint32_t *lut;
+    uint32_t acc, inc;
+    LpBank<N, K> bi, bq;
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
+    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
+    {
+        acc = st[lane];
+        inc = st[lanes + lane];
+        bi.load(st, lanes, lane, 2);
+        bq.load(st, lanes, lane, 2 + 2 * N * K);
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+        st[lane] = acc;
+        bi.store(st, lanes, lane, 2);
+        bq.store(st, lanes, lane, 2 + 2 * N * K);
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x)
+    {
+        acc += inc;
+        const Cplx lo = cossin_dev(int32_t(acc), lut);
+        const int32_t xi = __mulhi(lo.re, x);
+        const int32_t xq = __mulhi(lo.im, x);
+        return Cplx{bi.step(p, xi), bq.step(p, xq)};
+    }
+};
+
+__global__ __launch_bounds__(256) void cossin_kernel(const int32_t *phase, Cplx *out, size_t n)
+{
+    __shared__ uint32_t lut[1 << kCossinDepth];
+    fill_cossin(lut, threadIdx.x, 256);
+    __syncthreads();
+    const size_t stride = size_t(gridDim.x) * 256;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) out[i] = cossin_dev(phase[i], lut);
+}
+
+int lockin_cfg_check(const idsp_lockin_i32 *c)
+{
+    if (!c) return fail(IDSP_EINVAL, "cfg is NULL");
+    if (c->order != 1 && c->order != 2) return fail(IDSP_EINVAL, "Lowpass order %d not in {1,2} (src/lowpass.rs:75)", c->order);
+    if (c->cascade < 1 || c->cascade > IDSP_LOCKIN_MAX_CASCADE) return fail(IDSP_EINVAL, "cascade %d not in 1..4", c->cascade);
+    return IDSP_OK;
+}
+
+LpParams lp_params(const idsp_lockin_i32 *c)
+{
+    LpParams p;
+    for (int i = 0; i < IDSP_LOCKIN_MAX_CASCADE; i++) {
+        p.k[i][0] = c->k[i][0];
+        p.k[i][1] = c->k[i][1];
+    }
+    return p;
+}
+
+template <template <int, int> class Proc, class OutT>
+int dispatch_nk(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, OutT *y, size_t lanes, size_t frames,
+                int layout, hipStream_t s)
+{
+    const LpParams p = lp_params(cfg);
+#define IDSP_CASE(N, K) \
+    if (cfg->order == N && cfg->cascade == K) return launch_stream<Proc<N, K>>(p, state, x, y, lanes, frames, layout, s)
+    IDSP_CASE(1, 1);
+    IDSP_CASE(1, 2);
+    IDSP_CASE(1, 3);
+    IDSP_CASE(1, 4);
+    IDSP_CASE(2, 1);
+    IDSP_CASE(2, 2);
+    IDSP_CASE(2, 3);
+    IDSP_CASE(2, 4);
+#undef IDSP_CASE
+    return fail(IDSP_EINVAL, "unsupported lowpass configuration");
+}
+
+}  // namespace
+}  // namespace idsp
+
+using namespace idsp;
+
+extern "C" {
+
+int idsp_cossin_i32(const int32_t *phase, int32_t *out, size_t n, void *stream)
+{
+    if (n && (!phase || !out)) return fail(IDSP_EINVAL, "phase or out is NULL");
+    if (n == 0) return IDSP_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cossin_kernel, dim3(unsigned(blocks)), dim3(256), 0, as_stream(stream), phase,
+                       reinterpret_cast<Cplx *>(out), n);
+    return launch_status();
+}
+
+int idsp_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout, void *stream)
+{
+    if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return fail(IDSP_EINVAL, "bad layout %d", layout);
+    if (lanes && (!state || (frames && !out))) return fail(IDSP_EINVAL, "state or out is NULL");
+    if (lanes == 0) return IDSP_OK;
+    DdsProc::Params p{0};
+    return launch_stream<DdsProc>(p, state, static_cast<const int32_t *>(nullptr), reinterpret_cast<Cplx *>(out), lanes,
+                                  frames, layout, as_stream(stream));
+}
+
+size_t idsp_lockin_state_words(const idsp_lockin_i32 *cfg)
+{
+    if (lockin_cfg_check(cfg)) return 0;
+    return size_t(2 + 2 * cfg->cascade * cfg->order * 2);
+}
+
+int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes,
+                            size_t frames, int layout, void *stream)
+{
+    int rc = lockin_cfg_check(cfg);
+    if (rc) return rc;
+    if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
+    if (lanes == 0) return IDSP_OK;
+    return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, as_stream(stream));
+}
+
+int idsp_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes,
+                     size_t frames, int layout, void *stream)
+{
+    int rc = lockin_cfg_check(cfg);
+    if (rc) return rc;
+    if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
+    if (lanes == 0) return IDSP_OK;
+    return dispatch_nk<LowpassProc, int32_t>(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+}  // extern "C"

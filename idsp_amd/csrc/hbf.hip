@@ -1,0 +1,465 @@
+// hbf.hip — half-band FIR decimator / interpolator cascades over many lanes
+// (reference: src/hbf.rs — `get()` :46-68, `HbfDec` :142-192, `HbfInt`
+// :196-236, cascades :385-421,476-512).
+//
+// Mapping.  One 256-thread workgroup owns one lane (one contiguous stream in
+// LANE_MAJOR) and walks it in chunks of kChunk high-rate samples.  All stages
+// of the cascade run back to back inside the chunk with the inter-stage
+// streams held in LDS — the role of the reference's `Major` scratch buffers
+// (dsp-process/src/compose.rs:581-593) — so HBM sees each input sample once
+// and each output sample once.  The per-stage history that the reference
+// keeps at the front of its state arrays (`copy_within`, src/hbf.rs:182-183,
+// :224) sits in front of each LDS stream buffer and is rolled after every
+// chunk; it is loaded from / stored to the caller's state words at entry /
+// exit, so chunked calls continue bit-exactly.
+//
+// Arithmetic is the reference's, operation for operation: for each output the
+// window sum  Σ_k (new_k + old_k) * tap_k  is accumulated sequentially from
+// the outermost tap (k = 0) inwards starting from -0.0 (`f32::sum`), then the
+// delayed even sample is added.  Compiled with -ffp-contract=off.
+//
+// LDS layout of one stream buffer with history length H:
+//   [ pad d = (4 - H % 4) % 4 | H history words | new samples ... | slack ]
+// so the new samples start 16-byte aligned (wide aligned writes) and a thread
+// that owns outputs i0..i0+3 (i0 % 4 == 0) reads its window with aligned
+// ds_read_b128 from word i0 and addresses it with the compile-time offset d.
+#include <cstring>
+
+#include "common.h"
+
+namespace idsp {
+
+bool hbf_cfg_ok(const idsp_hbf_cascade_f32 *c);  // api_util.hip
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 4096;  // high-rate samples per chunk and lane
+constexpr int kSlack = 16;    // words readable past the last valid sample
+
+struct HbfArgs {
+    int32_t stages;
+    int32_t m[IDSP_HBF_MAX_STAGES];
+    int32_t buf_a[IDSP_HBF_MAX_STAGES];  // LDS word offset: dec even stream / int x stream
+    int32_t buf_b[IDSP_HBF_MAX_STAGES];  // LDS word offset: dec odd stream
+    int32_t st_off[IDSP_HBF_MAX_STAGES + 1];  // state word offset of each stage (+ total)
+    int32_t stage_off;                        // LDS word offset: FRAME_MAJOR output staging
+    float taps[IDSP_HBF_MAX_STAGES][IDSP_HBF_MAX_TAPS];
+};
+
+__host__ __device__ constexpr int pad4(int h) { return (4 - h % 4) % 4; }
+__host__ __device__ constexpr int up4(int v) { return (v + 3) & ~3; }
+
+// Σ_k (w[hi - k] + w[lo + k]) * c[k], k = 0..M-1, sequential from -0.0  (src/hbf.rs:60-66)
+template <int M>
+__device__ __forceinline__ float window_sum(const float *w, int lo, const float (&c)[IDSP_HBF_MAX_TAPS])
+{
+    float acc = -0.0f;
+#pragma unroll
+    for (int k = 0; k < M; k++) acc = acc + (w[lo + 2 * M - 1 - k] + w[lo + k]) * c[k];
+    return acc;
+}
+
+// ---------------------------------------------------------------- decimator
+// One `HbfDec` stage (src/hbf.rs:163-185) for n outputs.
+//   E: even stream, history He = M-1;  O: odd stream, history Ho = 2M-1
+//   y[i] = get(O)[i] + E[i]   (logical indices, 0 = oldest history word)
+// Outputs go either to the next stage's streams as pairs [even, odd] or to
+// global memory.
+template <int M>
+__device__ __forceinline__ void dec_stage(const float *E, const float *O, int n, const float (&taps)[IDSP_HBF_MAX_TAPS],
+                                          float *En, float *On, float *yg, int tid)
+{
+    constexpr int de = pad4(M - 1), dq = pad4(2 * M - 1);
+    constexpr int WO = up4(dq + 2 * M + 3), WE = up4(de + 4);
+    const int nq = (n + 3) >> 2;
+    for (int g = tid; g < nq; g += kThreads) {
+        const int i0 = g * 4;
+        float w[WO], e[WE];
+#pragma unroll
+        for (int v = 0; v < WO / 4; v++) {
+            const float4 t = *reinterpret_cast<const float4 *>(O + i0 + 4 * v);
+            w[4 * v] = t.x, w[4 * v + 1] = t.y, w[4 * v + 2] = t.z, w[4 * v + 3] = t.w;
+        }
+#pragma unroll
+        for (int v = 0; v < WE / 4; v++) {
+            const float4 t = *reinterpret_cast<const float4 *>(E + i0 + 4 * v);
+            e[4 * v] = t.x, e[4 * v + 1] = t.y, e[4 * v + 2] = t.z, e[4 * v + 3] = t.w;
+        }
+        float out[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) out[p] = window_sum<M>(w, dq + p, taps) + e[de + p];
+        if (yg) {
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (i0 + p < n) yg[i0 + p] = out[p];
+        } else {
+            // `ChunkIn<_, 2>`: consecutive outputs pair up as the next [even, odd]
+            *reinterpret_cast<float2 *>(En + (i0 >> 1)) = make_float2(out[0], out[2]);
+            *reinterpret_cast<float2 *>(On + (i0 >> 1)) = make_float2(out[1], out[3]);
+        }
+    }
+}
+
+// runtime-M fallback (arbitrary tap counts): one output per thread and pass
+__device__ void dec_stage_any(int M, const float *E, const float *O, int n, const float *taps, float *En, float *On,
+                              float *yg, int tid)
+{
+    const int de = pad4(M - 1), dq = pad4(2 * M - 1);
+    for (int i = tid; i < n; i += kThreads) {
+        float acc = -0.0f;
+        for (int k = 0; k < M; k++) acc = acc + (O[dq + i + 2 * M - 1 - k] + O[dq + i + k]) * taps[k];
+        const float out = acc + E[de + i];
+        if (yg)
+            yg[i] = out;
+        else if (i & 1)
+            On[i >> 1] = out;
+        else
+            En[i >> 1] = out;
+    }
+}
+
+__device__ __forceinline__ void dec_stage_dispatch(int M, const float *E, const float *O, int n,
+                                                   const float (&taps)[IDSP_HBF_MAX_TAPS], float *En, float *On,
+                                                   float *yg, int tid)
+{
+    switch (M) {
+        case 2: dec_stage<2>(E, O, n, taps, En, On, yg, tid); break;
+        case 3: dec_stage<3>(E, O, n, taps, En, On, yg, tid); break;
+        case 4: dec_stage<4>(E, O, n, taps, En, On, yg, tid); break;
+        case 5: dec_stage<5>(E, O, n, taps, En, On, yg, tid); break;
+        case 6: dec_stage<6>(E, O, n, taps, En, On, yg, tid); break;
+        case 10: dec_stage<10>(E, O, n, taps, En, On, yg, tid); break;
+        case 15: dec_stage<15>(E, O, n, taps, En, On, yg, tid); break;
+        case 23: dec_stage<23>(E, O, n, taps, En, On, yg, tid); break;
+        default: dec_stage_any(M, E, O, n, taps, En, On, yg, tid); break;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void hbf_dec_kernel(const HbfArgs a, uint32_t *st, const float *x, float *y,
+                                                           const size_t lanes, const size_t frames, const int lane_major)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const size_t lane = blockIdx.x;
+    const int S = a.stages;
+    const int R = 1 << S;
+
+    // history <- state words (per stage: even[M-1] then odd[2M-1], oldest first)
+    for (int s = 0; s < S; s++) {
+        const int M = a.m[s], He = M - 1, Ho = 2 * M - 1;
+        float *E = lds + a.buf_a[s] + pad4(He), *O = lds + a.buf_b[s] + pad4(Ho);
+        for (int w = tid; w < He + Ho; w += kThreads) {
+            const float v = __uint_as_float(st[size_t(a.st_off[s] + w) * lanes + lane]);
+            if (w < He)
+                E[w] = v;
+            else
+                O[w - He] = v;
+        }
+    }
+
+    const size_t ch = size_t(kChunk >> S);  // output frames per chunk
+    const int M0 = a.m[0];
+    float *E0n = lds + a.buf_a[0] + up4(M0 - 1), *O0n = lds + a.buf_b[0] + up4(2 * M0 - 1);
+    const bool vec4 = lane_major && ((frames * size_t(R)) % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    float *ystage = lds + a.stage_off;
+
+    for (size_t f0 = 0; f0 < frames; f0 += ch) {
+        const int nf = int(frames - f0 < ch ? frames - f0 : ch);
+        const int nin = nf * R;
+        // stage-0 input: pairs [even, odd] split into the two streams
+        if (vec4) {
+            const float4 *x4 = reinterpret_cast<const float4 *>(x + (lane * frames + f0) * size_t(R));
+            for (int q = tid; q < nin / 4; q += kThreads) {
+                const float4 v = x4[q];
+                *reinterpret_cast<float2 *>(E0n + 2 * q) = make_float2(v.x, v.z);
+                *reinterpret_cast<float2 *>(O0n + 2 * q) = make_float2(v.y, v.w);
+            }
+        } else {
+            const int ppf = R / 2;  // pairs per frame
+            for (int q = tid; q < nin / 2; q += kThreads) {
+                const size_t f = f0 + size_t(q / ppf);
+                const size_t base = lane_major ? (lane * frames + f) * size_t(R) : (f * lanes + lane) * size_t(R);
+                const float2 v = *reinterpret_cast<const float2 *>(x + base + size_t(q % ppf) * 2);
+                E0n[q] = v.x;
+                O0n[q] = v.y;
+            }
+        }
+        __syncthreads();
+
+        int n = nin;
+        for (int s = 0; s < S; s++) {
+            n >>= 1;
+            const int M = a.m[s];
+            const float *E = lds + a.buf_a[s], *O = lds + a.buf_b[s];
+            if (s + 1 < S) {
+                const int Mn = a.m[s + 1];
+                dec_stage_dispatch(M, E, O, n, a.taps[s], lds + a.buf_a[s + 1] + up4(Mn - 1),
+                                   lds + a.buf_b[s + 1] + up4(2 * Mn - 1), nullptr, tid);
+            } else {
+                float *yg = lane_major ? y + lane * frames + f0 : nullptr;
+                if (lane_major) {
+                    dec_stage_dispatch(M, E, O, n, a.taps[s], nullptr, nullptr, yg, tid);
+                } else {
+                    // FRAME_MAJOR outputs are `lanes` apart: stage them in LDS first
+                    dec_stage_dispatch(M, E, O, n, a.taps[s], nullptr, nullptr, ystage, tid);
+                }
+            }
+            __syncthreads();
+        }
+        if (!lane_major) {
+            for (int i = tid; i < nf; i += kThreads) y[(f0 + size_t(i)) * lanes + lane] = ystage[i];
+            __syncthreads();
+        }
+
+        // roll the histories: word j <- word n_s + j (src/hbf.rs:182-183)
+        float keep[2];
+        int c = 0;
+        for (int w = tid; w < a.st_off[S]; w += kThreads, c++) {
+            int s = 0;
+            while (w >= a.st_off[s + 1]) s++;
+            const int M = a.m[s], He = M - 1, j = w - a.st_off[s];
+            const int ns = nin >> (s + 1);
+            keep[c & 1] = j < He ? lds[a.buf_a[s] + pad4(He) + ns + j] : lds[a.buf_b[s] + pad4(2 * M - 1) + ns + (j - He)];
+        }
+        __syncthreads();
+        c = 0;
+        for (int w = tid; w < a.st_off[S]; w += kThreads, c++) {
+            int s = 0;
+            while (w >= a.st_off[s + 1]) s++;
+            const int M = a.m[s], He = M - 1, j = w - a.st_off[s];
+            if (j < He)
+                lds[a.buf_a[s] + pad4(He) + j] = keep[c & 1];
+            else
+                lds[a.buf_b[s] + pad4(2 * M - 1) + (j - He)] = keep[c & 1];
+        }
+        __syncthreads();
+    }
+
+    for (int w = tid; w < a.st_off[S]; w += kThreads) {
+        int s = 0;
+        while (w >= a.st_off[s + 1]) s++;
+        const int M = a.m[s], He = M - 1, j = w - a.st_off[s];
+        const float v = j < He ? lds[a.buf_a[s] + pad4(He) + j] : lds[a.buf_b[s] + pad4(2 * M - 1) + (j - He)];
+        st[size_t(w) * lanes + lane] = __float_as_uint(v);
+    }
+}
+
+// -------------------------------------------------------------- interpolator
+// One `HbfInt` stage (src/hbf.rs:207-227) for n inputs -> n pairs:
+//   [get(X)[i], X[M + i]]  (interpolated sample, then the centre-tap identity).
+template <int M>
+__device__ __forceinline__ void int_stage(const float *X, int n, const float (&taps)[IDSP_HBF_MAX_TAPS], float *Xn,
+                                          float *yg, bool yvec, int tid)
+{
+    constexpr int dx = pad4(2 * M - 1);
+    constexpr int WX = up4(dx + 2 * M + 3);
+    const int nq = (n + 3) >> 2;
+    for (int g = tid; g < nq; g += kThreads) {
+        const int i0 = g * 4;
+        float w[WX];
+#pragma unroll
+        for (int v = 0; v < WX / 4; v++) {
+            const float4 t = *reinterpret_cast<const float4 *>(X + i0 + 4 * v);
+            w[4 * v] = t.x, w[4 * v + 1] = t.y, w[4 * v + 2] = t.z, w[4 * v + 3] = t.w;
+        }
+        float out[8];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            out[2 * p] = window_sum<M>(w, dx + p, taps);
+            out[2 * p + 1] = w[dx + M + p];
+        }
+        if (yg) {
+            if (yvec && i0 + 4 <= n) {
+                *reinterpret_cast<float4 *>(yg + 2 * i0) = make_float4(out[0], out[1], out[2], out[3]);
+                *reinterpret_cast<float4 *>(yg + 2 * i0 + 4) = make_float4(out[4], out[5], out[6], out[7]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 8; p++)
+                    if (2 * i0 + p < 2 * n) yg[2 * i0 + p] = out[p];
+            }
+        } else {
+            // `ChunkOut<_, 2>`: the pairs flatten into the next stage's input stream
+            *reinterpret_cast<float4 *>(Xn + 2 * i0) = make_float4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<float4 *>(Xn + 2 * i0 + 4) = make_float4(out[4], out[5], out[6], out[7]);
+        }
+    }
+}
+
+__device__ void int_stage_any(int M, const float *X, int n, const float *taps, float *Xn, float *yg, int tid)
+{
+    const int dx = pad4(2 * M - 1);
+    for (int i = tid; i < n; i += kThreads) {
+        float acc = -0.0f;
+        for (int k = 0; k < M; k++) acc = acc + (X[dx + i + 2 * M - 1 - k] + X[dx + i + k]) * taps[k];
+        float *dst = yg ? yg : Xn;
+        dst[2 * i] = acc;
+        dst[2 * i + 1] = X[dx + M + i];
+    }
+}
+
+__device__ __forceinline__ void int_stage_dispatch(int M, const float *X, int n, const float (&taps)[IDSP_HBF_MAX_TAPS],
+                                                   float *Xn, float *yg, bool yvec, int tid)
+{
+    switch (M) {
+        case 2: int_stage<2>(X, n, taps, Xn, yg, yvec, tid); break;
+        case 3: int_stage<3>(X, n, taps, Xn, yg, yvec, tid); break;
+        case 4: int_stage<4>(X, n, taps, Xn, yg, yvec, tid); break;
+        case 5: int_stage<5>(X, n, taps, Xn, yg, yvec, tid); break;
+        case 6: int_stage<6>(X, n, taps, Xn, yg, yvec, tid); break;
+        case 10: int_stage<10>(X, n, taps, Xn, yg, yvec, tid); break;
+        case 15: int_stage<15>(X, n, taps, Xn, yg, yvec, tid); break;
+        case 23: int_stage<23>(X, n, taps, Xn, yg, yvec, tid); break;
+        default: int_stage_any(M, X, n, taps, Xn, yg, tid); break;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void hbf_int_kernel(const HbfArgs a, uint32_t *st, const float *x, float *y,
+                                                           const size_t lanes, const size_t frames, const int lane_major)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const size_t lane = blockIdx.x;
+    const int S = a.stages;
+    const int R = 1 << S;
+
+    for (int s = 0; s < S; s++) {
+        const int H = 2 * a.m[s] - 1;
+        float *X = lds + a.buf_a[s] + pad4(H);
+        for (int w = tid; w < H; w += kThreads) X[w] = __uint_as_float(st[size_t(a.st_off[s] + w) * lanes + lane]);
+    }
+
+    const size_t ch = size_t(kChunk >> S);  // input frames per chunk
+    float *X0n = lds + a.buf_a[0] + up4(2 * a.m[0] - 1);
+    float *ystage = lds + a.stage_off;  // FRAME_MAJOR output chunks
+
+    for (size_t f0 = 0; f0 < frames; f0 += ch) {
+        const int nf = int(frames - f0 < ch ? frames - f0 : ch);
+        for (int i = tid; i < nf; i += kThreads)
+            X0n[i] = lane_major ? x[lane * frames + f0 + size_t(i)] : x[(f0 + size_t(i)) * lanes + lane];
+        __syncthreads();
+
+        int n = nf;
+        for (int s = 0; s < S; s++) {
+            const int M = a.m[s];
+            const float *X = lds + a.buf_a[s];
+            if (s + 1 < S) {
+                int_stage_dispatch(M, X, n, a.taps[s], lds + a.buf_a[s + 1] + up4(2 * a.m[s + 1] - 1), nullptr, false, tid);
+            } else if (lane_major) {
+                float *yg = y + (lane * frames + f0) * size_t(R);
+                const bool yvec = reinterpret_cast<uintptr_t>(yg) % 16 == 0;
+                int_stage_dispatch(M, X, n, a.taps[s], nullptr, yg, yvec, tid);
+            } else {
+                int_stage_dispatch(M, X, n, a.taps[s], ystage, nullptr, false, tid);
+            }
+            __syncthreads();
+            n <<= 1;
+        }
+        if (!lane_major) {
+            for (int i = tid; i < nf * R; i += kThreads)
+                y[((f0 + size_t(i / R)) * lanes + lane) * size_t(R) + size_t(i % R)] = ystage[i];
+            __syncthreads();
+        }
+
+        // roll histories: word j <- word n_s + j (src/hbf.rs:224)
+        float keep[2];
+        int c = 0;
+        for (int w = tid; w < a.st_off[S]; w += kThreads, c++) {
+            int s = 0;
+            while (w >= a.st_off[s + 1]) s++;
+            const int H = 2 * a.m[s] - 1, j = w - a.st_off[s];
+            keep[c & 1] = lds[a.buf_a[s] + pad4(H) + (nf << s) + j];
+        }
+        __syncthreads();
+        c = 0;
+        for (int w = tid; w < a.st_off[S]; w += kThreads, c++) {
+            int s = 0;
+            while (w >= a.st_off[s + 1]) s++;
+            const int H = 2 * a.m[s] - 1, j = w - a.st_off[s];
+            lds[a.buf_a[s] + pad4(H) + j] = keep[c & 1];
+        }
+        __syncthreads();
+    }
+
+    for (int w = tid; w < a.st_off[S]; w += kThreads) {
+        int s = 0;
+        while (w >= a.st_off[s + 1]) s++;
+        const int H = 2 * a.m[s] - 1, j = w - a.st_off[s];
+        st[size_t(w) * lanes + lane] = __float_as_uint(lds[a.buf_a[s] + pad4(H) + j]);
+    }
+}
+
+// ------------------------------------------------------------------- host
+int fill_args(const idsp_hbf_cascade_f32 *cfg, bool dec, HbfArgs &a, int &lds_words)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.stages = cfg->stages;
+    int off = 0, so = 0;
+    for (int s = 0; s < cfg->stages; s++) {
+        const int M = cfg->m[s];
+        a.m[s] = M;
+        for (int k = 0; k < M; k++) a.taps[s][k] = cfg->taps[s][k];
+        a.st_off[s] = so;
+        if (dec) {
+            const int n = kChunk >> (s + 1);  // outputs of stage s per chunk = samples per stream
+            a.buf_a[s] = off;
+            off += up4(up4(M - 1) + n + kSlack);
+            a.buf_b[s] = off;
+            off += up4(up4(2 * M - 1) + n + kSlack + 2 * M);
+            so += 3 * M - 2;
+        } else {
+            const int n = (kChunk >> cfg->stages) << s;  // inputs of stage s per chunk
+            a.buf_a[s] = off;
+            off += up4(up4(2 * M - 1) + n + kSlack + 2 * M);
+            so += 2 * M - 1;
+        }
+    }
+    a.st_off[cfg->stages] = so;
+    a.stage_off = off;  // FRAME_MAJOR output staging: one chunk of outputs
+    off += (dec ? kChunk / 2 : kChunk) + kSlack;
+    lds_words = off;
+    return IDSP_OK;
+}
+
+template <class K>
+int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state, const float *x, float *y, size_t lanes,
+               size_t frames, int layout, void *stream)
+{
+    if (!hbf_cfg_ok(cfg)) return fail(IDSP_EINVAL, "invalid hbf cascade (stages 1..5, taps 1..32 per stage)");
+    if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return fail(IDSP_EINVAL, "bad layout %d", layout);
+    if (lanes && (!state || (frames && (!x || !y)))) return fail(IDSP_EINVAL, "state, x or y is NULL");
+    if (lanes > (size_t(1) << 31) - 1 || frames > (size_t(1) << 40)) return fail(IDSP_EINVAL, "lanes/frames out of range");
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+    if (reinterpret_cast<uintptr_t>(x) % 8 || reinterpret_cast<uintptr_t>(y) % 8)
+        return fail(IDSP_EINVAL, "x and y must be 8-byte aligned");
+    HbfArgs a;
+    int lds_words = 0;
+    fill_args(cfg, dec, a, lds_words);
+    const size_t bytes = size_t(lds_words) * sizeof(float);
+    if (bytes > 64 * 1024)
+        IDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    hipLaunchKernelGGL(kernel, dim3(unsigned(lanes)), dim3(kThreads), bytes, as_stream(stream), a,
+                       static_cast<uint32_t *>(state), x, y, lanes, frames, layout == IDSP_LANE_MAJOR ? 1 : 0);
+    return launch_status();
+}
+
+}  // namespace
+}  // namespace idsp
+
+using namespace idsp;
+
+extern "C" {
+
+int idsp_hbf_dec_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y, size_t lanes,
+                     size_t frames, int layout, void *stream)
+{
+    return launch_hbf(hbf_dec_kernel, cfg, true, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y, size_t lanes,
+                     size_t frames, int layout, void *stream)
+{
+    return launch_hbf(hbf_int_kernel, cfg, false, state, x, y, lanes, frames, layout, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+// lane_stream.h — the two streaming kernels every per-lane recurrence of the
+// hot path runs through (biquad family, lowpass, DDS, lock-in).
+//
+// Replaces "L2 block loop x L3 process body x N lanes" of the reference
+// (dsp-process/src/process.rs:122-127,137-141 driven by Lanes,
+// dsp-process/src/compose.rs:468-494) by ONE launch:
+//   * one lane per thread; the serially dependent recurrence state lives in
+//     VGPRs for the whole call and is read/written once (word-plane-major
+//     state, include/idsp_hip.h);
+//   * the shared configuration arrives as a kernarg POD, i.e. in SGPRs —
+//     uniform across the wave, no LDS or vector loads on the hot loop;
+//   * FRAME_MAJOR: a wave reads one 256-byte row segment per frame through a
+//     rotating register window that requests frame f+U before frame f is
+//     consumed, so a wave keeps U row segments in flight at all times (HBM
+//     latency >> per-sample work, and at 64k lanes there is exactly one wave
+//     per SIMD — no other wave hides it);
+//   * LANE_MAJOR: adjacent lanes are `frames` elements apart, so a wave moves
+//     64-lane x TS-sample tiles through a padded LDS tile: row-contiguous
+//     (coalesced) global accesses on one side, conflict-free column walks by
+//     the owning thread on the other.
+//
+// A processor P provides:
+//   using In / Out;            element types (Out may be a 2-word struct)
+//   static constexpr bool HAS_IN;
+//   struct Params;             POD, passed by value as kernarg
+//   load(prm, st, lanes, lane) / store(...)   state <-> registers
+//   Out step(prm, In x)        one sample of the reference `process()`
+//   static constexpr int LDS_WORDS;   read-only table words (0 = none), filled
+//   by static fill_shared(uint32_t*) with the whole block and handed to the
+//   processor through set_shared(const uint32_t*).
+#pragma once
+
+#include "common.h"
+
+namespace idsp {
+
+constexpr int kWave = 64;
+constexpr int kFmBlock = 256;  // 4 waves: one per SIMD of a CU, 1 KiB row segment per block
+
+// ---------------------------------------------------------------- FRAME_MAJOR
+template <class P, int U>
+__global__ __launch_bounds__(kFmBlock) void stream_frame_major(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const size_t lanes, const size_t frames)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    __shared__ uint32_t ptab[P::LDS_WORDS ? P::LDS_WORDS : 1];
+    if constexpr (P::LDS_WORDS > 0) {
+        P::fill_shared(ptab, threadIdx.x, kFmBlock);
+        __syncthreads();
+    }
+    const size_t lane = size_t(blockIdx.x) * kFmBlock + threadIdx.x;
+    if (lane >= lanes) return;
+
+    P p;
+    if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
+    p.load(prm, st, lanes, lane);
+
+    const In *xp = x + lane;
+    Out *yp = y + lane;
+
+    if constexpr (P::HAS_IN) {
+        // Rotating register window: frame f + U is requested right before frame
+        // f is consumed, so U row segments per wave are in flight at all
+        // times (vmcnt is in-order: the wait for frame f tolerates the U-1
+        // younger loads and the interleaved stores).  Reads always run ahead of
+        // this thread's writes, so y == x is safe.
+        In ring[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (size_t(u) < frames) ring[u] = xp[size_t(u) * lanes];
+        size_t f = 0;
+        for (; f + 2 * U <= frames; f += U) {
+            const In *xn = xp + (f + U) * lanes;
+            Out *yn = yp + f * lanes;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const In v = ring[u];
+                ring[u] = xn[size_t(u) * lanes];
+                yn[size_t(u) * lanes] = p.step(prm, v);
+            }
+        }
+        // drain: fewer than 2U frames left, predicates are wave-uniform
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t fr = f + u;
+            if (fr < frames) {
+                const In v = ring[u];
+                if (fr + U < frames) ring[u] = xp[(fr + U) * lanes];
+                yp[fr * lanes] = p.step(prm, v);
+            }
+        }
+        f += U;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t fr = f + u;
+            if (fr < frames) yp[fr * lanes] = p.step(prm, ring[u]);
+        }
+    } else {
+        for (size_t f = 0; f < frames; f++) {
+            *yp = p.step(prm, In{});
+            yp += lanes;
+        }
+    }
+    p.store(prm, st, lanes, lane);
+}
+
+// ----------------------------------------------------------------- LANE_MAJOR
+// One wave per workgroup; tiles are wave-private, so the barriers below only
+// order this wave's own LDS traffic.
+template <class P>
+__global__ __launch_bounds__(kWave) void stream_lane_major(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const size_t lanes, const size_t frames)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    static_assert(sizeof(In) == 4, "inputs are one 32-bit word");
+    constexpr int OW = sizeof(Out) / 4;  // output words per sample
+    static_assert(OW == 1 || OW == 2, "outputs are one or two 32-bit words");
+    constexpr int TS = kWave / OW;       // samples per tile and lane; out row = 64 words
+    constexpr int RPI = kWave / TS;      // tile rows covered by one load instruction
+    constexpr bool kAlias = P::HAS_IN && OW == 1;
+
+    __shared__ uint32_t tin[P::HAS_IN ? kWave : 1][TS + 1];
+    __shared__ uint32_t tout_[kAlias ? 1 : kWave][kWave + 1];
+    uint32_t(*tout)[kWave + 1] = kAlias ? reinterpret_cast<uint32_t(*)[kWave + 1]>(tin) : tout_;
+
+    const int lid = threadIdx.x;
+    const size_t lane0 = size_t(blockIdx.x) * kWave;
+    const size_t lane = lane0 + lid;
+    const bool active = lane < lanes;
+    const size_t nrows = lanes - lane0 < size_t(kWave) ? lanes - lane0 : size_t(kWave);
+
+    __shared__ uint32_t ptab[P::LDS_WORDS ? P::LDS_WORDS : 1];
+    if constexpr (P::LDS_WORDS > 0) P::fill_shared(ptab, lid, kWave);  // published by the first tile barrier
+
+    P p;
+    if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
+    if (active) p.load(prm, st, lanes, lane);
+
+    const uint32_t *xw = reinterpret_cast<const uint32_t *>(x);
+    uint32_t *yw = reinterpret_cast<uint32_t *>(y);
+    // element (row r, col c) handled by this thread in load instruction i
+    const int lrow = lid / TS, lcol = lid % TS;
+
+    uint32_t stage[TS];
+    auto fetch = [&](size_t t0) {
+        if constexpr (P::HAS_IN) {
+            const size_t ncols = frames - t0 < size_t(TS) ? frames - t0 : size_t(TS);
+#pragma unroll
+            for (int i = 0; i < TS; i++) {
+                const size_t r = size_t(i) * RPI + lrow;
+                stage[i] = (r < nrows && size_t(lcol) < ncols) ? xw[(lane0 + r) * frames + t0 + lcol] : 0u;
+            }
+        }
+    };
+
+    fetch(0);
+    for (size_t t0 = 0; t0 < frames; t0 += TS) {
+        const size_t ncols = frames - t0 < size_t(TS) ? frames - t0 : size_t(TS);
+        if constexpr (P::HAS_IN) {
+#pragma unroll
+            for (int i = 0; i < TS; i++) tin[i * RPI + lrow][lcol] = stage[i];
+        }
+        __syncthreads();
+        if (t0 + TS < frames) fetch(t0 + TS);  // next tile in flight during the arithmetic
+
+        if (active) {
+            if (ncols == size_t(TS)) {
+#pragma unroll
+                for (int j = 0; j < TS; j++) {
+                    In v{};
+                    if constexpr (P::HAS_IN) v = __builtin_bit_cast(In, tin[lid][j]);
+                    const Out o = p.step(prm, v);
+                    if constexpr (OW == 1) {
+                        tout[lid][j] = __builtin_bit_cast(uint32_t, o);
+                    } else {
+                        const uint2 w = __builtin_bit_cast(uint2, o);
+                        tout[lid][2 * j] = w.x;
+                        tout[lid][2 * j + 1] = w.y;
+                    }
+                }
+            } else {
+                for (size_t j = 0; j < ncols; j++) {
+                    In v{};
+                    if constexpr (P::HAS_IN) v = __builtin_bit_cast(In, tin[lid][j]);
+                    const Out o = p.step(prm, v);
+                    if constexpr (OW == 1) {
+                        tout[lid][j] = __builtin_bit_cast(uint32_t, o);
+                    } else {
+                        const uint2 w = __builtin_bit_cast(uint2, o);
+                        tout[lid][2 * j] = w.x;
+                        tout[lid][2 * j + 1] = w.y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // row-contiguous stores: one instruction = 64 consecutive words of one lane
+        const size_t nw = ncols * OW;
+        for (size_t r = 0; r < nrows; r++) {
+            if (size_t(lid) < nw) yw[((lane0 + r) * frames + t0) * OW + lid] = tout[r][lid];
+        }
+        __syncthreads();
+    }
+    if (active) p.store(prm, st, lanes, lane);
+}
+
+// --------------------------------------------------------------------- launch
+// Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
+// latency, so go deep; with many resident waves keep the register budget low.
+template <class P>
+int launch_stream(const typename P::Params &prm, void *state, const typename P::In *x,
+                  typename P::Out *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    if (lanes == 0) return IDSP_OK;
+    uint32_t *st = static_cast<uint32_t *>(state);
+    if (layout == IDSP_LANE_MAJOR) {
+        const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
+        hipLaunchKernelGGL((stream_lane_major<P>), dim3(grid), dim3(kWave), 0, s, prm, st, x, y, lanes, frames);
+    } else {
+        const unsigned grid = unsigned((lanes + kFmBlock - 1) / kFmBlock);
+        const size_t waves = (lanes + kWave - 1) / kWave;
+        if (waves <= 2048)
+            hipLaunchKernelGGL((stream_frame_major<P, 24>), dim3(grid), dim3(kFmBlock), 0, s, prm, st, x, y, lanes, frames);
+        else
+            hipLaunchKernelGGL((stream_frame_major<P, 8>), dim3(grid), dim3(kFmBlock), 0, s, prm, st, x, y, lanes, frames);
+    }
+    return launch_status();
+}
+
+}  // namespace idsp

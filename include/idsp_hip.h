@@ -1,0 +1,310 @@
+/*
+ * idsp_hip.h — C ABI of libidsp_hip.so, the MI355X (gfx950) bulk engine for the
+ * per-sample filter hot path of quartiq/idsp.
+ *
+ * This header is the drop-in boundary: every entry point replaces one
+ * `dsp_process::{SplitProcess::block, SplitInplace::inplace,
+ * SplitViewProcess::process_view}` call of the reference, executed for many
+ * independent lanes at once.  Citations are `path:line` inside the reference
+ * tree (idsp 0.22.0).  A Rust `extern "C"` block binding these symbols is shown
+ * in INTEGRATION.md.
+ *
+ * Conventions common to all processing entry points
+ * --------------------------------------------------
+ *  - plain C types only; `x`, `y`, `state` are DEVICE pointers owned by the
+ *    caller; `stream` is a `hipStream_t` passed as `void*` (NULL = default
+ *    stream).  Calls are asynchronous on that stream.
+ *  - the library never allocates hidden memory and keeps no mutable globals
+ *    apart from the thread-local last-error string.
+ *  - `lanes`  = number of independent channels (reference: const generic `N` of
+ *    `Lanes<C>` / `[S; N]`, dsp-process/src/compose.rs:449-513).
+ *    `frames` = samples per lane in this call (reference: slice length).
+ *  - `layout` selects the two memory layouts of dsp-process/src/view.rs:10-17:
+ *      IDSP_FRAME_MAJOR  `[[T; lanes]; frames]`  element (f, l) at `f*lanes + l`
+ *      IDSP_LANE_MAJOR   `lanes` contiguous slices, element (f, l) at `l*frames + f`
+ *    (view.rs:190-195 `lane(i) = flat[i*frames..]`).
+ *  - `y == x` (in-place, reference `inplace()`) is allowed for all same-rate
+ *    operators; partial overlap is not.
+ *  - `state` is read at entry and written back at exit, so consecutive calls
+ *    continue the stream exactly as consecutive `block()` calls do in the
+ *    reference.  A zero-filled state is the reference's `Default::default()`.
+ *    The reference state structs carry no `repr(C)` (src/iir/biquad.rs:258-269),
+ *    so this ABI fixes its own record: a state is a sequence of 32-bit words per
+ *    lane, stored WORD-PLANE-MAJOR on the device for coalescing:
+ *        word w of lane l  ->  ((uint32_t*)state)[w * lanes + l]
+ *    64-bit fields occupy two consecutive words (low word first).  The word
+ *    lists are given with each operator below; idsp_*_state_words() return the
+ *    counts.
+ *  - return value: IDSP_OK (0) or a negative idsp_status.  Shape / parameter
+ *    violations that are `debug_assert!`/`const assert!` in the reference
+ *    (dsp-process/src/process.rs:42-45, src/iir/biquad.rs:448-450) are reported
+ *    as IDSP_EINVAL; the library never aborts.  idsp_last_error() returns a
+ *    thread-local description of the most recent failure.
+ */
+#ifndef IDSP_HIP_H
+#define IDSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDSP_ABI_VERSION 1
+
+typedef enum idsp_status {
+    IDSP_OK = 0,
+    IDSP_EINVAL = -1,  /* bad shape / parameter (reference: debug_assert / const assert) */
+    IDSP_EHIP = -2,    /* HIP runtime error, text in idsp_last_error() */
+    IDSP_ENODEV = -3   /* no usable gfx950 device */
+} idsp_status;
+
+typedef enum idsp_layout {
+    IDSP_FRAME_MAJOR = 0, /* dsp-process/src/view.rs:10  */
+    IDSP_LANE_MAJOR = 1   /* dsp-process/src/view.rs:17  */
+} idsp_layout;
+
+/* Maximum number of serial sections accepted per call (slice composition
+ * `[C] x [S]`, dsp-process/src/compose.rs:43-77). */
+#define IDSP_MAX_SECTIONS 64
+
+/* ------------------------------------------------------------------------ */
+/* library / device utilities                                               */
+/* ------------------------------------------------------------------------ */
+
+/* IDSP_ABI_VERSION the library was built with. */
+int idsp_version(void);
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char *idsp_last_error(void);
+/* Number of visible HIP devices, or a negative idsp_status. */
+int idsp_device_count(void);
+/* Select the device used by subsequent calls of this thread. */
+int idsp_device_set(int device);
+/* Plain device-memory helpers so a host language without a HIP binding (the
+ * Rust shim, ctypes) can own buffers.  Not used on the hot path. */
+int idsp_device_alloc(void **ptr, size_t bytes);
+int idsp_device_free(void *ptr);
+int idsp_device_memset(void *ptr, int value, size_t bytes, void *stream);
+int idsp_device_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int idsp_device_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int idsp_stream_sync(void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* iir::Biquad — fixed point (src/iir/biquad.rs)                            */
+/* ------------------------------------------------------------------------ */
+
+/* `Biquad<Q32<F>>` (src/iir/biquad.rs:96-116): ba = [b0,b1,b2,a1,a2] raw Q bits
+ * with a1,a2 stored exactly as used in the recurrence; frac = F, 0 <= F < 32. */
+typedef struct idsp_biquad_i32 {
+    int32_t ba[5];
+    int32_t frac;
+} idsp_biquad_i32;
+
+/* `BiquadClamp<Q32<F>, i32>` (src/iir/biquad.rs:121-157). */
+typedef struct idsp_biquad_clamp_i32 {
+    int32_t ba[5];
+    int32_t frac;
+    int32_t u;   /* summing junction offset */
+    int32_t min; /* lower limit */
+    int32_t max; /* upper limit */
+} idsp_biquad_clamp_i32;
+
+/* `Biquad<f32>`. */
+typedef struct idsp_biquad_f32 {
+    float ba[5];
+} idsp_biquad_f32;
+
+/* `BiquadClamp<f32, f32>`. */
+typedef struct idsp_biquad_clamp_f32 {
+    float ba[5];
+    float u;
+    float min;
+    float max;
+} idsp_biquad_clamp_f32;
+
+/* Coefficient ingestion, host side, once per configuration.
+ * `From<[[f64;3];2]> for Biquad<C>` (src/iir/biquad.rs:545-566) followed by the
+ * float -> Q conversion `round(v * 2^F)` saturating, NaN -> 0
+ * (dsp-fixedpoint/src/num_traits_impl.rs:32-46).  sos = [b0,b1,b2,a0,a1,a2]
+ * with the literature sign of a1/a2 (this is also the row format of
+ * `sos()` in src/py.rs:49-73). */
+int idsp_biquad_i32_from_sos(const double sos[6], int frac, idsp_biquad_i32 *out);
+/* Same normalisation evaluated in f32 (`From<[[f32;3];2]> for Biquad<f32>`). */
+int idsp_biquad_f32_from_sos(const float sos[6], idsp_biquad_f32 *out);
+/* Same normalisation evaluated in f64, then each coefficient cast `as f32`
+ * (`From<[f64;5]> for Biquad<f32>`, src/iir/biquad.rs:570-576). */
+int idsp_biquad_f32_from_sos_f64(const double sos[6], idsp_biquad_f32 *out);
+
+/* All idsp_biquad_* / idsp_cascade_* calls process `n` serial sections
+ * (1 <= n <= IDSP_MAX_SECTIONS; `cfg` points at n host-side records; n == 0 is
+ * the reference's empty-slice identity, compose.rs:63-65).  Section s owns the
+ * state words [s*W, (s+1)*W).
+ *
+ * state words per section (W):
+ *   DF1        `DirectForm1<T>`        W=4  { x0, x1, y0, y1 }        biquad.rs:260-269,319
+ *   DF1 dither `DirectForm1Dither`     W=5  { x0, x1, y0, y1, e }     biquad.rs:484-491
+ *   DF1 wide   `DirectForm1Wide`       W=6  { x0, x1, y0.lo, y0.hi, y1.lo, y1.hi }  biquad.rs:445-454
+ *   DF2T       `DirectForm2Transposed` W=2  { s0, s1 }                biquad.rs:407
+ *   Cascade    `DirectForm<T, n>`      2+2n words total { x0, x1, (y0, y1) x n }    biquad.rs:260-269,324
+ */
+
+/* `Biquad<Q32<F>>` x `DirectForm1<i32>` (src/iir/biquad.rs:366-383). */
+int idsp_biquad_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                        const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                        int layout, void *stream);
+/* `BiquadClamp<Q32<F>, i32>` x `DirectForm1<i32>` (src/iir/biquad.rs:394-404). */
+int idsp_biquad_i32_df1_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state,
+                              const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                              int layout, void *stream);
+/* `Biquad<Q32<F>>` x `DirectForm1Dither` (src/iir/biquad.rs:511-530). */
+int idsp_biquad_i32_dither(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                           const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                           int layout, void *stream);
+/* `BiquadClamp<Q32<F>, i32>` x `DirectForm1Dither` (src/iir/biquad.rs:532-538). */
+int idsp_biquad_i32_dither_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state,
+                                 const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                                 int layout, void *stream);
+/* `Biquad<Q32<F>>` x `DirectForm1Wide` (src/iir/biquad.rs:456-472). */
+int idsp_biquad_i32_wide(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                         const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                         int layout, void *stream);
+/* `BiquadClamp<Q32<F>, i32>` x `DirectForm1Wide` (src/iir/biquad.rs:474-480);
+ * this is the per-section operator of `sos_clamp_wide()` in src/py.rs:76-108. */
+int idsp_biquad_i32_wide_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state,
+                               const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                               int layout, void *stream);
+/* `Cascade<[Biquad<Q32<F>>; n]>` x `DirectForm<i32, n>` — shared delay lines
+ * (src/iir/biquad.rs:339-364).  1 <= n <= 8. */
+int idsp_cascade_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                         const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                         int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* iir::Biquad — f32                                                        */
+/* ------------------------------------------------------------------------ */
+
+/* `Biquad<f32>` x `DirectForm1<f32>` (src/iir/biquad.rs:366-383): every product
+ * and sum individually rounded, evaluated left to right, no FMA. */
+int idsp_biquad_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state,
+                        const float *x, float *y, size_t lanes, size_t frames,
+                        int layout, void *stream);
+/* `BiquadClamp<f32>` x `DirectForm1<f32>` (src/iir/biquad.rs:394-404). */
+int idsp_biquad_f32_df1_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state,
+                              const float *x, float *y, size_t lanes, size_t frames,
+                              int layout, void *stream);
+/* `Biquad<f32>` x `DirectForm2Transposed<f32>` (src/iir/biquad.rs:418-428). */
+int idsp_biquad_f32_df2t(const idsp_biquad_f32 *cfg, size_t n, void *state,
+                         const float *x, float *y, size_t lanes, size_t frames,
+                         int layout, void *stream);
+/* `BiquadClamp<f32>` x `DirectForm2Transposed<f32>` (src/iir/biquad.rs:430-440). */
+int idsp_biquad_f32_df2t_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state,
+                               const float *x, float *y, size_t lanes, size_t frames,
+                               int layout, void *stream);
+/* `Cascade<[Biquad<f32>; n]>` x `DirectForm<f32, n>` (src/iir/biquad.rs:339-364). */
+int idsp_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state,
+                         const float *x, float *y, size_t lanes, size_t frames,
+                         int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* hbf — symmetric FIR and half-band decimator / interpolator cascades      */
+/* ------------------------------------------------------------------------ */
+
+#define IDSP_HBF_MAX_STAGES 5
+#define IDSP_HBF_MAX_TAPS 32
+
+/* A cascade of `EvenSymmetric<[f32; M]>` half-band stages (src/hbf.rs:70-138)
+ * in PROCESSING order.  taps[s][0..m[s]) are ordered outermost (small) to
+ * centre (large) exactly like HBF_TAPS (src/hbf.rs:308-349). */
+typedef struct idsp_hbf_cascade_f32 {
+    int32_t stages;                 /* 1..IDSP_HBF_MAX_STAGES */
+    int32_t m[IDSP_HBF_MAX_STAGES]; /* one-sided tap count per stage, 1..IDSP_HBF_MAX_TAPS */
+    float taps[IDSP_HBF_MAX_STAGES][IDSP_HBF_MAX_TAPS];
+} idsp_hbf_cascade_f32;
+
+/* Built-in tap sets: set 0 = HBF_TAPS (140 dB, src/hbf.rs:308-349),
+ * set 1 = HBF_TAPS_98 (src/hbf.rs:258-292). */
+/* Fill `out` like `HBF_DEC_CASCADE` restricted to a 2^stages rate change
+ * (src/hbf.rs:385-421: highest-rate/fewest-tap stage first, i.e. tuple index
+ * stages-1 down to 0). */
+int idsp_hbf_dec_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out);
+/* Fill `out` like `HBF_INT_CASCADE` (src/hbf.rs:476-512: tuple index 0 first). */
+int idsp_hbf_int_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out);
+/* `hbf_dec_response_length` / `hbf_int_response_length` (src/hbf.rs:424-448,515-539)
+ * generalised to an arbitrary cascade. */
+int idsp_hbf_dec_response_length(const idsp_hbf_cascade_f32 *cfg);
+int idsp_hbf_int_response_length(const idsp_hbf_cascade_f32 *cfg);
+
+/* State words per lane: for each stage s in processing order
+ *   decimator   `HbfDec`  (src/hbf.rs:142-145): even[m-1] then odd[2m-1], oldest first
+ *   interpolator `HbfInt` (src/hbf.rs:196-198): x[2m-1], oldest first
+ * i.e. exactly the samples `copy_within` keeps (src/hbf.rs:182-183,224). */
+size_t idsp_hbf_dec_state_words(const idsp_hbf_cascade_f32 *cfg);
+size_t idsp_hbf_int_state_words(const idsp_hbf_cascade_f32 *cfg);
+
+/* Half-band decimator cascade, rate change R = 2^stages
+ * (`SplitProcess<[f32; R], f32, _>` for the `Major`/`ChunkIn` nest,
+ * src/hbf.rs:156-192,385-421).  `frames` counts OUTPUT samples per lane; each
+ * input element is a chunk `[f32; R]` of R consecutive high-rate samples:
+ *   FRAME_MAJOR  x[(f*lanes + l)*R + k]   y[f*lanes + l]
+ *   LANE_MAJOR   x[(l*frames + f)*R + k]  y[l*frames + f]   (lane = contiguous stream)
+ */
+int idsp_hbf_dec_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+/* Half-band interpolator cascade (src/hbf.rs:200-236,476-512).  `frames`
+ * counts INPUT samples per lane; each output element is a chunk `[f32; R]`:
+ *   FRAME_MAJOR  x[f*lanes + l]   y[(f*lanes + l)*R + k]
+ *   LANE_MAJOR   x[l*frames + f]  y[(l*frames + f)*R + k]
+ */
+int idsp_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* cossin / Accu DDS / Lockin                                               */
+/* ------------------------------------------------------------------------ */
+
+/* `cossin(phase)` (src/cossin.rs:14-67) elementwise: out[2*i] = cos, out[2*i+1]
+ * = sin — the `cossin(p) -> i32[N,2]` function of src/py.rs:10-28. */
+int idsp_cossin_i32(const int32_t *phase, int32_t *out, size_t n, void *stream);
+
+/* DDS: per lane `Accu<Wrapping<i32>>` (src/accu.rs:34-41, pre-increment) feeding
+ * `Complex::<i32>::from_angle` (src/complex.rs:237-240).  State words per lane:
+ * { accu.state, accu.step }.  Output element = Complex<i32> = [re, im] adjacent
+ * (src/complex.rs:15-20): out[(index(f,l))*2 + {0,1}]. */
+int idsp_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout,
+                 void *stream);
+
+#define IDSP_LOCKIN_MAX_CASCADE 4
+
+/* `Lockin<[Lowpass<N>; K]>` (src/lockin.rs:11-39, src/lowpass.rs:13-80).
+ * order = N (1 or 2), cascade = K (1..IDSP_LOCKIN_MAX_CASCADE),
+ * k[c][0..N) = `Lowpass<N>.0` of cascade element c. */
+typedef struct idsp_lockin_i32 {
+    int32_t order;
+    int32_t cascade;
+    int32_t k[IDSP_LOCKIN_MAX_CASCADE][2];
+} idsp_lockin_i32;
+
+/* State words per lane: { accu.state, accu.step } followed by
+ * `[[LowpassState<N>; K]; 2]` (index 0 = I/re, 1 = Q/im), each i64 as lo,hi:
+ *   word 2 + ((iq*K + c)*N + j)*2 + {0: lo, 1: hi}. */
+size_t idsp_lockin_state_words(const idsp_lockin_i32 *cfg);
+
+/* Phase-accumulator lock-in: per frame `phase = accu.next()`, then
+ * `Lockin::process(state, (x, Wrapping(phase)))` (src/lockin.rs:30-39):
+ * cossin -> `x * Q32<32>` mix (dsp-fixedpoint/src/lib.rs:449-456) -> the lowpass
+ * cascade on I and Q.  Output Complex<i32>: y[index(f,l)*2 + {0: re, 1: im}]. */
+int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x,
+                            int32_t *y, size_t lanes, size_t frames, int layout,
+                            void *stream);
+
+/* `Lowpass<N>` cascade alone on a real stream (src/lowpass.rs:47-78; array
+ * composition dsp-process/src/compose.rs:80-113).  State: `[LowpassState<N>; K]`
+ * words ((c*N + j)*2 + {lo,hi}). */
+int idsp_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDSP_HIP_H */

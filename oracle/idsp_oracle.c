@@ -1,0 +1,813 @@
+/*
+ * idsp_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ * See idsp_oracle.h for the role and pinning status of this file.
+ *
+ * Scalar restatement of the reference hot path (quartiq/idsp 0.22.0).  Each
+ * function cites the reference lines it follows.  Arithmetic conventions:
+ *   - Rust release-mode integer arithmetic wraps; done here through unsigned
+ *     types so that no C signed-overflow UB is involved.
+ *   - `>>` on signed values is arithmetic (gcc), Rust `as` integer casts
+ *     truncate, float -> int `as` saturates with NaN -> 0.
+ *   - build with -ffp-contract=off and without fast-math: Rust never fuses
+ *     `a*b + c`.
+ */
+#include "idsp_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- helpers */
+
+static inline int64_t wadd64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+static inline int32_t wadd32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int64_t wshl64(int64_t a, int s) { return (int64_t)((uint64_t)a << s); }
+static inline int64_t mul_wide(int32_t c, int32_t v) { return (int64_t)c * (int64_t)v; }
+static inline int32_t trunc32(int64_t a) { return (int32_t)(uint32_t)(uint64_t)a; }
+
+static inline size_t idx_of(size_t f, size_t l, size_t lanes, size_t frames, int layout)
+{
+    return layout == IDSP_LANE_MAJOR ? l * frames + f : f * lanes + l;
+}
+
+static inline float f32_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f32_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static int check_common(const void *cfg, size_t n, const void *state, const void *x, const void *y,
+                        size_t lanes, size_t frames, int layout)
+{
+    if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return IDSP_EINVAL;
+    if (n > IDSP_MAX_SECTIONS) return IDSP_EINVAL;
+    if (n && !cfg) return IDSP_EINVAL;
+    if (lanes && n && !state) return IDSP_EINVAL;
+    if (lanes && frames && (!x || !y)) return IDSP_EINVAL;
+    return IDSP_OK;
+}
+
+/* num_traits::clamp: `if input < min {min} else if input > max {max} else {input}` */
+static inline int32_t clamp_i32(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float clamp_f32(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ------------------------------------------------ coefficient ingestion (a8) */
+
+/* dsp-fixedpoint/src/num_traits_impl.rs:32-46: Q::new((v * (1/DELTA)).round().as_())
+ * with DELTA = 2^-F (lib.rs:220-224); `round` = half away from zero; `as i32`
+ * saturates, NaN -> 0. */
+int32_t idsp_ref_quantize_f64(double v, int frac)
+{
+    double s = round(v * ldexp(1.0, frac));
+    if (isnan(s)) return 0;
+    if (s >= 2147483647.0) return INT32_MAX;
+    if (s <= -2147483648.0) return INT32_MIN;
+    return (int32_t)s;
+}
+
+/* src/iir/biquad.rs:545-566 `From<[[f64;3];2]>`: a0 = 1/ba[1][0];
+ * [b0*a0, b1*a0, b2*a0, -a1*a0, -a2*a0] then `From<[T;5]>` (:570-576). */
+int idsp_ref_biquad_i32_from_sos(const double sos[6], int frac, idsp_biquad_i32 *out)
+{
+    if (!sos || !out || frac < 0 || frac > 31) return IDSP_EINVAL;
+    double a0 = 1.0 / sos[3];
+    double ba[5] = {sos[0] * a0, sos[1] * a0, sos[2] * a0, -sos[4] * a0, -sos[5] * a0};
+    for (int i = 0; i < 5; i++) out->ba[i] = idsp_ref_quantize_f64(ba[i], frac);
+    out->frac = frac;
+    return IDSP_OK;
+}
+
+int idsp_ref_biquad_f32_from_sos(const float sos[6], idsp_biquad_f32 *out)
+{
+    if (!sos || !out) return IDSP_EINVAL;
+    float a0 = 1.0f / sos[3];
+    out->ba[0] = sos[0] * a0;
+    out->ba[1] = sos[1] * a0;
+    out->ba[2] = sos[2] * a0;
+    out->ba[3] = -sos[4] * a0;
+    out->ba[4] = -sos[5] * a0;
+    return IDSP_OK;
+}
+
+int idsp_ref_biquad_f32_from_sos_f64(const double sos[6], idsp_biquad_f32 *out)
+{
+    if (!sos || !out) return IDSP_EINVAL;
+    double a0 = 1.0 / sos[3];
+    double ba[5] = {sos[0] * a0, sos[1] * a0, sos[2] * a0, -sos[4] * a0, -sos[5] * a0};
+    for (int i = 0; i < 5; i++) out->ba[i] = (float)ba[i];
+    return IDSP_OK;
+}
+
+/* src/iir/coefficients.rs:259-283: fcos_alpha() and lowpass(). */
+void idsp_ref_filter_lowpass(double w0, double gain, double q, double sos[6])
+{
+    double fsin = sin(w0), fcos = cos(w0);
+    double alpha = 0.5 * fsin * (1.0 / q);
+    double b = gain * 0.5 * (1.0 - fcos);
+    sos[0] = b; sos[1] = 2.0 * b; sos[2] = b;
+    sos[3] = 1.0 + alpha; sos[4] = -2.0 * fcos; sos[5] = 1.0 - alpha;
+}
+
+/* src/iir/coefficients.rs:302-335: highpass(). */
+void idsp_ref_filter_highpass(double w0, double gain, double q, double sos[6])
+{
+    double fsin = sin(w0), fcos = cos(w0);
+    double alpha = 0.5 * fsin * (1.0 / q);
+    double b = gain * 0.5 * (1.0 + fcos);
+    sos[0] = b; sos[1] = -2.0 * b; sos[2] = b;
+    sos[3] = 1.0 + alpha; sos[4] = -2.0 * fcos; sos[5] = 1.0 - alpha;
+}
+
+/* ------------------------------------------------------- biquad sections */
+/* Local state is the per-lane word record of include/idsp_hip.h. */
+
+/* src/iir/biquad.rs:366-383 with C = Q<i32,i64,F>: products widen to i64
+ * (dsp-fixedpoint/src/ops.rs:91-97, lib.rs:310-312), Q+Q adds (ops.rs:63-76),
+ * `.as_()` = quantize = (acc >> F) as i32 (num_traits_impl.rs:74-85,
+ * lib.rs:297-299,270-272). */
+static inline int64_t sum5_i32(const int32_t ba[5], int32_t x0, int32_t x1, int32_t x2, int32_t y1, int32_t y2)
+{
+    int64_t acc = mul_wide(ba[0], x0);
+    acc = wadd64(acc, mul_wide(ba[1], x1));
+    acc = wadd64(acc, mul_wide(ba[2], x2));
+    acc = wadd64(acc, mul_wide(ba[3], y1));
+    acc = wadd64(acc, mul_wide(ba[4], y2));
+    return acc;
+}
+
+static inline int32_t df1_i32(const int32_t ba[5], int frac, uint32_t *s, int32_t x0)
+{
+    int32_t y0 = trunc32(sum5_i32(ba, x0, (int32_t)s[0], (int32_t)s[1], (int32_t)s[2], (int32_t)s[3]) >> frac);
+    s[1] = s[0]; s[0] = (uint32_t)x0;
+    s[3] = s[2]; s[2] = (uint32_t)y0;
+    return y0;
+}
+
+/* src/iir/biquad.rs:394-404: clamp(inner + u, min, max); state.y[0][0] = y0. */
+static inline int32_t df1_clamp_i32(const idsp_biquad_clamp_i32 *c, uint32_t *s, int32_t x0)
+{
+    int32_t y0 = clamp_i32(wadd32(df1_i32(c->ba, c->frac, s, x0), c->u), c->min, c->max);
+    s[2] = (uint32_t)y0;
+    return y0;
+}
+
+/* src/iir/biquad.rs:511-530. */
+static inline int32_t dither_i32(const int32_t ba[5], int frac, uint32_t *s, int32_t x0)
+{
+    int64_t acc = wadd64((int64_t)(uint64_t)s[4],
+                         sum5_i32(ba, x0, (int32_t)s[0], (int32_t)s[1], (int32_t)s[2], (int32_t)s[3]));
+    acc = wshl64(acc, 32 - frac);
+    /* `(acc as u32) >> (32 - F)`; for F = 0 the low word is zero after `<<= 32`
+     * and Rust's release-mode shift masks the amount, giving 0. */
+    s[4] = frac == 0 ? 0u : ((uint32_t)(uint64_t)acc) >> (32 - frac);
+    int32_t y0 = trunc32(acc >> 32);
+    s[1] = s[0]; s[0] = (uint32_t)x0;
+    s[3] = s[2]; s[2] = (uint32_t)y0;
+    return y0;
+}
+
+/* src/iir/biquad.rs:532-538. */
+static inline int32_t dither_clamp_i32(const idsp_biquad_clamp_i32 *c, uint32_t *s, int32_t x0)
+{
+    int32_t y0 = clamp_i32(wadd32(dither_i32(c->ba, c->frac, s, x0), c->u), c->min, c->max);
+    s[2] = (uint32_t)y0;
+    return y0;
+}
+
+/* src/iir/biquad.rs:456-472.  Words: x0,x1,y0.lo,y0.hi,y1.lo,y1.hi. */
+static inline int32_t wide_i32(const int32_t ba[5], int frac, uint32_t *s, int32_t x0)
+{
+    int64_t acc = mul_wide(ba[0], x0);
+    acc = wadd64(acc, mul_wide(ba[1], (int32_t)s[0]));
+    acc = wadd64(acc, mul_wide(ba[2], (int32_t)s[1]));
+    s[1] = s[0]; s[0] = (uint32_t)x0;
+    int64_t y0 = (int64_t)(((uint64_t)s[3] << 32) | s[2]);
+    int64_t y1 = (int64_t)(((uint64_t)s[5] << 32) | s[4]);
+    acc = wadd64(acc, ((int64_t)(uint64_t)(uint32_t)y0 * (int64_t)ba[3]) >> 32);
+    acc = wadd64(acc, (int64_t)(int32_t)(y0 >> 32) * (int64_t)ba[3]);
+    acc = wadd64(acc, ((int64_t)(uint64_t)(uint32_t)y1 * (int64_t)ba[4]) >> 32);
+    acc = wadd64(acc, (int64_t)(int32_t)(y1 >> 32) * (int64_t)ba[4]);
+    acc = wshl64(acc, 32 - frac);
+    s[4] = s[2]; s[5] = s[3];
+    s[2] = (uint32_t)(uint64_t)acc; s[3] = (uint32_t)((uint64_t)acc >> 32);
+    return trunc32(acc >> 32);
+}
+
+/* src/iir/biquad.rs:474-480: state.y[0] = ((y0 as i64) << 32) | state.y[0] as u32 as i64. */
+static inline int32_t wide_clamp_i32(const idsp_biquad_clamp_i32 *c, uint32_t *s, int32_t x0)
+{
+    int32_t y0 = clamp_i32(wadd32(wide_i32(c->ba, c->frac, s, x0), c->u), c->min, c->max);
+    s[3] = (uint32_t)y0;
+    return y0;
+}
+
+/* src/iir/biquad.rs:366-383 with C = T = A = f32: ((((b0*x0 + b1*x1) + b2*x2) + a1*y1) + a2*y2). */
+static inline float df1_f32(const float ba[5], uint32_t *s, float x0)
+{
+    float x1 = f32_from_bits(s[0]), x2 = f32_from_bits(s[1]);
+    float y1 = f32_from_bits(s[2]), y2 = f32_from_bits(s[3]);
+    float acc = ba[0] * x0;
+    acc = acc + ba[1] * x1;
+    acc = acc + ba[2] * x2;
+    acc = acc + ba[3] * y1;
+    acc = acc + ba[4] * y2;
+    s[1] = s[0]; s[0] = f32_to_bits(x0);
+    s[3] = s[2]; s[2] = f32_to_bits(acc);
+    return acc;
+}
+
+static inline float df1_clamp_f32(const idsp_biquad_clamp_f32 *c, uint32_t *s, float x0)
+{
+    float y0 = clamp_f32(df1_f32(c->ba, s, x0) + c->u, c->min, c->max);
+    s[2] = f32_to_bits(y0);
+    return y0;
+}
+
+/* src/iir/biquad.rs:418-428. */
+static inline float df2t_f32(const float ba[5], uint32_t *s, float x0)
+{
+    float s0 = f32_from_bits(s[0]), s1 = f32_from_bits(s[1]);
+    float y0 = s0 + ba[0] * x0;
+    float n0 = (s1 + ba[1] * x0) + ba[3] * y0;
+    float n1 = ba[2] * x0 + ba[4] * y0;
+    s[0] = f32_to_bits(n0); s[1] = f32_to_bits(n1);
+    return y0;
+}
+
+/* src/iir/biquad.rs:430-440. */
+static inline float df2t_clamp_f32(const idsp_biquad_clamp_f32 *c, uint32_t *s, float x0)
+{
+    float s0 = f32_from_bits(s[0]), s1 = f32_from_bits(s[1]);
+    float y0 = clamp_f32((s0 + c->ba[0] * x0) + c->u, c->min, c->max);
+    float n0 = (s1 + c->ba[1] * x0) + c->ba[3] * y0;
+    float n1 = c->ba[2] * x0 + c->ba[4] * y0;
+    s[0] = f32_to_bits(n0); s[1] = f32_to_bits(n1);
+    return y0;
+}
+
+static int frac_ok_i32(const idsp_biquad_i32 *c, size_t n)
+{
+    for (size_t i = 0; i < n; i++) if (c[i].frac < 0 || c[i].frac > 31) return 0;
+    return 1;
+}
+static int frac_ok_clamp(const idsp_biquad_clamp_i32 *c, size_t n)
+{
+    for (size_t i = 0; i < n; i++) if (c[i].frac < 0 || c[i].frac > 31) return 0;
+    return 1;
+}
+
+/*
+ * Lane driver.  Per lane it follows the serial slice composition
+ * `[C] x [S]` STAGE-major (dsp-process/src/compose.rs:43-77: first section
+ * `block(x, y)`, every further section `inplace(y)`), each of those being the
+ * default per-sample loops of process.rs:122-127,137-141; the lanes are visited
+ * one after the other like `Lanes::process_view` (compose.rs:478-494).
+ */
+#define LANE_DRIVER(NAME, CFG_T, T, W, FRAC_CHECK, CALL)                                          \
+    static int NAME##_range(const CFG_T *cfg, size_t n, void *state, const T *x, T *y, size_t lanes, \
+                            size_t frames, int layout, size_t l0, size_t l1)                       \
+    {                                                                                              \
+        uint32_t *st = (uint32_t *)state;                                                          \
+        for (size_t l = l0; l < l1; l++) {                                                         \
+            if (n == 0) {                                                                          \
+                for (size_t f = 0; f < frames; f++) {                                              \
+                    size_t i = idx_of(f, l, lanes, frames, layout);                                \
+                    y[i] = x[i];                                                                   \
+                }                                                                                  \
+                continue;                                                                          \
+            }                                                                                      \
+            for (size_t k = 0; k < n; k++) {                                                       \
+                const CFG_T *c = &cfg[k];                                                          \
+                uint32_t s[W];                                                                     \
+                for (int w = 0; w < W; w++) s[w] = st[(k * W + w) * lanes + l];                    \
+                const T *src = k == 0 ? x : y;                                                     \
+                for (size_t f = 0; f < frames; f++) {                                              \
+                    size_t i = idx_of(f, l, lanes, frames, layout);                                \
+                    T x0 = src[i];                                                                 \
+                    y[i] = CALL;                                                                   \
+                }                                                                                  \
+                for (int w = 0; w < W; w++) st[(k * W + w) * lanes + l] = s[w];                    \
+            }                                                                                      \
+        }                                                                                          \
+        return IDSP_OK;                                                                            \
+    }                                                                                              \
+    int NAME(const CFG_T *cfg, size_t n, void *state, const T *x, T *y, size_t lanes,              \
+             size_t frames, int layout)                                                            \
+    {                                                                                              \
+        int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);                         \
+        if (rc) return rc;                                                                         \
+        if (!(FRAC_CHECK)) return IDSP_EINVAL;                                                     \
+        return NAME##_range(cfg, n, state, x, y, lanes, frames, layout, 0, lanes);                 \
+    }
+
+LANE_DRIVER(idsp_ref_biquad_i32_df1, idsp_biquad_i32, int32_t, 4, frac_ok_i32(cfg, n),
+            df1_i32(c->ba, c->frac, s, x0))
+LANE_DRIVER(idsp_ref_biquad_i32_df1_clamp, idsp_biquad_clamp_i32, int32_t, 4, frac_ok_clamp(cfg, n),
+            df1_clamp_i32(c, s, x0))
+LANE_DRIVER(idsp_ref_biquad_i32_dither, idsp_biquad_i32, int32_t, 5, frac_ok_i32(cfg, n),
+            dither_i32(c->ba, c->frac, s, x0))
+LANE_DRIVER(idsp_ref_biquad_i32_dither_clamp, idsp_biquad_clamp_i32, int32_t, 5, frac_ok_clamp(cfg, n),
+            dither_clamp_i32(c, s, x0))
+LANE_DRIVER(idsp_ref_biquad_i32_wide, idsp_biquad_i32, int32_t, 6, frac_ok_i32(cfg, n),
+            wide_i32(c->ba, c->frac, s, x0))
+LANE_DRIVER(idsp_ref_biquad_i32_wide_clamp, idsp_biquad_clamp_i32, int32_t, 6, frac_ok_clamp(cfg, n),
+            wide_clamp_i32(c, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f32_df1, idsp_biquad_f32, float, 4, 1, df1_f32(c->ba, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f32_df1_clamp, idsp_biquad_clamp_f32, float, 4, 1, df1_clamp_f32(c, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f32_df2t, idsp_biquad_f32, float, 2, 1, df2t_f32(c->ba, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f32_df2t_clamp, idsp_biquad_clamp_f32, float, 2, 1, df2t_clamp_f32(c, s, x0))
+
+/* `Cascade<[Biquad<C>; N]>` x `DirectForm<T, N>` (src/iir/biquad.rs:339-364):
+ * sample-major fold over sections; section k's input history is the output
+ * history of section k-1 (x for k = 0).  Words: x0,x1,(y0,y1) x n. */
+int idsp_ref_cascade_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x,
+                             int32_t *y, size_t lanes, size_t frames, int layout)
+{
+    int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (n < 1 || n > 8 || !frac_ok_i32(cfg, n)) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    size_t W = 2 + 2 * n;
+    for (size_t l = 0; l < lanes; l++) {
+        int32_t s[18];
+        for (size_t w = 0; w < W; w++) s[w] = (int32_t)st[w * lanes + l];
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            int32_t x0 = x[i];
+            int32_t *xh = &s[0]; /* fold accumulator `(x0, &mut x)` */
+            for (size_t k = 0; k < n; k++) {
+                int32_t *yh = &s[2 + 2 * k];
+                int32_t y0 = trunc32(sum5_i32(cfg[k].ba, x0, xh[0], xh[1], yh[0], yh[1]) >> cfg[k].frac);
+                xh[1] = xh[0]; xh[0] = x0; /* *x = [x0, x[0]] */
+                x0 = y0; xh = yh;
+            }
+            xh[1] = xh[0]; xh[0] = x0; /* *y = [y0, y[0]] */
+            y[i] = x0;
+        }
+        for (size_t w = 0; w < W; w++) st[w * lanes + l] = (uint32_t)s[w];
+    }
+    return IDSP_OK;
+}
+
+int idsp_ref_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x,
+                             float *y, size_t lanes, size_t frames, int layout)
+{
+    int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (n < 1 || n > 8) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    size_t W = 2 + 2 * n;
+    for (size_t l = 0; l < lanes; l++) {
+        float s[18];
+        for (size_t w = 0; w < W; w++) s[w] = f32_from_bits(st[w * lanes + l]);
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            float x0 = x[i];
+            float *xh = &s[0];
+            for (size_t k = 0; k < n; k++) {
+                float *yh = &s[2 + 2 * k];
+                const float *ba = cfg[k].ba;
+                float acc = ba[0] * x0;
+                acc = acc + ba[1] * xh[0];
+                acc = acc + ba[2] * xh[1];
+                acc = acc + ba[3] * yh[0];
+                acc = acc + ba[4] * yh[1];
+                xh[1] = xh[0]; xh[0] = x0;
+                x0 = acc; xh = yh;
+            }
+            xh[1] = xh[0]; xh[0] = x0;
+            y[i] = x0;
+        }
+        for (size_t w = 0; w < W; w++) st[w * lanes + l] = f32_to_bits(s[w]);
+    }
+    return IDSP_OK;
+}
+
+/* --------------------------------------------------- threaded CPU baseline */
+
+typedef struct {
+    const idsp_biquad_i32 *cfg; size_t n; void *state; const int32_t *x; int32_t *y;
+    size_t lanes, frames; int layout; size_t l0, l1;
+} mt_job;
+
+static void *mt_worker(void *p)
+{
+    mt_job *j = (mt_job *)p;
+    idsp_ref_biquad_i32_df1_range(j->cfg, j->n, j->state, j->x, j->y, j->lanes, j->frames, j->layout, j->l0, j->l1);
+    return NULL;
+}
+
+int idsp_ref_biquad_i32_df1_mt(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x,
+                               int32_t *y, size_t lanes, size_t frames, int layout, int threads)
+{
+    int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (!frac_ok_i32(cfg, n) || threads < 1 || threads > 1024) return IDSP_EINVAL;
+    if (threads == 1) return idsp_ref_biquad_i32_df1_range(cfg, n, state, x, y, lanes, frames, layout, 0, lanes);
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)threads);
+    if (!tid || !jobs) { free(tid); free(jobs); return IDSP_EINVAL; }
+    for (int t = 0; t < threads; t++) {
+        mt_job j = {cfg, n, state, x, y, lanes, frames, layout,
+                    lanes * (size_t)t / (size_t)threads, lanes * (size_t)(t + 1) / (size_t)threads};
+        jobs[t] = j;
+        pthread_create(&tid[t], NULL, mt_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    free(tid); free(jobs);
+    return IDSP_OK;
+}
+
+/* ------------------------------------------------------------------- hbf */
+
+/* src/hbf.rs:308-349 (HBF_TAPS) and :258-292 (HBF_TAPS_98); index = tuple index. */
+static const int HBF_M[2][5] = {{23, 10, 5, 4, 3}, {15, 6, 3, 3, 2}};
+static const float HBF_TAPS_TBL[2][5][23] = {
+    {
+        {7.60375795e-07f, -3.77494111e-06f, 1.26458559e-05f, -3.43188253e-05f, 8.10687478e-05f,
+         -1.72971467e-04f, 3.40845059e-04f, -6.29522864e-04f, 1.10128831e-03f, -1.83933299e-03f,
+         2.95124926e-03f, -4.57290964e-03f, 6.87374176e-03f, -1.00656257e-02f, 1.44199840e-02f,
+         -2.03025100e-02f, 2.82462332e-02f, -3.91128509e-02f, 5.44795658e-02f, -7.77002672e-02f,
+         1.17523452e-01f, -2.06185388e-01f, 6.34588695e-01f},
+        {-1.12811343e-05f, 1.12724671e-04f, -6.07439343e-04f, 2.31904511e-03f, -7.00322950e-03f,
+         1.78225473e-02f, -4.01209836e-02f, 8.43315989e-02f, -1.83189521e-01f, 6.26346521e-01f},
+        {0.0007686f, -0.00768669f, 0.0386536f, -0.14002434f, 0.60828885f},
+        {-0.00261331f, 0.02476858f, -0.12112638f, 0.59897111f},
+        {0.01186105f, -0.09808109f, 0.58622005f},
+    },
+    {
+        {7.02144012e-05f, -2.43279582e-04f, 6.35026936e-04f, -1.39782541e-03f, 2.74613582e-03f,
+         -4.96403839e-03f, 8.41806912e-03f, -1.35827601e-02f, 2.11004053e-02f, -3.19267647e-02f,
+         4.77024289e-02f, -7.18014345e-02f, 1.12942004e-01f, -2.03279594e-01f, 6.33592923e-01f},
+        {-0.00086943f, 0.00577837f, -0.02201674f, 0.06357869f, -0.16627679f, 0.61979312f},
+        {0.01414651f, -0.10439639f, 0.59026742f},
+        {0.01227974f, -0.09930782f, 0.58702834f},
+        {-0.06291796f, 0.5629161f},
+    },
+};
+
+static int hbf_fill(int tap_set, int stages, int dec, idsp_hbf_cascade_f32 *out)
+{
+    if (!out || tap_set < 0 || tap_set > 1 || stages < 1 || stages > 5) return IDSP_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->stages = stages;
+    for (int s = 0; s < stages; s++) {
+        /* decimator: HBF_DEC_CASCADE nests tuple index stages-1 (highest rate) first,
+         * src/hbf.rs:412-421; interpolator: index 0 first, src/hbf.rs:503-512 */
+        int t = dec ? stages - 1 - s : s;
+        out->m[s] = HBF_M[tap_set][t];
+        for (int k = 0; k < out->m[s]; k++) out->taps[s][k] = HBF_TAPS_TBL[tap_set][t][k];
+    }
+    return IDSP_OK;
+}
+
+int idsp_ref_hbf_dec_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out) { return hbf_fill(tap_set, stages, 1, out); }
+int idsp_ref_hbf_int_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out) { return hbf_fill(tap_set, stages, 0, out); }
+
+static int hbf_cfg_ok(const idsp_hbf_cascade_f32 *c)
+{
+    if (!c || c->stages < 1 || c->stages > IDSP_HBF_MAX_STAGES) return 0;
+    for (int s = 0; s < c->stages; s++) if (c->m[s] < 1 || c->m[s] > IDSP_HBF_MAX_TAPS) return 0;
+    return 1;
+}
+
+/* src/hbf.rs:424-448: from the highest-rate stage down: n = n/2 + LEN(stage),
+ * LEN = 2M-1 (src/hbf.rs:76-78 `len()`). */
+int idsp_ref_hbf_dec_response_length(const idsp_hbf_cascade_f32 *c)
+{
+    if (!hbf_cfg_ok(c)) return IDSP_EINVAL;
+    int n = 0;
+    for (int s = 0; s < c->stages; s++) { n /= 2; n += 2 * c->m[s] - 1; }
+    return n;
+}
+
+/* src/hbf.rs:515-539: n = (n + LEN(stage)) * 2 from the lowest-rate stage up. */
+int idsp_ref_hbf_int_response_length(const idsp_hbf_cascade_f32 *c)
+{
+    if (!hbf_cfg_ok(c)) return IDSP_EINVAL;
+    int n = 0;
+    for (int s = 0; s < c->stages; s++) { n += 2 * c->m[s] - 1; n *= 2; }
+    return n;
+}
+
+size_t idsp_ref_hbf_dec_state_words(const idsp_hbf_cascade_f32 *c)
+{
+    if (!hbf_cfg_ok(c)) return 0;
+    size_t w = 0;
+    for (int s = 0; s < c->stages; s++) w += (size_t)(3 * c->m[s] - 2);
+    return w;
+}
+
+size_t idsp_ref_hbf_int_state_words(const idsp_hbf_cascade_f32 *c)
+{
+    if (!hbf_cfg_ok(c)) return 0;
+    size_t w = 0;
+    for (int s = 0; s < c->stages; s++) w += (size_t)(2 * c->m[s] - 1);
+    return w;
+}
+
+/* src/hbf.rs:46-68 `get::<_,_,M,false,true>` for ONE window w[0..2M):
+ * old = w[..M], new = w[M..] reversed; Σ (new + old) * tap, accumulated by
+ * `f32::sum` — a sequential fold seeded with -0.0 (Rust >= 1.83; edition 2024
+ * implies >= 1.85). */
+static inline float hbf_get(const float *taps, int m, const float *w)
+{
+    float acc = -0.0f;
+    for (int k = 0; k < m; k++) acc = acc + (w[2 * m - 1 - k] + w[k]) * taps[k];
+    return acc;
+}
+
+#define HBF_BLOCK 32 /* any block size gives the same result (src/hbf.rs:166) */
+
+/* One `HbfDec` stage over n output samples; in = n pairs [even, odd]
+ * (src/hbf.rs:163-185), literal including the block loop and copy_within.
+ * st = even[m-1] ++ odd[2m-1]. */
+static void hbf_dec_stage(const float *taps, int m, float *st, const float *in, float *out, size_t n)
+{
+    int len = 2 * m - 1;
+    float even[IDSP_HBF_MAX_TAPS - 1 + HBF_BLOCK], odd[2 * IDSP_HBF_MAX_TAPS - 1 + HBF_BLOCK];
+    memcpy(even, st, sizeof(float) * (size_t)(m - 1));
+    memcpy(odd, st + (m - 1), sizeof(float) * (size_t)len);
+    for (size_t p = 0; p < n; p += HBF_BLOCK) {
+        size_t c = n - p < HBF_BLOCK ? n - p : HBF_BLOCK;
+        for (size_t i = 0; i < c; i++) {
+            even[(size_t)(m - 1) + i] = in[2 * (p + i)];
+            odd[(size_t)len + i] = in[2 * (p + i) + 1];
+        }
+        for (size_t i = 0; i < c; i++) out[p + i] = hbf_get(taps, m, odd + i) + even[i];
+        memmove(even, even + c, sizeof(float) * (size_t)(m - 1));
+        memmove(odd, odd + c, sizeof(float) * (size_t)len);
+    }
+    memcpy(st, even, sizeof(float) * (size_t)(m - 1));
+    memcpy(st + (m - 1), odd, sizeof(float) * (size_t)len);
+}
+
+/* One `HbfInt` stage over n input samples -> n pairs (src/hbf.rs:207-227). st = x[2m-1]. */
+static void hbf_int_stage(const float *taps, int m, float *st, const float *in, float *out, size_t n)
+{
+    int len = 2 * m - 1;
+    float xb[2 * IDSP_HBF_MAX_TAPS - 1 + HBF_BLOCK];
+    memcpy(xb, st, sizeof(float) * (size_t)len);
+    for (size_t p = 0; p < n; p += HBF_BLOCK) {
+        size_t c = n - p < HBF_BLOCK ? n - p : HBF_BLOCK;
+        memcpy(xb + len, in + p, sizeof(float) * c);
+        for (size_t i = 0; i < c; i++) {
+            out[2 * (p + i)] = hbf_get(taps, m, xb + i); /* interpolated */
+            out[2 * (p + i) + 1] = xb[(size_t)m + i];    /* centre tap: identity */
+        }
+        memmove(xb, xb + c, sizeof(float) * (size_t)len);
+    }
+    memcpy(st, xb, sizeof(float) * (size_t)len);
+}
+
+/* Cascade per lane, whole-buffer stage-major.  The reference runs the same
+ * stages chunk-wise through `Major` scratch (dsp-process/src/compose.rs:581-593)
+ * with `ChunkIn<_,2>` regrouping (adapters.rs:333-339); each stage is a causal
+ * streaming operator, so chunking does not change any value. */
+int idsp_ref_hbf_dec_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
+                         size_t lanes, size_t frames, int layout)
+{
+    if (!hbf_cfg_ok(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    size_t R = (size_t)1 << cfg->stages, W = idsp_ref_hbf_dec_state_words(cfg);
+    uint32_t *st = (uint32_t *)state;
+    float *a = (float *)malloc(sizeof(float) * (frames * R + 1));
+    float *b = (float *)malloc(sizeof(float) * (frames * R / 2 + 1));
+    float *ls = (float *)malloc(sizeof(float) * W);
+    if (!a || !b || !ls) { free(a); free(b); free(ls); return IDSP_EINVAL; }
+    for (size_t l = 0; l < lanes; l++) {
+        for (size_t w = 0; w < W; w++) ls[w] = f32_from_bits(st[w * lanes + l]);
+        for (size_t f = 0; f < frames; f++)
+            memcpy(a + f * R, x + idx_of(f, l, lanes, frames, layout) * R, sizeof(float) * R);
+        size_t n = frames * R, off = 0;
+        float *src = a, *dst = b;
+        for (int s = 0; s < cfg->stages; s++) {
+            n /= 2;
+            hbf_dec_stage(cfg->taps[s], cfg->m[s], ls + off, src, dst, n);
+            off += (size_t)(3 * cfg->m[s] - 2);
+            float *t = src; src = dst; dst = t;
+        }
+        for (size_t f = 0; f < frames; f++) y[idx_of(f, l, lanes, frames, layout)] = src[f];
+        for (size_t w = 0; w < W; w++) st[w * lanes + l] = f32_to_bits(ls[w]);
+    }
+    free(a); free(b); free(ls);
+    return IDSP_OK;
+}
+
+int idsp_ref_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
+                         size_t lanes, size_t frames, int layout)
+{
+    if (!hbf_cfg_ok(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    size_t R = (size_t)1 << cfg->stages, W = idsp_ref_hbf_int_state_words(cfg);
+    uint32_t *st = (uint32_t *)state;
+    float *a = (float *)malloc(sizeof(float) * (frames * R + 1));
+    float *b = (float *)malloc(sizeof(float) * (frames * R + 1));
+    float *ls = (float *)malloc(sizeof(float) * W);
+    if (!a || !b || !ls) { free(a); free(b); free(ls); return IDSP_EINVAL; }
+    for (size_t l = 0; l < lanes; l++) {
+        for (size_t w = 0; w < W; w++) ls[w] = f32_from_bits(st[w * lanes + l]);
+        for (size_t f = 0; f < frames; f++) a[f] = x[idx_of(f, l, lanes, frames, layout)];
+        size_t n = frames, off = 0;
+        float *src = a, *dst = b;
+        for (int s = 0; s < cfg->stages; s++) {
+            hbf_int_stage(cfg->taps[s], cfg->m[s], ls + off, src, dst, n);
+            n *= 2;
+            off += (size_t)(2 * cfg->m[s] - 1);
+            float *t = src; src = dst; dst = t;
+        }
+        for (size_t f = 0; f < frames; f++)
+            memcpy(y + idx_of(f, l, lanes, frames, layout) * R, src + f * R, sizeof(float) * R);
+        for (size_t w = 0; w < W; w++) st[w * lanes + l] = f32_to_bits(ls[w]);
+    }
+    free(a); free(b); free(ls);
+    return IDSP_OK;
+}
+
+/* ----------------------------------------------------------------- cossin */
+
+#define COSSIN_DEPTH 7
+static uint32_t g_cossin[1 << COSSIN_DEPTH];
+static pthread_once_t g_cossin_once = PTHREAD_ONCE_INIT;
+
+/* build.rs:8-41: midpoint samples, AMPLITUDE = u16::MAX,
+ * cos = round((cos*2 - 1)*A - 1), sin = round(sin*A), entry = cos + (sin << 16). */
+static void cossin_init(void)
+{
+    const double A = 65535.0;
+    for (int i = 0; i < (1 << COSSIN_DEPTH); i++) {
+        double th = M_PI / 4. * (((double)i + 0.5) / (double)(1 << COSSIN_DEPTH));
+        double s = sin(th), c = cos(th);
+        uint32_t ci = (uint32_t)round((c * 2. - 1.) * A - 1.);
+        uint32_t si = (uint32_t)round(s * A);
+        g_cossin[i] = ci + (si << 16);
+    }
+}
+
+const uint32_t *idsp_ref_cossin_table(void)
+{
+    pthread_once(&g_cossin_once, cossin_init);
+    return g_cossin;
+}
+
+/* src/cossin.rs:14-67. */
+void idsp_ref_cossin(int32_t phase_in, int32_t *cos_out, int32_t *sin_out)
+{
+    const uint32_t *lut = idsp_ref_cossin_table();
+    uint32_t octant = (uint32_t)phase_in;
+    uint32_t ph = (uint32_t)phase_in;
+    if (octant & (1u << 29)) ph = ~ph;
+    const int ALIGN_MSB = 32 - 16 - 1;
+    ph = (ph << 3) >> (32 - COSSIN_DEPTH - ALIGN_MSB);
+    int32_t phase = (int32_t)ph;
+    uint32_t lookup = lut[phase >> ALIGN_MSB];
+    phase &= (1 << ALIGN_MSB) - 1;
+    phase -= 1 << (ALIGN_MSB - 1);
+    const int32_t PI4 = (int32_t)(M_PI / 4. * (double)(1 << 16));
+    int32_t dphi = (phase * PI4) >> 16;
+    int32_t c = (int32_t)(uint16_t)lookup + (1 << 16);
+    int32_t s = (int32_t)(lookup >> 16);
+    int32_t dcos = (s * dphi) >> COSSIN_DEPTH;
+    int32_t dsin = (c * dphi) >> (COSSIN_DEPTH + 1);
+    c = (int32_t)((uint32_t)c << (ALIGN_MSB - 1)) - dcos;
+    s = (int32_t)((uint32_t)s << ALIGN_MSB) + dsin;
+    octant ^= octant >> 1;
+    if (octant & (1u << 29)) { int32_t t = c; c = s; s = t; }
+    if (octant & (1u << 30)) c = (int32_t)(0u - (uint32_t)c);
+    if (octant & (1u << 31)) s = (int32_t)(0u - (uint32_t)s);
+    *cos_out = c;
+    *sin_out = s;
+}
+
+int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n)
+{
+    if (n && (!phase || !out)) return IDSP_EINVAL;
+    for (size_t i = 0; i < n; i++) idsp_ref_cossin(phase[i], &out[2 * i], &out[2 * i + 1]);
+    return IDSP_OK;
+}
+
+/* src/accu.rs:34-41 (state += step; yield state) -> src/complex.rs:237-240. */
+int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout)
+{
+    if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && !out))) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        uint32_t acc = st[l], step = st[lanes + l];
+        for (size_t f = 0; f < frames; f++) {
+            acc += step;
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            idsp_ref_cossin((int32_t)acc, &out[2 * i], &out[2 * i + 1]);
+        }
+        st[l] = acc;
+    }
+    return IDSP_OK;
+}
+
+/* ---------------------------------------------------- lowpass and lock-in */
+
+/* i32::saturating_sub */
+static inline int32_t sat_sub_i32(int32_t a, int32_t b)
+{
+    int64_t d = (int64_t)a - (int64_t)b;
+    return d > INT32_MAX ? INT32_MAX : (d < INT32_MIN ? INT32_MIN : (int32_t)d);
+}
+
+static inline int64_t wmul64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+
+/* src/lowpass.rs:47-78; s = [i64; N]. */
+static inline int32_t lowpass_step(int order, const int32_t *k, int64_t *s, int32_t x)
+{
+    int64_t d = (int64_t)sat_sub_i32(x, (int32_t)(s[0] >> 32)) * (int64_t)k[0];
+    int32_t y;
+    if (order == 1) {
+        s[0] = wadd64(s[0], d);
+        y = (int32_t)(s[0] >> 32);
+        s[0] = wadd64(s[0], d);
+    } else {
+        d = wadd64(d, wmul64(s[1] >> 32, (int64_t)k[1]));
+        s[1] = wadd64(s[1], d);
+        s[0] = wadd64(s[0], s[1]);
+        y = (int32_t)(s[0] >> 32);
+        s[0] = wadd64(s[0], s[1]);
+        s[1] = wadd64(s[1], d);
+    }
+    return y;
+}
+
+static int lockin_cfg_ok(const idsp_lockin_i32 *c)
+{
+    return c && (c->order == 1 || c->order == 2) && c->cascade >= 1 && c->cascade <= IDSP_LOCKIN_MAX_CASCADE;
+}
+
+size_t idsp_ref_lockin_state_words(const idsp_lockin_i32 *c)
+{
+    return lockin_cfg_ok(c) ? (size_t)(2 + 2 * c->cascade * c->order * 2) : 0;
+}
+
+/* `[Lowpass<N>; K]` array composition, sample-major `process`
+ * (dsp-process/src/compose.rs:84-93). */
+static inline int32_t lowpass_cascade(const idsp_lockin_i32 *c, int64_t *s, int32_t x)
+{
+    for (int k = 0; k < c->cascade; k++) x = lowpass_step(c->order, c->k[k], s + k * c->order, x);
+    return x;
+}
+
+int idsp_ref_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                         size_t lanes, size_t frames, int layout)
+{
+    if (!lockin_cfg_ok(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    int ns = cfg->cascade * cfg->order;
+    for (size_t l = 0; l < lanes; l++) {
+        int64_t s[IDSP_LOCKIN_MAX_CASCADE * 2];
+        for (int j = 0; j < ns; j++)
+            s[j] = (int64_t)(((uint64_t)st[(size_t)(2 * j + 1) * lanes + l] << 32) | st[(size_t)(2 * j) * lanes + l]);
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            y[i] = lowpass_cascade(cfg, s, x[i]);
+        }
+        for (int j = 0; j < ns; j++) {
+            st[(size_t)(2 * j) * lanes + l] = (uint32_t)(uint64_t)s[j];
+            st[(size_t)(2 * j + 1) * lanes + l] = (uint32_t)((uint64_t)s[j] >> 32);
+        }
+    }
+    return IDSP_OK;
+}
+
+/* src/lockin.rs:30-39 then :17-27; `x * lo` = `i32 * Q32<32>` =
+ * ((q as i64 * x as i64) >> 32) as i32 (dsp-fixedpoint/src/lib.rs:449-456,324-326). */
+int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                                size_t lanes, size_t frames, int layout)
+{
+    if (!lockin_cfg_ok(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    int ns = cfg->cascade * cfg->order;
+    for (size_t l = 0; l < lanes; l++) {
+        uint32_t acc = st[l], step = st[lanes + l];
+        int64_t s[2][IDSP_LOCKIN_MAX_CASCADE * 2];
+        for (int q = 0; q < 2; q++)
+            for (int j = 0; j < ns; j++) {
+                size_t w = (size_t)(2 + (q * ns + j) * 2);
+                s[q][j] = (int64_t)(((uint64_t)st[(w + 1) * lanes + l] << 32) | st[w * lanes + l]);
+            }
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            acc += step;
+            int32_t c, sn;
+            idsp_ref_cossin((int32_t)acc, &c, &sn);
+            int32_t xi = trunc32(mul_wide(c, x[i]) >> 32);
+            int32_t xq = trunc32(mul_wide(sn, x[i]) >> 32);
+            y[2 * i] = lowpass_cascade(cfg, s[0], xi);
+            y[2 * i + 1] = lowpass_cascade(cfg, s[1], xq);
+        }
+        st[l] = acc;
+        for (int q = 0; q < 2; q++)
+            for (int j = 0; j < ns; j++) {
+                size_t w = (size_t)(2 + (q * ns + j) * 2);
+                st[w * lanes + l] = (uint32_t)(uint64_t)s[q][j];
+                st[(w + 1) * lanes + l] = (uint32_t)((uint64_t)s[q][j] >> 32);
+            }
+    }
+    return IDSP_OK;
+}

@@ -1,0 +1,105 @@
+/*
+ * idsp_oracle.h — CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C restatement of the reference algorithms on the hot path
+ * (quartiq/idsp 0.22.0).  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load this library; nothing under
+ * idsp_amd/ may include, link or call it.
+ *
+ * Every `idsp_ref_*` function is the twin of the `idsp_*` entry point of the
+ * same name in include/idsp_hip.h: identical arguments (minus `stream`),
+ * identical buffer and state layouts, but HOST pointers, executed by a scalar
+ * loop that follows the reference line by line (citations at each function in
+ * idsp_oracle.c).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   pinned by reference known-answer tests (tests/golden/ref_kat.json):
+ *     i32 DF1 biquad + float->Q quantisation, BiquadClamp, DF2T identity,
+ *     DF1Dither doctest, HbfDec KAT + response lengths, cossin error bounds,
+ *     Accu doctest, Lanes/LaneMajor view semantics.
+ *   PARITY UNPINNED (no asserted value exists in the reference): Lowpass<1|2>,
+ *     Lockin, DirectForm1Wide, clamp on Dither/Wide, HbfInt sample values,
+ *     HBF_TAPS_98, exact cossin outputs at given phases.  For these the pin is
+ *     the agreement of two independent restatements (this file and
+ *     oracle/spec.py).
+ * The reference itself is Rust and cannot be built in this image (no
+ * rustc/cargo), so there is no oracle/_ref.
+ */
+#ifndef IDSP_ORACLE_H
+#define IDSP_ORACLE_H
+
+#include "../include/idsp_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* scalar helpers exported for direct known-answer tests */
+void idsp_ref_cossin(int32_t phase, int32_t *cos_out, int32_t *sin_out);
+const uint32_t *idsp_ref_cossin_table(void); /* 128 entries, build.rs:8-41 */
+int32_t idsp_ref_quantize_f64(double v, int frac);
+int idsp_ref_biquad_i32_from_sos(const double sos[6], int frac, idsp_biquad_i32 *out);
+int idsp_ref_biquad_f32_from_sos(const float sos[6], idsp_biquad_f32 *out);
+int idsp_ref_biquad_f32_from_sos_f64(const double sos[6], idsp_biquad_f32 *out);
+/* coefficients::Filter::{lowpass,highpass} in f64 (src/iir/coefficients.rs:266-335);
+ * w0 = angular critical frequency, q = Shape::Q. Output sos = [b0,b1,b2,a0,a1,a2]. */
+void idsp_ref_filter_lowpass(double w0, double gain, double q, double sos[6]);
+void idsp_ref_filter_highpass(double w0, double gain, double q, double sos[6]);
+
+int idsp_ref_biquad_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                            const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_df1_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state,
+                                  const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_dither(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                               const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_dither_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state,
+                                     const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_wide(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                             const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_wide_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state,
+                                   const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_cascade_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                             const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+
+int idsp_ref_biquad_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state,
+                            const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f32_df1_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state,
+                                  const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f32_df2t(const idsp_biquad_f32 *cfg, size_t n, void *state,
+                             const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f32_df2t_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state,
+                                   const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state,
+                             const float *x, float *y, size_t lanes, size_t frames, int layout);
+
+int idsp_ref_hbf_dec_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out);
+int idsp_ref_hbf_int_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out);
+int idsp_ref_hbf_dec_response_length(const idsp_hbf_cascade_f32 *cfg);
+int idsp_ref_hbf_int_response_length(const idsp_hbf_cascade_f32 *cfg);
+size_t idsp_ref_hbf_dec_state_words(const idsp_hbf_cascade_f32 *cfg);
+size_t idsp_ref_hbf_int_state_words(const idsp_hbf_cascade_f32 *cfg);
+int idsp_ref_hbf_dec_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
+                         size_t lanes, size_t frames, int layout);
+int idsp_ref_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
+                         size_t lanes, size_t frames, int layout);
+
+int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n);
+int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout);
+size_t idsp_ref_lockin_state_words(const idsp_lockin_i32 *cfg);
+int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x,
+                                int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                         size_t lanes, size_t frames, int layout);
+
+/* CPU-baseline helper for bench.py: run idsp_ref_biquad_i32_df1 over `lanes`
+ * split across `threads` POSIX threads (contiguous lane blocks, LANE_MAJOR or
+ * FRAME_MAJOR as given).  threads == 1 mirrors the reference's serial lane
+ * loop (dsp-process/src/compose.rs:490-492). */
+int idsp_ref_biquad_i32_df1_mt(const idsp_biquad_i32 *cfg, size_t n, void *state,
+                               const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                               int layout, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,112 @@
+"""Two interchangeable back ends with numpy in / numpy out so every known-answer
+and parity case is written once: `OracleBackend` (CPU restatement, checker) and
+`GpuBackend` (the HIP engine through its C ABI, device buffers via torch).
+
+Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from tests import _harness as H
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self):
+        self.o = H.oracle()
+
+    def stream(self, op, cfg, n, state, x, lanes, frames, layout, inplace=False):
+        x = np.ascontiguousarray(x)
+        y = x if inplace else np.empty_like(x)
+        rc = self.o.stream(op, cfg, n, state, x, y, lanes, frames, layout)
+        return rc, y
+
+    def cfgcall(self, op, cfg, state, x, y_shape, y_dtype, lanes, frames, layout):
+        x = np.ascontiguousarray(x) if x is not None else None
+        y = np.empty(y_shape, dtype=y_dtype)
+        rc = self.o.cfgcall(op, cfg, state, x, y, lanes, frames, layout)
+        return rc, y
+
+    def cossin(self, phases):
+        phases = np.ascontiguousarray(phases, dtype=np.int32)
+        out = np.empty((phases.size, 2), dtype=np.int32)
+        rc = self.o.fn["cossin_i32"](H._ptr(phases), H._ptr(out), phases.size)
+        return rc, out
+
+    def dds(self, state, lanes, frames, layout):
+        out = np.empty(lanes * frames * 2, dtype=np.int32)
+        rc = self.o.fn["dds_i32"](H._ptr(state), H._ptr(out), lanes, frames, layout)
+        return rc, out
+
+    def helper(self, name, *args):
+        return self.o.fn[name](*args)
+
+
+class GpuBackend:
+    name = "hip"
+
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+        self.e = H.engine()
+        self.dev = torch.device("cuda:0")
+
+    def _up(self, a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a)
+        view = a.view(np.int32) if a.dtype == np.uint32 else a
+        return self.torch.from_numpy(view.copy()).to(self.dev)
+
+    def _down(self, t, like_dtype):
+        a = t.cpu().numpy()
+        return a.view(like_dtype) if a.dtype != like_dtype else a
+
+    def stream(self, op, cfg, n, state, x, lanes, frames, layout, inplace=False):
+        torch = self.torch
+        xs = self._up(x)
+        ys = xs if inplace else torch.empty_like(xs)
+        if not inplace:
+            ys.fill_(-77 if xs.dtype == torch.int32 else float("nan"))  # poison: every element must be written
+        ss = self._up(state)
+        rc = self.e.stream(op, cfg, n, ss, xs, ys, lanes, frames, layout)
+        torch.cuda.synchronize()
+        if ss is not None:
+            state[...] = self._down(ss, np.uint32).reshape(state.shape)
+        return rc, self._down(ys, x.dtype).reshape(np.shape(x))
+
+    def cfgcall(self, op, cfg, state, x, y_shape, y_dtype, lanes, frames, layout):
+        torch = self.torch
+        xs = self._up(x)
+        tdt = torch.float32 if y_dtype == np.float32 else torch.int32
+        ys = torch.empty(int(np.prod(y_shape)), dtype=tdt, device=self.dev)
+        ys.fill_(float("nan") if tdt == torch.float32 else -77)
+        ss = self._up(state)
+        rc = self.e.cfgcall(op, cfg, ss, xs, ys, lanes, frames, layout)
+        torch.cuda.synchronize()
+        state[...] = self._down(ss, np.uint32).reshape(state.shape)
+        return rc, self._down(ys, y_dtype).reshape(y_shape)
+
+    def cossin(self, phases):
+        torch = self.torch
+        ps = self._up(np.ascontiguousarray(phases, dtype=np.int32))
+        out = torch.empty(ps.numel() * 2, dtype=torch.int32, device=self.dev)
+        rc = self.e.fn["cossin_i32"](H._ptr(ps), H._ptr(out), ps.numel(), None)
+        torch.cuda.synchronize()
+        return rc, out.cpu().numpy().reshape(-1, 2)
+
+    def dds(self, state, lanes, frames, layout):
+        torch = self.torch
+        ss = self._up(state)
+        out = torch.empty(lanes * frames * 2, dtype=torch.int32, device=self.dev)
+        rc = self.e.fn["dds_i32"](H._ptr(ss), H._ptr(out), lanes, frames, layout, None)
+        torch.cuda.synchronize()
+        state[...] = self._down(ss, np.uint32).reshape(state.shape)
+        return rc, out.cpu().numpy()
+
+    def helper(self, name, *args):
+        return self.e.fn[name](*args)

@@ -1,0 +1,269 @@
+"""The reference's own known-answer tests for the hot path, written once against
+a back end (`tests/_backends.py`).  `test_oracle_kat.py` runs them on the CPU
+oracle (pinning it), `test_gpu_reference_kat.py` replays them through the HIP
+path.  Data comes from tests/golden/ref_kat.json (each entry cites the
+reference file:line that asserts it)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+
+from idsp_amd import _abi
+from tests import _harness as H
+
+FM, LM = H.FM, H.LM
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kat.json")))
+INF = {"inf": math.inf, "-inf": -math.inf}
+
+
+def _f(v):
+    return INF.get(v, v) if isinstance(v, str) else v
+
+
+def _f32bits(vals):
+    return np.asarray(vals, dtype=np.float32).view(np.uint32)
+
+
+def _sos_builder(be, entry):
+    """coefficients::Filter::{lowpass,highpass} (f64) -> Biquad<Q32<F>> through the
+    back end's own ingestion helper (idsp[_ref]_biquad_i32_from_sos)."""
+    w0 = math.tau * entry["critical_frequency"]
+    q = 1.0 / math.sqrt(2.0)  # Shape::default(), src/iir/coefficients.rs:19-22
+    fsin, fcos = math.sin(w0), math.cos(w0)
+    alpha = 0.5 * fsin * (1.0 / q)
+    if entry["builder"] == "lowpass":  # src/iir/coefficients.rs:276-283
+        b = entry["gain"] * 0.5 * (1.0 - fcos)
+        sos = [b, 2.0 * b, b, 1.0 + alpha, -2.0 * fcos, 1.0 - alpha]
+    else:  # src/iir/coefficients.rs:328-335
+        b = entry["gain"] * 0.5 * (1.0 + fcos)
+        sos = [b, -2.0 * b, b, 1.0 + alpha, -2.0 * fcos, 1.0 - alpha]
+    out = _abi.BiquadI32()
+    assert be.helper("biquad_i32_from_sos", (C.c_double * 6)(*sos), entry["frac"], C.byref(out)) == 0
+    return out
+
+
+def case_biquad_i32_filter(be):
+    for e in KAT["biquad_i32_filter"]:
+        cfg = _sos_builder(be, e)
+        for layout in (FM, LM):
+            x = np.array(e["x"], dtype=np.int32)  # `iir.inplace(&mut DirectForm1::default(), &mut xy)`
+            st = np.zeros((4, 1), dtype=np.uint32)
+            rc, y = be.stream("biquad_i32_df1", (_abi.BiquadI32 * 1)(cfg), 1, st, x, 1, len(x), layout, inplace=True)
+            assert rc == 0
+            assert y.tolist() == e["y"], e["cite"]
+
+
+def case_biquad_f32_df1_state(be):
+    e = KAT["biquad_f32_df1_state"]
+    st = _f32bits(e["state_x"] + e["state_y"]).reshape(4, 1).copy()
+    rc, y = be.stream("biquad_f32_df1", H.biquad_f32([e["ba"]]), 1, st, np.array([e["x0"]], np.float32), 1, 1, FM)
+    assert rc == 0 and y[0] == e["y0"]
+    assert st.view(np.float32)[:, 0].tolist() == e["after_x"] + e["after_y"]
+
+
+def case_biquad_f32_simple(be):
+    for e in KAT["biquad_f32_simple"]:
+        st = _f32bits([0.0, 0.0] + e["state_y"]).reshape(4, 1).copy()
+        rc, y = be.stream("biquad_f32_df1", H.biquad_f32([e["ba"]]), 1, st, np.array([e["x0"]], np.float32), 1, 1, LM)
+        assert rc == 0 and y[0] == e["y0"], e["cite"]
+
+
+def case_biquad_f32_clamp(be):
+    for e in KAT["biquad_f32_clamp"]:
+        # BiquadClamp::<f32>::default(): zero coefficients, u/min/max as given
+        cfg = H.biquad_clamp_f32([([0.0] * 5, _f(e["u"]), _f(e["min"]), _f(e["max"]))])
+        st = np.zeros((4, 1), dtype=np.uint32)
+        rc, y = be.stream("biquad_f32_df1_clamp", cfg, 1, st, np.array([e["x0"]], np.float32), 1, 1, FM)
+        assert rc == 0 and y[0] == e["y0"], e["cite"]
+
+
+def case_biquad_f32_df2t_identity(be):
+    for e in KAT["biquad_f32_df2t_identity"]:
+        st = np.zeros((2, 1), dtype=np.uint32)
+        x = np.array([e["x0"]], np.float32)
+        if e["clamp"]:
+            cfg = H.biquad_clamp_f32([([1.0, 0, 0, 0, 0], 0.0, -math.inf, math.inf)])
+            rc, y = be.stream("biquad_f32_df2t_clamp", cfg, 1, st, x, 1, 1, FM)
+        else:
+            rc, y = be.stream("biquad_f32_df2t", H.biquad_f32([[1.0, 0, 0, 0, 0]]), 1, st, x, 1, 1, FM)
+        assert rc == 0 and y[0] == e["y0"], e["cite"]
+
+
+def case_biquad_i32_dither(be):
+    e = KAT["biquad_i32_dither"]
+    st = np.array(e["state_x"] + e["state_y"] + [e["e"]], dtype=np.uint32).reshape(5, 1)
+    rc, y = be.stream("biquad_i32_dither", H.biquad_i32([(e["ba"], e["frac"])]), 1, st, np.array([e["x0"]], np.int32), 1, 1, FM)
+    assert rc == 0 and y[0] == e["y0"]
+    assert st[:, 0].tolist() == e["after_x"] + e["after_y"] + [e["after_e"]]
+
+
+def _f32_from_sos(be, sos):
+    out = _abi.BiquadF32()
+    # `Biquad::from([[0.7, -0.4, 0.1], [1.0, -0.2, 0.05]])` infers f32 from the state type
+    assert be.helper("biquad_f32_from_sos", (C.c_float * 6)(*sos), C.byref(out)) == 0
+    return list(out.ba)
+
+
+def case_biquad_f32_df1_vs_df2t(be):
+    e = KAT["biquad_f32_df1_vs_df2t"]
+    ba = _f32_from_sos(be, e["sos"])
+    x = np.array(e["x"], np.float32)
+    _, y1 = be.stream("biquad_f32_df1", H.biquad_f32([ba]), 1, np.zeros((4, 1), np.uint32), x, 1, len(x), LM)
+    _, y2 = be.stream("biquad_f32_df2t", H.biquad_f32([ba]), 1, np.zeros((2, 1), np.uint32), x, 1, len(x), LM)
+    assert np.all(np.abs(y1 - y2) < e["tol"])
+
+
+def case_biquad_f32_cascade_vs_repeated(be):
+    e = KAT["biquad_f32_cascade_vs_repeated"]
+    ba = _f32_from_sos(be, e["sos"])
+    n = e["sections"]
+    x = np.array(e["x"], np.float32)
+    _, yc = be.stream("cascade_f32_df1", H.biquad_f32([ba] * n), n, np.zeros((2 + 2 * n, 1), np.uint32), x, 1, len(x), LM)
+    _, yr = be.stream("biquad_f32_df1", H.biquad_f32([ba] * n), n, np.zeros((4 * n, 1), np.uint32), x, 1, len(x), LM)
+    assert np.all(np.abs(yc - yr) < e["tol"])
+    assert np.array_equal(yc.view(np.uint32), yr.view(np.uint32))  # same expression tree: bit-identical
+
+
+def case_hbf_dec_single(be):
+    e = KAT["hbf_dec_single"]
+    cfg = H.hbf_cfg([e["taps"]])
+    st = np.zeros((1, 1), dtype=np.uint32)  # 3M-2 = 1 word
+    x = np.array(e["x"], np.float32)
+    # `h.block(&[], &mut [])` first (src/hbf.rs:549): an empty block is a no-op
+    rc, _ = be.cfgcall("hbf_dec_f32", cfg, st, np.zeros(0, np.float32), (0,), np.float32, 1, 0, LM)
+    assert rc == 0
+    for layout in (LM, FM):
+        st[:] = 0
+        rc, y = be.cfgcall("hbf_dec_f32", cfg, st, x, (4,), np.float32, 1, 4, layout)
+        assert rc == 0 and y.tolist() == e["y"]
+
+
+def _cascade(be, kind, tap_set, stages):
+    cfg = _abi.HbfCascadeF32()
+    assert be.helper(f"hbf_{kind}_cascade", tap_set, stages, C.byref(cfg)) == 0
+    return cfg
+
+
+def case_hbf_response_length(be):
+    e = KAT["hbf_response_length"]
+    for d, n in e["dec"].items():
+        assert be.helper("hbf_dec_response_length", C.byref(_cascade(be, "dec", e["tap_set"], int(d)))) == n
+    for d, n in e["int"].items():
+        assert be.helper("hbf_int_response_length", C.byref(_cascade(be, "int", e["tap_set"], int(d)))) == n
+
+
+def case_hbf_dec_response(be):
+    """src/hbf.rs:577-595: 100 random frames, then 64 zero frames: y[n-1] != 0, y[n] == 0."""
+    cfg = _cascade(be, "dec", 0, 4)
+    words = be.helper("hbf_dec_state_words", C.byref(cfg))
+    assert words == 118
+    st = np.zeros((words, 1), dtype=np.uint32)
+    rng = np.random.default_rng(7)
+    x = rng.random(100 * 16, dtype=np.float32)
+    rc, _ = be.cfgcall("hbf_dec_f32", cfg, st, x, (100,), np.float32, 1, 100, LM)
+    assert rc == 0
+    rc, y = be.cfgcall("hbf_dec_f32", cfg, st, np.zeros(64 * 16, np.float32), (64,), np.float32, 1, 64, LM)
+    n = be.helper("hbf_dec_response_length", C.byref(cfg))
+    assert rc == 0 and n == 57
+    assert y[n - 1] != 0.0
+    assert y[n] == 0.0 and not np.any(y[n:])
+
+
+def case_hbf_int_response_and_spectrum(be):
+    """src/hbf.rs:598-633: impulse response length and spectral mask of the x16 interpolator."""
+    e = KAT["hbf_spectrum"]
+    R = e["depth"]
+    cfg = _cascade(be, "int", 0, R)
+    r = be.helper("hbf_int_response_length", C.byref(cfg))
+    nin = (r >> R) + 1
+    x = np.zeros(nin, np.float32)
+    x[0] = 1.0
+    st = np.zeros((be.helper("hbf_int_state_words", C.byref(cfg)), 1), dtype=np.uint32)
+    rc, y = be.cfgcall("hbf_int_f32", cfg, st, x, (nin << R,), np.float32, 1, nin, LM)
+    assert rc == 0
+    assert y[r] != 0.0
+    assert not np.any(y[r + 1:])
+    z = np.zeros(e["fft_len"], dtype=np.float64)
+    z[: y.size] = y.astype(np.float64) / (1 << R)
+    p = 10.0 * np.log10(np.abs(np.fft.fft(z)) ** 2)
+    f = p.size / (1 << R)
+    p_pass = np.max(np.abs(p[: int(math.floor(f * e["passband"]))]))
+    assert p_pass < e["max_passband_ripple_db"], p_pass
+    p_stop = np.max(p[int(math.ceil(f * (1.0 - e["passband"]))): p.size // 2])
+    assert p_stop < e["max_stopband_db"], p_stop
+
+
+def case_cossin_bounds(be):
+    """src/cossin.rs:131-196 over 2^20 phases."""
+    e = KAT["cossin_bounds"]
+    depth = e["phase_depth"]
+    amp = float(1 << 31) - 0.85 * float(1 << 15)
+    phase = (np.arange(1 << depth, dtype=np.int64) << (32 - depth)).astype(np.uint32).view(np.int32)
+    rc, cs = be.cossin(phase)
+    assert rc == 0
+    have = cs.astype(np.float64) / amp
+    rad = 2.0 * np.pi * phase.astype(np.float64) / float(1 << 32)
+    want = np.stack([np.cos(rad), np.sin(rad)], axis=1)
+    err = have - want
+    assert abs(math.fsum(have[:, 0])) < e["sum_cos"]
+    assert abs(math.fsum(have[:, 1])) < e["sum_sin"]
+    assert abs(math.fsum(have[:, 0] * want[:, 0] - have[:, 1] * want[:, 1])) < e["demod_re"]
+    assert abs(math.fsum(have[:, 1] * want[:, 0] + have[:, 0] * want[:, 1])) < e["demod_im"]
+    assert abs(math.fsum(err[:, 0])) < e["sum_err"] and abs(math.fsum(err[:, 1])) < e["sum_err"]
+    assert np.sqrt(np.mean(err ** 2, axis=0)).max() < e["rms"]
+    assert np.abs(err).max() < e["max"]
+    s = KAT["survey_checksums"]
+    rc, c0 = be.cossin(np.array([0], np.int32))
+    assert c0[0].tolist() == s["cossin_0"]
+
+
+def case_cossin_spur(be):
+    """src/cossin.rs:199-230: complex DDS at bin k, first spur pair at (M +- 1)k, -120.4 dBc."""
+    e = KAT["cossin_spur"]
+    n, k = 1 << e["dds_log2"], e["k"]
+    st = np.zeros((2, 1), dtype=np.uint32)
+    st[1, 0] = np.uint32(k << (32 - e["dds_log2"]))
+    rc, out = be.dds(st, 1, n, LM)
+    assert rc == 0
+    amp = float(1 << 31) - 0.85 * float(1 << 15)
+    z = (out[0::2] + 1j * out[1::2]) / amp
+    power = np.abs(np.fft.fft(z)) ** 2
+    m = 8 * 128
+    lo, hi = n - ((m - 1) * k) % n, ((m + 1) * k) % n
+    for b in (lo, hi):
+        assert abs(10 * np.log10(power[b] / power[k]) - e["spur_dbc"]) < e["tol_db"]
+    rest = power.copy()
+    rest[k] = 0
+    assert int(np.argmax(rest)) in (lo, hi)
+
+
+def case_accu(be):
+    e = KAT["accu"]
+    st = np.array([[e["state"]], [e["step"]]], dtype=np.int64).astype(np.uint32)
+    rc, out = be.dds(st, 1, 2, FM)
+    assert rc == 0
+    o = H.oracle()
+    want = [o.cossin(p) for p in e["next"]]
+    assert out.reshape(2, 2).tolist() == [list(w) for w in want]
+    assert np.int32(st[0, 0]) == e["next"][-1]
+
+
+def case_lane_views(be):
+    e = KAT["lane_major_lanes"]
+    cfg = H.biquad_clamp_f32([([1.0, 0, 0, 0, 0], float(e["offset"]), -math.inf, math.inf)])
+    x = np.array(e["x"], np.float32)
+    st = np.zeros((4, e["lanes"]), dtype=np.uint32)
+    rc, y = be.stream("biquad_f32_df1_clamp", cfg, 1, st, x, e["lanes"], e["frames"], LM)
+    assert rc == 0 and y.tolist() == [float(v) for v in e["y"]]
+    f = KAT["frame_major_fallback"]
+    x = np.array(f["frames_x"], np.float32)
+    st = np.zeros((4, 2), dtype=np.uint32)
+    rc, y = be.stream("biquad_f32_df1_clamp", cfg, 1, st, x, 2, 2, FM)
+    assert rc == 0 and y.tolist() == [[float(v) for v in r] for r in f["frames_y"]]
+
+
+ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]
