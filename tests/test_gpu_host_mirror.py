@@ -1,0 +1,131 @@
+"""The host-side mirror driving the HIP engine, written like the reference's
+own doctests/tests (names and call shapes of dsp-process / idsp)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import idsp_amd as ia
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(gpu):
+    return gpu
+
+
+def dev(a, dtype):
+    return torch.tensor(a, dtype=dtype, device="cuda")
+
+
+def test_lowpass_doctest_inplace():
+    """src/iir/coefficients.rs:289-300 through `Split::new(iir, DirectForm1).lanes(1)`."""
+    w0 = math.tau * 0.1
+    alpha = 0.5 * math.sin(w0) * math.sqrt(2.0)
+    b = 1000.0 * 0.5 * (1.0 - math.cos(w0))
+    iir = ia.Biquad.from_sos([b, 2 * b, b, 1 + alpha, -2 * math.cos(w0), 1 - alpha], frac=30)
+    xy = dev([[3], [-4], [5], [7], [-3], [2]], torch.int32)
+    ia.Split(iir, ia.DirectForm1).lanes(1).inplace(xy)
+    assert xy.flatten().tolist() == [5, 3, 9, 25, 42, 49]
+
+
+def test_lane_major_lanes_view():
+    """dsp-process/src/lib.rs:146-154 with a per-sample offset stage."""
+    p = ia.Split(ia.BiquadClamp(ia.Biquad.identity(), u=3.0), ia.DirectForm1).lanes(2)
+    x = dev([1, 2, 3, 10, 20, 30], torch.float32)
+    y = torch.zeros(6, dtype=torch.float32, device="cuda")
+    p.process_view(ia.View(x, ia.LaneMajor, 2), ia.ViewMut(y, ia.LaneMajor, 2))
+    assert y.tolist() == [4, 5, 6, 13, 23, 33]
+    with pytest.raises(ValueError):  # frames mismatch: debug_assert_eq!(x.frames(), y.frames())
+        p.process_view(ia.View(x, ia.LaneMajor, 2), ia.ViewMut(y[:4], ia.LaneMajor, 2))
+
+
+def test_frame_major_block_and_state_continuity():
+    b = ia.Biquad.from_sos([0.2, 0.3, 0.1, 1.0, -0.5, 0.2])
+    x = torch.randn(100, 7, device="cuda")
+    whole = ia.Split(b, ia.DirectForm2Transposed).lanes(7)
+    y = torch.empty_like(x)
+    whole.block(x, y)
+    halves = ia.Split(b, ia.DirectForm2Transposed).lanes(7)
+    y2 = torch.empty_like(x)
+    halves.block(x[:37].contiguous(), y2[:37])
+    halves.block(x[37:].contiguous(), y2[37:])
+    assert torch.equal(y, y2) and torch.equal(whole.state, halves.state)
+
+
+def test_cascade_equals_serial_sections():
+    """src/iir/biquad.rs:685-699."""
+    stage = ia.Biquad.from_sos([0.5, 0.25, 0.125, 1.0, -0.1, 0.02], f32_math=True)
+    x = dev([[-0.75], [0.5], [0.0], [0.25], [-0.125], [1.0], [-0.5], [0.375]], torch.float32)
+    yc, yr = torch.empty_like(x), torch.empty_like(x)
+    ia.Split(ia.Cascade([stage] * 3)).lanes(1).block(x, yc)
+    ia.Split([stage] * 3, ia.DirectForm1).lanes(1).block(x, yr)
+    assert torch.equal(yc, yr)
+
+
+def test_hbf_dec_kat_and_cascade_gain():
+    """src/hbf.rs:548-555, then DC gain 2 per stage on HBF_DEC_CASCADE /16."""
+    h = ia.HbfDecCascade(taps=[[0.5]]).lanes(1)
+    y = torch.zeros(4, device="cuda")
+    h.process_view(ia.View(torch.ones(8, device="cuda"), ia.LaneMajor, 1, width=2), ia.ViewMut(y, ia.LaneMajor, 1))
+    assert y.tolist() == [1.5, 2.0, 2.0, 2.0]
+    d = ia.HbfDecCascade(4).lanes(3)
+    assert d.response_length() == 57 and d.state.shape == (118, 3)
+    x = torch.ones(3 * 200 * 16, device="cuda")
+    y = torch.zeros(3 * 200, device="cuda")
+    d.process_view(ia.View(x, ia.LaneMajor, 3, width=16), ia.ViewMut(y, ia.LaneMajor, 3))
+    assert abs(y[-1].item() - 16.0) < 1e-4
+
+
+def test_cossin_pyfunction_shape():
+    """src/py.rs:10-28: i32[N] -> i32[N, 2]."""
+    out = ia.cossin(dev([0, 1 << 30, -(1 << 30)], torch.int32))
+    assert out.shape == (3, 2)
+    assert out[0].tolist() == [2147454703, -1898]
+    assert abs(out[1, 0].item()) < 1 << 17 and out[1, 1].item() > (1 << 31) - (1 << 16)
+
+
+def test_sos_pyfunction_matches_oracle():
+    """src/py.rs:49-73 `sos(sos, xy)` (Q29, slice composition) on one stream."""
+    import ctypes as C
+
+    from idsp_amd import _abi
+    from tests import _harness as H
+
+    rows = [[0.1, 0.2, 0.1, 1.0, -1.2, 0.5], [0.3, -0.1, 0.05, 1.0, -0.3, 0.1]]
+    rng = np.random.default_rng(0)
+    x = rng.integers(-(1 << 26), 1 << 26, size=1000, dtype=np.int32)
+    xy = torch.from_numpy(x.copy()).cuda()
+    ia.sos(rows, xy)
+    o = H.oracle()
+    cfg = (_abi.BiquadI32 * 2)()
+    for c, r in zip(cfg, rows):
+        o.fn["biquad_i32_from_sos"]((C.c_double * 6)(*r), 29, C.byref(c))
+    st = np.zeros((8, 1), np.uint32)
+    y = x.copy()
+    assert o.stream("biquad_i32_df1", cfg, 2, st, y, y, 1, 1000, H.LM) == 0
+    assert np.array_equal(xy.cpu().numpy(), y)
+
+
+def test_lockin_recovers_dc_iq():
+    """Shape of examples/ddc_lockin.rs:100-110 on the integer lock-in: a tone at the
+    LO frequency demodulates to a DC I/Q vector; the Q32<32> mixer halves the
+    full-scale LO (cossin amplitude 2^31 read as Q32<32> = 0.5), so |IQ| = A/4."""
+    n, lanes = 16384, 4
+    f = 0.173
+    step = int(round(f * (1 << 32)))
+    phi = 0.37
+    t = np.arange(1, n + 1)
+    amp = 1 << 28
+    x = np.round(amp * np.cos(2 * np.pi * ((t * step) % (1 << 32)) / (1 << 32) - phi)).astype(np.int32)
+    k = math.pi * (1 << 31) * 0.004
+    lp = ia.Lowpass([int(k * k / (1 << 32)), -int(k * math.sqrt(2.0))])
+    p = ia.Lockin([lp, lp]).lanes(lanes, step=step)
+    xd = torch.from_numpy(np.repeat(x[:, None], lanes, axis=1).copy()).cuda()
+    y = torch.empty((n, lanes, 2), dtype=torch.int32, device="cuda")
+    p.block(xd, y)
+    iq = y[12288:].double().mean(dim=0).cpu().numpy() / amp
+    assert np.allclose(iq[:, 0], 0.25 * math.cos(phi), atol=3e-3)
+    assert np.allclose(iq[:, 1], 0.25 * math.sin(phi), atol=3e-3)

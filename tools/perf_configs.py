@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline survey over the BASELINE.json configs (C2..C5 shapes) on
+one GPU.  Development tool (bench.py is the contract benchmark): prints one
+JSON line per kernel with algorithmic GB/s against the 8 TB/s HBM peak.
+
+  python tools/perf_configs.py [--only c2,c3,...] [--iters 10]
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from idsp_amd import _abi  # noqa: E402
+from idsp_amd._lib import call  # noqa: E402
+
+PEAK = 8000.0
+dev = torch.device("cuda:0")
+
+
+def lowpass_sos(f0):
+    w0 = math.tau * f0
+    fsin, fcos = math.sin(w0), math.cos(w0)
+    alpha = 0.5 * fsin * math.sqrt(2.0)
+    b = 0.5 * (1.0 - fcos)
+    return [b, 2.0 * b, b, 1.0 + alpha, -2.0 * fcos, 1.0 - alpha]
+
+
+def timeit(fn, iters, warm=3):
+    stream = torch.cuda.current_stream()
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def report(name, units, unit_name, alg_bytes, med, mn, **extra):
+    print(json.dumps({
+        "kernel": name, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+        f"G{unit_name}/s": round(units / (med * 1e-3) / 1e9, 1),
+        "GB/s": round(alg_bytes / (med * 1e-3) / 1e9, 1), "frac_hbm_peak": round(alg_bytes / (med * 1e-3) / 1e9 / PEAK, 4),
+        **extra}), flush=True)
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def sptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def biquad(op, dtype, words, lanes, frames, layout, n_sections, iters, tag):
+    if dtype == torch.int32:
+        q = _abi.BiquadI32()
+        call("biquad_i32_from_sos", (C.c_double * 6)(*lowpass_sos(0.01)), 30, C.byref(q))
+        if "clamp" in op:
+            cfg = (_abi.BiquadClampI32 * n_sections)()
+            for c in cfg:
+                c.ba[:] = list(q.ba)
+                c.frac, c.u, c.min, c.max = 30, 3, -(1 << 30), 1 << 30
+        else:
+            cfg = (_abi.BiquadI32 * n_sections)(*([q] * n_sections))
+        x = torch.randint(-(1 << 24), 1 << 24, (lanes * frames,), dtype=torch.int32, device=dev)
+    else:
+        q = _abi.BiquadF32()
+        call("biquad_f32_from_sos_f64", (C.c_double * 6)(*lowpass_sos(0.01)), C.byref(q))
+        if "clamp" in op:
+            cfg = (_abi.BiquadClampF32 * n_sections)()
+            for c in cfg:
+                c.ba[:] = list(q.ba)
+                c.u, c.min, c.max = 0.01, -10.0, 10.0
+        else:
+            cfg = (_abi.BiquadF32 * n_sections)(*([q] * n_sections))
+        x = torch.randn(lanes * frames, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    st = torch.zeros((words * n_sections if "cascade" not in op else 2 + 2 * n_sections, lanes), dtype=torch.int32, device=dev)
+
+    def run():
+        call(op, C.cast(cfg, C.c_void_p), n_sections, p(st), p(x), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    # sections beyond 4 run as extra in-place passes: each pass moves 8 B/sample
+    passes = 1 if "cascade" in op else (n_sections + 3) // 4
+    report(f"{tag}:{op} x{n_sections} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample",
+           8 * lanes * frames * passes, med, mn)
+
+
+def hbf(kind, stages, lanes, frames_low, layout, iters, tag):
+    cfg = _abi.HbfCascadeF32()
+    call(f"hbf_{kind}_cascade", 0, stages, C.byref(cfg))
+    R = 1 << stages
+    words = call(f"hbf_{kind}_state_words", C.byref(cfg))
+    hi = torch.randn(lanes * frames_low * R, dtype=torch.float32, device=dev)
+    lo = torch.randn(lanes * frames_low, dtype=torch.float32, device=dev)
+    st = torch.zeros((words, lanes), dtype=torch.int32, device=dev)
+    x, y = (hi, lo) if kind == "dec" else (lo, hi)
+
+    def run():
+        call(f"hbf_{kind}_f32", C.byref(cfg), p(st), p(x), p(y), lanes, frames_low, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    n_hi = lanes * frames_low * R
+    report(f"{tag}:hbf_{kind} /{R} {'LM' if layout else 'FM'} {lanes}x{frames_low * R}", n_hi, "hi-rate-sample",
+           4 * n_hi + 4 * lanes * frames_low, med, mn)
+
+
+def lockin(order, cascade, lanes, frames, layout, iters, tag):
+    cfg = _abi.LockinI32()
+    cfg.order, cfg.cascade = order, cascade
+    k = math.pi * (1 << 31) * 1e-3  # f0 = 1e-3 fn (src/lowpass.rs:31-38)
+    for c in range(cascade):
+        if order == 1:
+            cfg.k[c][0] = int(k)
+        else:
+            cfg.k[c][0], cfg.k[c][1] = int(k * k / (1 << 32)), -int(k * math.sqrt(2.0))
+    words = call("lockin_state_words", C.byref(cfg))
+    x = torch.randint(-(1 << 28), 1 << 28, (lanes * frames,), dtype=torch.int32, device=dev)
+    y = torch.empty(lanes * frames * 2, dtype=torch.int32, device=dev)
+    st = torch.zeros((words, lanes), dtype=torch.int32, device=dev)
+    st[1] = torch.randint(-(1 << 31), (1 << 31) - 1, (lanes,), dtype=torch.int64, device=dev).to(torch.int32)
+
+    def run():
+        call("lockin_i32_process", C.byref(cfg), p(st), p(x), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:lockin Lowpass<{order}>x{cascade} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample",
+           12 * lanes * frames, med, mn)
+
+
+def dds(lanes, frames, layout, iters, tag):
+    st = torch.zeros((2, lanes), dtype=torch.int32, device=dev)
+    st[1] = torch.randint(-(1 << 31), (1 << 31) - 1, (lanes,), dtype=torch.int64, device=dev).to(torch.int32)
+    y = torch.empty(lanes * frames * 2, dtype=torch.int32, device=dev)
+
+    def run():
+        call("dds_i32", p(st), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:dds {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample", 8 * lanes * frames, med, mn)
+
+
+def cossin(n, iters, tag):
+    ph = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device=dev).to(torch.int32)
+    out = torch.empty(2 * n, dtype=torch.int32, device=dev)
+
+    def run():
+        call("cossin_i32", p(ph), p(out), n, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:cossin {n}", n, "phase", 12 * n, med, mn)
+
+
+def copy_ref(nbytes, iters):
+    a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    b = torch.empty_like(a)
+    med, mn = timeit(lambda: b.copy_(a), iters)
+    report(f"ref:torch copy {nbytes >> 20} MiB", nbytes // 4, "word", 2 * nbytes, med, mn)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    sel = set(a.only.split(",")) if a.only else None
+    it = a.iters
+    FM, LM = 0, 1
+
+    def want(k):
+        return sel is None or k in sel
+
+    if want("ref"):
+        copy_ref(1 << 30, it)
+    if want("c2"):
+        for layout in (FM, LM):
+            biquad("biquad_i32_df1", torch.int32, 4, 65536, 4096, layout, 1, it, "C2")
+    if want("i32var"):
+        for op, w in (("biquad_i32_df1_clamp", 4), ("biquad_i32_dither", 5), ("biquad_i32_dither_clamp", 5),
+                      ("biquad_i32_wide", 6), ("biquad_i32_wide_clamp", 6)):
+            biquad(op, torch.int32, w, 65536, 4096, FM, 1, it, "C2v")
+        biquad("biquad_i32_df1", torch.int32, 4, 65536, 4096, FM, 4, it, "C2v")
+        biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, 4, it, "C2v")
+        biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, 8, it, "C2v")
+    if want("f32"):
+        for op, w in (("biquad_f32_df1", 4), ("biquad_f32_df2t", 2), ("biquad_f32_df1_clamp", 4), ("biquad_f32_df2t_clamp", 2)):
+            for layout in (FM, LM):
+                biquad(op, torch.float32, w, 65536, 4096, layout, 1, it, "f32")
+    if want("c5"):
+        # one GPU's shard of C5 at 8 GPUs (2^17 lanes) and the whole C5 on one GPU (2^20 lanes)
+        biquad("biquad_f32_df2t", torch.float32, 2, 1 << 17, 4096, FM, 1, it, "C5/8")
+        biquad("biquad_f32_df2t", torch.float32, 2, 1 << 20, 4096, FM, 1, max(3, it // 3), "C5")
+        biquad("biquad_f32_df2t", torch.float32, 2, 1 << 20, 4096, LM, 1, max(3, it // 3), "C5")
+    if want("c3"):
+        hbf("dec", 4, 16384, 4096, LM, it, "C3")
+        hbf("dec", 4, 16384, 4096, FM, max(3, it // 3), "C3")
+        hbf("int", 4, 16384, 4096, LM, it, "C3i")
+    if want("hbfvar"):
+        for s in (1, 2, 3, 5):
+            hbf("dec", s, 16384, 65536 >> s, LM, it, "hbf")
+            hbf("int", s, 16384, 65536 >> s, LM, it, "hbf")
+    if want("c4"):
+        for layout in (FM, LM):
+            lockin(2, 2, 32768, 4096, layout, it, "C4")
+        lockin(1, 1, 32768, 4096, FM, it, "C4v")
+        lockin(2, 2, 65536, 4096, FM, it, "C4v")
+        dds(32768, 4096, FM, it, "dds")
+        dds(65536, 4096, FM, it, "dds")
+        cossin(1 << 27, it, "cossin")
+
+
+if __name__ == "__main__":
+    main()
