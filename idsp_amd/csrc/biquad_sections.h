@@ -1,4 +1,4 @@
-// biquad.hip — iir::Biquad / BiquadClamp / Cascade over many lanes
+// biquad_sections.h — iir::Biquad / BiquadClamp / Cascade over many lanes
 // (reference: src/iir/biquad.rs; fixed-point semantics dsp-fixedpoint/src).
 //
 // Each section type is a small device functor operating on the per-lane state
@@ -6,18 +6,22 @@
 // serial sections sample-major, which yields the same values as the
 // reference's stage-major slice composition (dsp-process/src/compose.rs:43-77)
 // because every section is a causal function of its own input sequence.
+// The extern "C" entry points live in biquad_*.hip (one translation unit per
+// family so the many template instances compile in parallel).
 //
 // Integer paths are bit-exact restatements of Rust release (wrapping)
 // arithmetic: i32 x i32 -> i64 products (v_mad_i64_i32), wrapping i64 sums,
 // arithmetic `>> F`, truncating casts.  Float paths keep the reference's
 // left-to-right association with every product and sum rounded separately
 // (the library is compiled with -ffp-contract=off; f32 denormals enabled).
+#pragma once
+
 #include <type_traits>
 
 #include "lane_stream.h"
 
 namespace idsp {
-namespace {
+namespace bq {
 
 constexpr int kMaxChain = 4;    // sections fused per launch; longer chains run in passes
 constexpr int kMaxCascade = 8;  // Cascade<[Biquad; N]> shares delay lines: single launch
@@ -66,6 +70,7 @@ struct Df1I32 {
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 4;  // x0 x1 y0 y1
+    static constexpr int COST = 50;  // ~VALU cycles per sample and wave (5 quarter-rate 64-bit MADs)
     static __device__ __forceinline__ int32_t step(const SecI32 &c, uint32_t (&s)[W], int32_t x0)
     {
         int32_t y0 = shr_lo(sum5(c, x0, int32_t(s[0]), int32_t(s[1]), int32_t(s[2]), int32_t(s[3])), c.frac);
@@ -84,6 +89,7 @@ struct DitherI32 {
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 5;  // x0 x1 y0 y1 e
+    static constexpr int COST = 60;
     static __device__ __forceinline__ int32_t step(const SecI32 &c, uint32_t (&s)[W], int32_t x0)
     {
         int64_t acc = wadd(int64_t(uint64_t(s[4])), sum5(c, x0, int32_t(s[0]), int32_t(s[1]), int32_t(s[2]), int32_t(s[3])));
@@ -107,6 +113,7 @@ struct WideI32 {
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 6;  // x0 x1 y0.lo y0.hi y1.lo y1.hi
+    static constexpr int COST = 100;
     static __device__ __forceinline__ int32_t step(const SecI32 &c, uint32_t (&s)[W], int32_t x0)
     {
         int64_t acc = mulw(c.ba[0], x0);
@@ -140,6 +147,7 @@ struct Df1F32 {
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 4;
+    static constexpr int COST = 24;  // 9 full-rate f32 ops + moves
     static __device__ __forceinline__ float step(const SecF32 &c, uint32_t (&s)[W], float x0)
     {
         float acc = c.ba[0] * x0;
@@ -162,6 +170,7 @@ struct Df2tF32 {
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 2;  // s0 s1
+    static constexpr int COST = 22;
     static __device__ __forceinline__ float step(const SecF32 &c, uint32_t (&s)[W], float x0)
     {
         float y0 = __uint_as_float(s[0]) + c.ba[0] * x0;
@@ -182,6 +191,7 @@ struct Chain {
     using Out = typename Sec::T;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
+    static constexpr int COST = N * Sec::COST;
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
 
@@ -216,6 +226,7 @@ struct CascadeDf1 {
     using Out = T;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
+    static constexpr int COST = N * (std::is_same<T, float>::value ? 24 : 50);
     using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32, SecI32>::type;
     using Params = ChainParams<SecT, N>;
     static constexpr int W = 2 + 2 * N;
@@ -327,7 +338,7 @@ int run_cascade(CfgFill fill, size_t n, void *state, const T *x, T *y, size_t la
     }
 }
 
-int check_frac(int frac, size_t k)
+inline int check_frac(int frac, size_t k)
 {
     // `const { assert!(F >= 0 && F < 32) }` biquad.rs:448-450,513-515
     if (frac < 0 || frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, frac);
@@ -397,90 +408,5 @@ int entry_f32(const Cfg *cfg, size_t n, void *state, const float *x, float *y, s
     return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 
-}  // namespace
+}  // namespace bq
 }  // namespace idsp
-
-using namespace idsp;
-
-extern "C" {
-
-int idsp_biquad_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
-                        size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_i32<Df1I32<false>, idsp_biquad_i32, FillI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_i32_df1_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x,
-                              int32_t *y, size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_i32<Df1I32<true>, idsp_biquad_clamp_i32, FillClampI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_i32_dither(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
-                           size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_i32<DitherI32<false>, idsp_biquad_i32, FillI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_i32_dither_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x,
-                                 int32_t *y, size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_i32<DitherI32<true>, idsp_biquad_clamp_i32, FillClampI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_i32_wide(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
-                         size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_i32<WideI32<false>, idsp_biquad_i32, FillI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_i32_wide_clamp(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x,
-                               int32_t *y, size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_i32<WideI32<true>, idsp_biquad_clamp_i32, FillClampI32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_cascade_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
-                         size_t lanes, size_t frames, int layout, void *stream)
-{
-    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
-    if (rc) return rc;
-    if (n > size_t(kMaxCascade)) return fail(IDSP_EINVAL, "cascade sections n = %zu > %d", n, kMaxCascade);
-    for (size_t k = 0; k < n; k++)
-        if ((rc = check_frac(cfg[k].frac, k))) return rc;
-    return run_cascade<int32_t>(FillI32{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
-}
-
-int idsp_biquad_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
-                        size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_f32<Df1F32<false>, idsp_biquad_f32, FillF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_f32_df1_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state, const float *x, float *y,
-                              size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_f32<Df1F32<true>, idsp_biquad_clamp_f32, FillClampF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_f32_df2t(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
-                         size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_f32<Df2tF32<false>, idsp_biquad_f32, FillF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_f32_df2t_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state, const float *x, float *y,
-                               size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_f32<Df2tF32<true>, idsp_biquad_clamp_f32, FillClampF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
-                         size_t lanes, size_t frames, int layout, void *stream)
-{
-    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
-    if (rc) return rc;
-    return run_cascade<float>(FillF32{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
-}
-
-}  // extern "C"

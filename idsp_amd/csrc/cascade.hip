@@ -1,0 +1,28 @@
+// cascade.hip — C-ABI entry points (include/idsp_hip.h) of this family; device code in biquad_sections.h.
+#include "biquad_sections.h"
+
+using namespace idsp;
+using namespace idsp::bq;
+
+extern "C" {
+
+int idsp_cascade_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (n > size_t(kMaxCascade)) return fail(IDSP_EINVAL, "cascade sections n = %zu > %d", n, kMaxCascade);
+    for (size_t k = 0; k < n; k++)
+        if ((rc = check_frac(cfg[k].frac, k))) return rc;
+    return run_cascade<int32_t>(FillI32{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+int idsp_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    return run_cascade<float>(FillF32{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+}  // extern "C"

@@ -132,6 +132,7 @@ struct LowpassProc {
     using Out = int32_t;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
+    static constexpr int COST = 40 * N * K;
     using Params = LpParams;
     LpBank<N, K> b;
     __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane) { b.load(st, lanes, lane, 0); }
@@ -145,6 +146,7 @@ struct DdsProc {
     using Out = Cplx;
     static constexpr bool HAS_IN = false;
     static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int COST = 100;
     struct Params {
         int32_t unused;
     };
@@ -173,6 +175,7 @@ struct LockinProc {
     using Out = Cplx;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int COST = 110 + 80 * N * K;
     using Params = LpParams;
     const uint32_t *lut;
     uint32_t acc, inc;
