@@ -42,6 +42,22 @@ inline int check_stream_args(const void *cfg, size_t n, const void *state, const
     return IDSP_OK;
 }
 
+// Workgroup barrier that orders LDS traffic only.  HIP's __syncthreads() also
+// drains vmcnt (all global loads AND stores of the wave), which serialises
+// every register prefetch and every output store behind the next barrier; the
+// kernels here only ever exchange data through LDS, so they wait for lgkmcnt
+// alone and leave global memory operations in flight across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// Same for a single-wave workgroup: LDS operations of one wave execute in
+// order, so only the compiler must be kept from moving accesses across.
+__device__ __forceinline__ void lds_wave_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 inline int launch_status()
 {
     hipError_t e = hipGetLastError();

@@ -23,13 +23,20 @@
 // so the new samples start 16-byte aligned (wide aligned writes) and a thread
 // that owns outputs i0..i0+3 (i0 % 4 == 0) reads its window with aligned
 // ds_read_b128 from word i0 and addresses it with the compile-time offset d.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
+#include "hbf_taps.h"
 
 namespace idsp {
 
 bool hbf_cfg_ok(const idsp_hbf_cascade_f32 *c);  // api_util.hip
+// hbf_wave_{dec,int}.hip: statically specialised kernels for the built-in cascades (0 = launched)
+int hbf_wave_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
+                 bool lane_major, hipStream_t stream);
+int hbf_wave_int(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
+                 bool lane_major, hipStream_t stream);
 
 namespace {
 
@@ -44,8 +51,15 @@ struct HbfArgs {
     int32_t buf_b[IDSP_HBF_MAX_STAGES];  // LDS word offset: dec odd stream
     int32_t st_off[IDSP_HBF_MAX_STAGES + 1];  // state word offset of each stage (+ total)
     int32_t stage_off;                        // LDS word offset: FRAME_MAJOR output staging
+    int32_t ablate;                           // DEBUG: bit s set = skip stage s arithmetic (timing ablation only)
     float taps[IDSP_HBF_MAX_STAGES][IDSP_HBF_MAX_TAPS];
 };
+
+// native clang vectors: one ds_read_b128 / ds_write_b128 / global dwordx4 per access (HIP's
+// float4 is a struct whose member-wise copies the compiler splits into ds_read2_b32 pairs,
+// which bank-conflict 4-way at a 16-byte lane stride)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __host__ __device__ constexpr int pad4(int h) { return (4 - h % 4) % 4; }
 __host__ __device__ constexpr int up4(int v) { return (v + 3) & ~3; }
@@ -78,12 +92,12 @@ __device__ __forceinline__ void dec_stage(const float *E, const float *O, int n,
         float w[WO], e[WE];
 #pragma unroll
         for (int v = 0; v < WO / 4; v++) {
-            const float4 t = *reinterpret_cast<const float4 *>(O + i0 + 4 * v);
+            const v4f t = *reinterpret_cast<const v4f *>(O + i0 + 4 * v);
             w[4 * v] = t.x, w[4 * v + 1] = t.y, w[4 * v + 2] = t.z, w[4 * v + 3] = t.w;
         }
 #pragma unroll
         for (int v = 0; v < WE / 4; v++) {
-            const float4 t = *reinterpret_cast<const float4 *>(E + i0 + 4 * v);
+            const v4f t = *reinterpret_cast<const v4f *>(E + i0 + 4 * v);
             e[4 * v] = t.x, e[4 * v + 1] = t.y, e[4 * v + 2] = t.z, e[4 * v + 3] = t.w;
         }
         float out[4];
@@ -95,8 +109,8 @@ __device__ __forceinline__ void dec_stage(const float *E, const float *O, int n,
                 if (i0 + p < n) yg[i0 + p] = out[p];
         } else {
             // `ChunkIn<_, 2>`: consecutive outputs pair up as the next [even, odd]
-            *reinterpret_cast<float2 *>(En + (i0 >> 1)) = make_float2(out[0], out[2]);
-            *reinterpret_cast<float2 *>(On + (i0 >> 1)) = make_float2(out[1], out[3]);
+            *reinterpret_cast<v2f *>(En + (i0 >> 1)) = v2f{out[0], out[2]};
+            *reinterpret_cast<v2f *>(On + (i0 >> 1)) = v2f{out[1], out[3]};
         }
     }
 }
@@ -164,34 +178,57 @@ __global__ __launch_bounds__(kThreads) void hbf_dec_kernel(const HbfArgs a, uint
     const bool vec4 = lane_major && ((frames * size_t(R)) % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     float *ystage = lds + a.stage_off;
 
+    // Register prefetch of the next chunk (vec4 path): the global loads of chunk c+1 are
+    // issued right after chunk c has been handed to LDS, so their HBM latency overlaps the
+    // stage arithmetic instead of stalling the workgroup at the top of every chunk.
+    constexpr int kPre = kChunk / 4 / kThreads;  // float4 pieces per thread and chunk
+    v4f pre[kPre];
+    auto fetch = [&](size_t f0) {
+        const int nf = int(frames - f0 < ch ? frames - f0 : ch);
+        const v4f *x4 = reinterpret_cast<const v4f *>(x + (lane * frames + f0) * size_t(R));
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int q = tid + i * kThreads;
+            if (q < nf * R / 4) pre[i] = x4[q];
+        }
+    };
+    if (vec4) fetch(0);
+
     for (size_t f0 = 0; f0 < frames; f0 += ch) {
         const int nf = int(frames - f0 < ch ? frames - f0 : ch);
         const int nin = nf * R;
         // stage-0 input: pairs [even, odd] split into the two streams
         if (vec4) {
-            const float4 *x4 = reinterpret_cast<const float4 *>(x + (lane * frames + f0) * size_t(R));
-            for (int q = tid; q < nin / 4; q += kThreads) {
-                const float4 v = x4[q];
-                *reinterpret_cast<float2 *>(E0n + 2 * q) = make_float2(v.x, v.z);
-                *reinterpret_cast<float2 *>(O0n + 2 * q) = make_float2(v.y, v.w);
+#pragma unroll
+            for (int i = 0; i < kPre; i++) {
+                const int q = tid + i * kThreads;
+                if (q < nin / 4) {
+                    *reinterpret_cast<v2f *>(E0n + 2 * q) = v2f{pre[i].x, pre[i].z};
+                    *reinterpret_cast<v2f *>(O0n + 2 * q) = v2f{pre[i].y, pre[i].w};
+                }
             }
+            if (f0 + ch < frames) fetch(f0 + ch);
         } else {
             const int ppf = R / 2;  // pairs per frame
             for (int q = tid; q < nin / 2; q += kThreads) {
                 const size_t f = f0 + size_t(q / ppf);
                 const size_t base = lane_major ? (lane * frames + f) * size_t(R) : (f * lanes + lane) * size_t(R);
-                const float2 v = *reinterpret_cast<const float2 *>(x + base + size_t(q % ppf) * 2);
+                const v2f v = *reinterpret_cast<const v2f *>(x + base + size_t(q % ppf) * 2);
                 E0n[q] = v.x;
                 O0n[q] = v.y;
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         int n = nin;
         for (int s = 0; s < S; s++) {
             n >>= 1;
             const int M = a.m[s];
             const float *E = lds + a.buf_a[s], *O = lds + a.buf_b[s];
+            if (a.ablate & (1 << s)) {
+                lds_barrier();
+                continue;
+            }
             if (s + 1 < S) {
                 const int Mn = a.m[s + 1];
                 dec_stage_dispatch(M, E, O, n, a.taps[s], lds + a.buf_a[s + 1] + up4(Mn - 1),
@@ -205,11 +242,11 @@ __global__ __launch_bounds__(kThreads) void hbf_dec_kernel(const HbfArgs a, uint
                     dec_stage_dispatch(M, E, O, n, a.taps[s], nullptr, nullptr, ystage, tid);
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         if (!lane_major) {
             for (int i = tid; i < nf; i += kThreads) y[(f0 + size_t(i)) * lanes + lane] = ystage[i];
-            __syncthreads();
+            lds_barrier();
         }
 
         // roll the histories: word j <- word n_s + j (src/hbf.rs:182-183)
@@ -222,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void hbf_dec_kernel(const HbfArgs a, uint
             const int ns = nin >> (s + 1);
             keep[c & 1] = j < He ? lds[a.buf_a[s] + pad4(He) + ns + j] : lds[a.buf_b[s] + pad4(2 * M - 1) + ns + (j - He)];
         }
-        __syncthreads();
+        lds_barrier();
         c = 0;
         for (int w = tid; w < a.st_off[S]; w += kThreads, c++) {
             int s = 0;
@@ -233,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void hbf_dec_kernel(const HbfArgs a, uint
             else
                 lds[a.buf_b[s] + pad4(2 * M - 1) + (j - He)] = keep[c & 1];
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     for (int w = tid; w < a.st_off[S]; w += kThreads) {
@@ -260,7 +297,7 @@ __device__ __forceinline__ void int_stage(const float *X, int n, const float (&t
         float w[WX];
 #pragma unroll
         for (int v = 0; v < WX / 4; v++) {
-            const float4 t = *reinterpret_cast<const float4 *>(X + i0 + 4 * v);
+            const v4f t = *reinterpret_cast<const v4f *>(X + i0 + 4 * v);
             w[4 * v] = t.x, w[4 * v + 1] = t.y, w[4 * v + 2] = t.z, w[4 * v + 3] = t.w;
         }
         float out[8];
@@ -271,8 +308,8 @@ __device__ __forceinline__ void int_stage(const float *X, int n, const float (&t
         }
         if (yg) {
             if (yvec && i0 + 4 <= n) {
-                *reinterpret_cast<float4 *>(yg + 2 * i0) = make_float4(out[0], out[1], out[2], out[3]);
-                *reinterpret_cast<float4 *>(yg + 2 * i0 + 4) = make_float4(out[4], out[5], out[6], out[7]);
+                *reinterpret_cast<v4f *>(yg + 2 * i0) = v4f{out[0], out[1], out[2], out[3]};
+                *reinterpret_cast<v4f *>(yg + 2 * i0 + 4) = v4f{out[4], out[5], out[6], out[7]};
             } else {
 #pragma unroll
                 for (int p = 0; p < 8; p++)
@@ -280,8 +317,8 @@ __device__ __forceinline__ void int_stage(const float *X, int n, const float (&t
             }
         } else {
             // `ChunkOut<_, 2>`: the pairs flatten into the next stage's input stream
-            *reinterpret_cast<float4 *>(Xn + 2 * i0) = make_float4(out[0], out[1], out[2], out[3]);
-            *reinterpret_cast<float4 *>(Xn + 2 * i0 + 4) = make_float4(out[4], out[5], out[6], out[7]);
+            *reinterpret_cast<v4f *>(Xn + 2 * i0) = v4f{out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<v4f *>(Xn + 2 * i0 + 4) = v4f{out[4], out[5], out[6], out[7]};
         }
     }
 }
@@ -333,11 +370,28 @@ __global__ __launch_bounds__(kThreads) void hbf_int_kernel(const HbfArgs a, uint
     float *X0n = lds + a.buf_a[0] + up4(2 * a.m[0] - 1);
     float *ystage = lds + a.stage_off;  // FRAME_MAJOR output chunks
 
+    // next chunk's inputs are fetched one chunk ahead (ch <= 2048 frames -> <= 8 per thread)
+    constexpr int kPreI = (kChunk / 2) / kThreads;
+    float pre[kPreI];
+    auto fetch = [&](size_t f0) {
+        const int nf = int(frames - f0 < ch ? frames - f0 : ch);
+#pragma unroll
+        for (int i = 0; i < kPreI; i++) {
+            const int j = tid + i * kThreads;
+            if (j < nf) pre[i] = lane_major ? x[lane * frames + f0 + size_t(j)] : x[(f0 + size_t(j)) * lanes + lane];
+        }
+    };
+    fetch(0);
+
     for (size_t f0 = 0; f0 < frames; f0 += ch) {
         const int nf = int(frames - f0 < ch ? frames - f0 : ch);
-        for (int i = tid; i < nf; i += kThreads)
-            X0n[i] = lane_major ? x[lane * frames + f0 + size_t(i)] : x[(f0 + size_t(i)) * lanes + lane];
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kPreI; i++) {
+            const int j = tid + i * kThreads;
+            if (j < nf) X0n[j] = pre[i];
+        }
+        if (f0 + ch < frames) fetch(f0 + ch);
+        lds_barrier();
 
         int n = nf;
         for (int s = 0; s < S; s++) {
@@ -352,13 +406,13 @@ __global__ __launch_bounds__(kThreads) void hbf_int_kernel(const HbfArgs a, uint
             } else {
                 int_stage_dispatch(M, X, n, a.taps[s], ystage, nullptr, false, tid);
             }
-            __syncthreads();
+            lds_barrier();
             n <<= 1;
         }
         if (!lane_major) {
             for (int i = tid; i < nf * R; i += kThreads)
                 y[((f0 + size_t(i / R)) * lanes + lane) * size_t(R) + size_t(i % R)] = ystage[i];
-            __syncthreads();
+            lds_barrier();
         }
 
         // roll histories: word j <- word n_s + j (src/hbf.rs:224)
@@ -370,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void hbf_int_kernel(const HbfArgs a, uint
             const int H = 2 * a.m[s] - 1, j = w - a.st_off[s];
             keep[c & 1] = lds[a.buf_a[s] + pad4(H) + (nf << s) + j];
         }
-        __syncthreads();
+        lds_barrier();
         c = 0;
         for (int w = tid; w < a.st_off[S]; w += kThreads, c++) {
             int s = 0;
@@ -378,7 +432,7 @@ __global__ __launch_bounds__(kThreads) void hbf_int_kernel(const HbfArgs a, uint
             const int H = 2 * a.m[s] - 1, j = w - a.st_off[s];
             lds[a.buf_a[s] + pad4(H) + j] = keep[c & 1];
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     for (int w = tid; w < a.st_off[S]; w += kThreads) {
@@ -415,10 +469,25 @@ int fill_args(const idsp_hbf_cascade_f32 *cfg, bool dec, HbfArgs &a, int &lds_wo
         }
     }
     a.st_off[cfg->stages] = so;
+    if (const char *e = getenv("IDSP_HBF_ABLATE")) a.ablate = atoi(e);
     a.stage_off = off;  // FRAME_MAJOR output staging: one chunk of outputs
     off += (dec ? kChunk / 2 : kChunk) + kSlack;
     lds_words = off;
     return IDSP_OK;
+}
+
+// Which built-in tap set (0 = HBF_TAPS, 1 = HBF_TAPS_98) `cfg` is, bit for bit, or -1.
+int builtin_tap_set(const idsp_hbf_cascade_f32 *cfg, bool dec)
+{
+    for (int ts = 0; ts < 2; ts++) {
+        bool same = true;
+        for (int s = 0; s < cfg->stages && same; s++) {
+            const int t = hbf_tuple_index(dec, cfg->stages, s);
+            same = cfg->m[s] == kHbfM[ts][t] && std::memcmp(cfg->taps[s], kHbfTaps[ts][t], sizeof(float) * size_t(cfg->m[s])) == 0;
+        }
+        if (same) return ts;
+    }
+    return -1;
 }
 
 template <class K>
@@ -432,6 +501,18 @@ int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state,
     if (lanes == 0 || frames == 0) return IDSP_OK;
     if (reinterpret_cast<uintptr_t>(x) % 8 || reinterpret_cast<uintptr_t>(y) % 8)
         return fail(IDSP_EINVAL, "x and y must be 8-byte aligned");
+    // Fast path: the reference's own cascades run on the specialised one-wave-per-lane
+    // kernels when every 16-byte access they make is aligned; anything else (custom taps,
+    // odd shapes) takes the generic workgroup-per-lane kernel below.
+    const int ts = getenv("IDSP_HBF_GENERIC") ? -1 : builtin_tap_set(cfg, dec);
+    const bool lm = layout == IDSP_LANE_MAJOR;
+    const size_t R = size_t(1) << cfg->stages;
+    const void *wide = dec ? static_cast<const void *>(x) : static_cast<const void *>(y);
+    if (ts >= 0 && reinterpret_cast<uintptr_t>(wide) % 16 == 0 && (lm ? (frames * R) % 4 == 0 : R >= 4)) {
+        const int rc = dec ? hbf_wave_dec(ts, cfg->stages, static_cast<uint32_t *>(state), x, y, lanes, frames, lm, as_stream(stream))
+                           : hbf_wave_int(ts, cfg->stages, static_cast<uint32_t *>(state), x, y, lanes, frames, lm, as_stream(stream));
+        if (rc == 0) return launch_status();
+    }
     HbfArgs a;
     int lds_words = 0;
     fill_args(cfg, dec, a, lds_words);

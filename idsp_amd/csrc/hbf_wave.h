@@ -1,0 +1,438 @@
+// hbf_wave.h — statically specialised half-band cascade kernels for the
+// reference's built-in cascades (HBF_DEC_CASCADE / HBF_INT_CASCADE over HBF_TAPS
+// and HBF_TAPS_98, src/hbf.rs:258-349,385-421,476-512).
+//
+// Mapping: ONE WAVE per lane, no workgroup barriers.  A wave walks its lane in
+// chunks of kCH = 1024 high-rate samples; every stage of the cascade runs inside
+// the chunk with the inter-stage streams in the wave's private LDS region (the
+// reference's `Major` scratch, dsp-process/src/compose.rs:581-593).  Because LDS
+// operations of one wave execute in order, stage hand-over needs only
+// `s_waitcnt lgkmcnt(0)`; waves never wait for each other, and with ~10 KiB of
+// LDS and < 128 VGPRs a CU holds 15-16 of them, which is what hides the HBM and
+// LDS latencies.  Stage count, tap counts, tap values, LDS offsets and the
+// outputs-per-thread blocking are all compile-time, so the tap multiplies use
+// literal constants and there is no per-stage control flow.
+//
+// Within a stage every thread produces P consecutive outputs (P = 4, 2 or 1,
+// chosen so that all 64 threads have work: n/64 clamped to 1..4) from one
+// aligned window read; the sample history the reference keeps with
+// `copy_within` (src/hbf.rs:182-183,224) sits in front of each stream buffer.
+//
+// Arithmetic: exactly `get()` (src/hbf.rs:46-68): Σ_k (new_k + old_k)·tap_k
+// accumulated sequentially from -0.0 from the outermost tap inwards, then the
+// delayed even sample (decimator) / the centre-tap identity (interpolator).
+#pragma once
+
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "hbf_taps.h"
+
+namespace idsp {
+namespace hbfw {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kW = 64;      // threads per workgroup = one wave
+constexpr int kCH = 1024;   // high-rate samples per chunk
+constexpr int kSlack = 8;   // words readable past the last valid sample of a stream
+
+constexpr int pad4(int h) { return (4 - h % 4) % 4; }
+constexpr int up4(int v) { return (v + 3) & ~3; }
+constexpr int blocking(int n) { return n >= 4 * kW ? 4 : (n >= 2 * kW ? 2 : 1); }
+
+// compile-time loop
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int TS, int S, bool DEC>
+struct Casc {
+    static constexpr int stages = S;
+    static constexpr int rate = 1 << S;
+    static constexpr int M(int s) { return kHbfM[TS][hbf_tuple_index(DEC, S, s)]; }
+    static constexpr float tap(int s, int k) { return kHbfTaps[TS][hbf_tuple_index(DEC, S, s)][k]; }
+    // full-chunk element count of stage s: decimator outputs / interpolator inputs
+    static constexpr int n(int s) { return DEC ? (kCH >> (s + 1)) : ((kCH >> S) << s); }
+    // LDS words: stream A = decimator even stream / interpolator x stream, B = decimator odd stream
+    static constexpr int sizeA(int s)
+    {
+        return DEC ? up4(up4(M(s) - 1) + n(s) + kSlack) : up4(up4(2 * M(s) - 1) + n(s) + kSlack);
+    }
+    static constexpr int sizeB(int s) { return DEC ? up4(up4(2 * M(s) - 1) + n(s) + kSlack) : 0; }
+    static constexpr int offA(int s)
+    {
+        int o = 0;
+        for (int t = 0; t < s; t++) o += sizeA(t) + sizeB(t);
+        return o;
+    }
+    static constexpr int offB(int s) { return offA(s) + sizeA(s); }
+    static constexpr int lds_words = offA(S);
+    static constexpr int state_off(int s)
+    {
+        int o = 0;
+        for (int t = 0; t < s; t++) o += DEC ? 3 * M(t) - 2 : 2 * M(t) - 1;
+        return o;
+    }
+};
+
+// Σ_k (w[lo + 2M-1-k] + w[lo + k]) * tap_k, sequential from -0.0 (src/hbf.rs:60-66)
+template <class C, int s>
+__device__ __forceinline__ float window_sum(const float *w, int lo)
+{
+    constexpr int M = C::M(s);
+    float acc = -0.0f;
+    static_for<0, M>([&](auto k) {
+        constexpr int K = decltype(k)::value;
+        acc = acc + (w[lo + 2 * M - 1 - K] + w[lo + K]) * C::tap(s, K);
+    });
+    return acc;
+}
+
+// load NV vectors of P words from an aligned LDS address into w[]
+template <int P, int NV>
+__device__ __forceinline__ void lds_window(const float *src, float *w)
+{
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        if constexpr (P == 4) {
+            const v4f t = *reinterpret_cast<const v4f *>(src + 4 * v);
+            w[4 * v] = t.x, w[4 * v + 1] = t.y, w[4 * v + 2] = t.z, w[4 * v + 3] = t.w;
+        } else if constexpr (P == 2) {
+            const v2f t = *reinterpret_cast<const v2f *>(src + 2 * v);
+            w[2 * v] = t.x, w[2 * v + 1] = t.y;
+        } else {
+            w[v] = src[v];
+        }
+    }
+}
+
+// ------------------------------------------------------------- decimator
+// stage s of `HbfDec` (src/hbf.rs:163-185): y[i] = get(odd)[i] + even[i]
+template <class C, int s, bool FULL>
+__device__ __forceinline__ void dec_stage(float *lds, int n_rt, float *yg, size_t ystride, int lid)
+{
+    constexpr int M = C::M(s), N = C::n(s), P = blocking(N);
+    constexpr int de = pad4(M - 1), dq = pad4(2 * M - 1);
+    constexpr int oq = dq % P, NV = (oq + 2 * M + P - 1 + P - 1) / P;
+    constexpr int oe = de % P, NVE = (oe + P + P - 1) / P;
+    constexpr int ITER = (N / P + kW - 1) / kW;
+    const float *E = lds + C::offA(s) + (de - oe);
+    const float *O = lds + C::offB(s) + (dq - oq);
+    const int n = FULL ? N : n_rt;
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+        const int g = lid + it * kW, i0 = g * P;
+        if (i0 >= n) continue;
+        float w[NV * P], e[NVE * P], out[P];
+        lds_window<P, NV>(O + i0, w);
+        lds_window<P, NVE>(E + i0, e);
+#pragma unroll
+        for (int p = 0; p < P; p++) out[p] = window_sum<C, s>(w, oq + p) + e[oe + p];
+        if constexpr (s + 1 == C::stages) {
+#pragma unroll
+            for (int p = 0; p < P; p++)
+                if (FULL || i0 + p < n) yg[size_t(i0 + p) * ystride] = out[p];
+        } else {
+            // `ChunkIn<_, 2>`: consecutive outputs pair up as the next stage's [even, odd]
+            constexpr int Mn = C::M(s + 1);
+            float *En = lds + C::offA(s + 1) + up4(Mn - 1), *On = lds + C::offB(s + 1) + up4(2 * Mn - 1);
+            if constexpr (P == 4) {
+                *reinterpret_cast<v2f *>(En + (i0 >> 1)) = v2f{out[0], out[2]};
+                *reinterpret_cast<v2f *>(On + (i0 >> 1)) = v2f{out[1], out[3]};
+            } else if constexpr (P == 2) {
+                En[g] = out[0];
+                On[g] = out[1];
+            } else {
+                (g & 1 ? On : En)[g >> 1] = out[0];
+            }
+        }
+    }
+}
+
+template <class C, bool FULL>
+__device__ __forceinline__ void dec_chunk(float *lds, int nin, float *yg, size_t ystride, int lid)
+{
+    static_for<0, C::stages>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        dec_stage<C, s_, FULL>(lds, nin >> (s_ + 1), yg, ystride, lid);
+        lds_wave_sync();
+    });
+    // roll the histories: word j <- word n_s + j (src/hbf.rs:182-183)
+    float ke[C::stages], ko[C::stages];
+    static_for<0, C::stages>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1;
+        const int ns = nin >> (s_ + 1);
+        ke[s_] = lid < He ? lds[C::offA(s_) + pad4(He) + ns + lid] : 0.f;
+        ko[s_] = lid < Ho ? lds[C::offB(s_) + pad4(Ho) + ns + lid] : 0.f;
+    });
+    lds_wave_sync();
+    static_for<0, C::stages>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1;
+        if (lid < He) lds[C::offA(s_) + pad4(He) + lid] = ke[s_];
+        if (lid < Ho) lds[C::offB(s_) + pad4(Ho) + lid] = ko[s_];
+    });
+    lds_wave_sync();
+}
+
+// LM: x[(lane*frames + f)*R + k], y[lane*frames + f];  FM: x[(f*lanes + lane)*R + k], y[f*lanes + lane]
+template <class C, bool LM>
+__global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x, float *y, const size_t lanes,
+                                                   const size_t frames)
+{
+    __shared__ __attribute__((aligned(16))) float lds[C::lds_words];
+    constexpr int S = C::stages, R = C::rate;
+    static_assert(LM || R >= 4, "FRAME_MAJOR wave kernel needs 16-byte frame pieces");
+    const int lid = threadIdx.x;
+    const size_t lane = blockIdx.x;
+
+    // history <- state words (per stage: even[M-1] then odd[2M-1], oldest first)
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1, so = C::state_off(s_);
+        if (lid < He) lds[C::offA(s_) + pad4(He) + lid] = __uint_as_float(st[size_t(so + lid) * lanes + lane]);
+        if (lid < Ho) lds[C::offB(s_) + pad4(Ho) + lid] = __uint_as_float(st[size_t(so + He + lid) * lanes + lane]);
+    });
+
+    constexpr int CHF = kCH / R;     // output frames per chunk
+    constexpr int kPre = kCH / 4 / kW;  // 16-byte pieces per thread and chunk
+    constexpr int M0 = C::M(0);
+    float *E0n = lds + C::offA(0) + up4(M0 - 1), *O0n = lds + C::offB(0) + up4(2 * M0 - 1);
+    v4f pre[kPre];
+    auto piece = [&](size_t f0, int q) -> const v4f * {
+        if constexpr (LM) {
+            return reinterpret_cast<const v4f *>(x + (lane * frames + f0) * size_t(R)) + q;
+        } else {
+            constexpr int PPF = R / 4;  // pieces per frame
+            return reinterpret_cast<const v4f *>(x + ((f0 + size_t(q / PPF)) * lanes + lane) * size_t(R)) + (q % PPF);
+        }
+    };
+    auto fetch = [&](size_t f0) {
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int q = lid + i * kW;
+            if (q < nf * R / 4) pre[i] = *piece(f0, q);
+        }
+    };
+    fetch(0);
+    for (size_t f0 = 0; f0 < frames; f0 += CHF) {
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+        const int nin = nf * R;
+        // stage-0 input: pairs [even, odd] split into the two streams
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int q = lid + i * kW;
+            if (q < nin / 4) {
+                *reinterpret_cast<v2f *>(E0n + 2 * q) = v2f{pre[i].x, pre[i].z};
+                *reinterpret_cast<v2f *>(O0n + 2 * q) = v2f{pre[i].y, pre[i].w};
+            }
+        }
+        if (f0 + CHF < frames) fetch(f0 + CHF);  // next chunk in flight during the arithmetic
+        lds_wave_sync();
+        float *yg = LM ? y + lane * frames + f0 : y + f0 * lanes + lane;
+        const size_t ystride = LM ? 1 : lanes;
+        if (nf == CHF)
+            dec_chunk<C, true>(lds, nin, yg, ystride, lid);
+        else
+            dec_chunk<C, false>(lds, nin, yg, ystride, lid);
+    }
+
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1, so = C::state_off(s_);
+        if (lid < He) st[size_t(so + lid) * lanes + lane] = __float_as_uint(lds[C::offA(s_) + pad4(He) + lid]);
+        if (lid < Ho) st[size_t(so + He + lid) * lanes + lane] = __float_as_uint(lds[C::offB(s_) + pad4(Ho) + lid]);
+    });
+}
+
+// ------------------------------------------------------------ interpolator
+// stage s of `HbfInt` (src/hbf.rs:207-227): pair i = [get(x)[i], x[M + i]]
+template <class C, int s, bool FULL, bool LM>
+__device__ __forceinline__ void int_stage(float *lds, int n_rt, float *y, size_t lanes, size_t frames, size_t lane,
+                                          size_t f0, int lid)
+{
+    constexpr int M = C::M(s), N = C::n(s), P = blocking(N), R = C::rate;
+    constexpr int dx = pad4(2 * M - 1), ox = dx % P, NV = (ox + 2 * M + P - 1 + P - 1) / P;
+    constexpr int ITER = (N / P + kW - 1) / kW;
+    const float *X = lds + C::offA(s) + (dx - ox);
+    const int n = FULL ? N : n_rt;
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+        const int g = lid + it * kW, i0 = g * P;
+        if (i0 >= n) continue;
+        float w[NV * P], out[2 * P];
+        lds_window<P, NV>(X + i0, w);
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            out[2 * p] = window_sum<C, s>(w, ox + p);  // interpolated
+            out[2 * p + 1] = w[ox + M + p];            // centre tap: identity
+        }
+        if constexpr (s + 1 == C::stages) {
+            // 2P consecutive outputs of this lane starting at chunk-local sample 2*i0
+            const int o0 = 2 * i0;
+            if constexpr (P >= 2) {
+#pragma unroll
+                for (int h = 0; h < 2 * P; h += 4) {
+                    const int o = o0 + h;  // 4 consecutive samples inside one frame (R >= 4)
+                    float *dst = LM ? y + (lane * frames + f0) * size_t(R) + o
+                                    : y + ((f0 + size_t(o / R)) * lanes + lane) * size_t(R) + (o % R);
+                    if (FULL || o + 3 < 2 * n)
+                        *reinterpret_cast<v4f *>(dst) = v4f{out[h], out[h + 1], out[h + 2], out[h + 3]};
+                    else
+                        for (int j = 0; j < 4; j++)
+                            if (o + j < 2 * n) dst[j] = out[h + j];
+                }
+            } else {
+                float *dst = LM ? y + (lane * frames + f0) * size_t(R) + o0
+                                : y + ((f0 + size_t(o0 / R)) * lanes + lane) * size_t(R) + (o0 % R);
+                *reinterpret_cast<v2f *>(dst) = v2f{out[0], out[1]};
+            }
+        } else {
+            // `ChunkOut<_, 2>`: the pairs flatten into the next stage's input stream
+            float *Xn = lds + C::offA(s + 1) + up4(2 * C::M(s + 1) - 1) + 2 * i0;
+            if constexpr (P == 4) {
+                *reinterpret_cast<v4f *>(Xn) = v4f{out[0], out[1], out[2], out[3]};
+                *reinterpret_cast<v4f *>(Xn + 4) = v4f{out[4], out[5], out[6], out[7]};
+            } else if constexpr (P == 2) {
+                *reinterpret_cast<v4f *>(Xn) = v4f{out[0], out[1], out[2], out[3]};
+            } else {
+                *reinterpret_cast<v2f *>(Xn) = v2f{out[0], out[1]};
+            }
+        }
+    }
+}
+
+template <class C, bool FULL, bool LM>
+__device__ __forceinline__ void int_chunk(float *lds, int nf, float *y, size_t lanes, size_t frames, size_t lane,
+                                          size_t f0, int lid)
+{
+    static_for<0, C::stages>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        int_stage<C, s_, FULL, LM>(lds, nf << s_, y, lanes, frames, lane, f0, lid);
+        lds_wave_sync();
+    });
+    float kx[C::stages];
+    static_for<0, C::stages>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int H = 2 * C::M(s_) - 1;
+        kx[s_] = lid < H ? lds[C::offA(s_) + pad4(H) + (nf << s_) + lid] : 0.f;
+    });
+    lds_wave_sync();
+    static_for<0, C::stages>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int H = 2 * C::M(s_) - 1;
+        if (lid < H) lds[C::offA(s_) + pad4(H) + lid] = kx[s_];
+    });
+    lds_wave_sync();
+}
+
+// LM: x[lane*frames + f], y[(lane*frames + f)*R + k];  FM: x[f*lanes + lane], y[(f*lanes + lane)*R + k]
+template <class C, bool LM>
+__global__ __launch_bounds__(kW) void hbf_int_wave(uint32_t *st, const float *x, float *y, const size_t lanes,
+                                                   const size_t frames)
+{
+    __shared__ __attribute__((aligned(16))) float lds[C::lds_words];
+    constexpr int S = C::stages, R = C::rate;
+    static_assert(R >= 4 || LM, "FRAME_MAJOR wave kernel needs 16-byte frame pieces");
+    const int lid = threadIdx.x;
+    const size_t lane = blockIdx.x;
+
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int H = 2 * C::M(s_) - 1;
+        if (lid < H) lds[C::offA(s_) + pad4(H) + lid] = __uint_as_float(st[size_t(C::state_off(s_) + lid) * lanes + lane]);
+    });
+
+    constexpr int CHF = kCH / R;  // input frames per chunk (<= 512)
+    constexpr int kPre = (CHF + kW - 1) / kW;
+    float *X0n = lds + C::offA(0) + up4(2 * C::M(0) - 1);
+    float pre[kPre];
+    auto fetch = [&](size_t f0) {
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int j = lid + i * kW;
+            if (j < nf) pre[i] = LM ? x[lane * frames + f0 + size_t(j)] : x[(f0 + size_t(j)) * lanes + lane];
+        }
+    };
+    fetch(0);
+    for (size_t f0 = 0; f0 < frames; f0 += CHF) {
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int j = lid + i * kW;
+            if (j < nf) X0n[j] = pre[i];
+        }
+        if (f0 + CHF < frames) fetch(f0 + CHF);
+        lds_wave_sync();
+        if (nf == CHF)
+            int_chunk<C, true, LM>(lds, nf, y, lanes, frames, lane, f0, lid);
+        else
+            int_chunk<C, false, LM>(lds, nf, y, lanes, frames, lane, f0, lid);
+    }
+
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int H = 2 * C::M(s_) - 1;
+        if (lid < H) st[size_t(C::state_off(s_) + lid) * lanes + lane] = __float_as_uint(lds[C::offA(s_) + pad4(H) + lid]);
+    });
+}
+
+// -------------------------------------------------------------------- host
+template <int TS, int S, bool DEC>
+int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm, hipStream_t stream)
+{
+    using C = Casc<TS, S, DEC>;
+    const dim3 grid{unsigned(lanes)}, block{unsigned(kW)};
+    if (lm) {
+        if constexpr (DEC)
+            hipLaunchKernelGGL((hbf_dec_wave<C, true>), grid, block, 0, stream, st, x, y, lanes, frames);
+        else
+            hipLaunchKernelGGL((hbf_int_wave<C, true>), grid, block, 0, stream, st, x, y, lanes, frames);
+    } else {
+        if constexpr (S >= 2) {
+            if constexpr (DEC)
+                hipLaunchKernelGGL((hbf_dec_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
+            else
+                hipLaunchKernelGGL((hbf_int_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
+        } else {
+            return 1;  // not handled here
+        }
+    }
+    return 0;
+}
+
+template <int TS, bool DEC>
+int launch_wave_s(int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm,
+                  hipStream_t stream)
+{
+    switch (stages) {
+        case 1: return launch_wave<TS, 1, DEC>(st, x, y, lanes, frames, lm, stream);
+        case 2: return launch_wave<TS, 2, DEC>(st, x, y, lanes, frames, lm, stream);
+        case 3: return launch_wave<TS, 3, DEC>(st, x, y, lanes, frames, lm, stream);
+        case 4: return launch_wave<TS, 4, DEC>(st, x, y, lanes, frames, lm, stream);
+        case 5: return launch_wave<TS, 5, DEC>(st, x, y, lanes, frames, lm, stream);
+        default: return 1;
+    }
+}
+
+}  // namespace hbfw
+
+// Returns 0 when a specialised wave kernel was launched, 1 when the request is
+// not covered (caller falls back to the generic kernels of hbf.hip).
+int hbf_wave_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
+                 bool lane_major, hipStream_t stream);
+int hbf_wave_int(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
+                 bool lane_major, hipStream_t stream);
+
+}  // namespace idsp

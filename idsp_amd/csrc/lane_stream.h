@@ -107,8 +107,9 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
 }
 
 // ----------------------------------------------------------------- LANE_MAJOR
-// One wave per workgroup; tiles are wave-private, so the barriers below only
-// order this wave's own LDS traffic.
+// One wave per workgroup; tiles are wave-private, so the syncs below only
+// order this wave's own LDS traffic (lds_wave_sync: no vmcnt drain, the next
+// tile's global loads stay in flight).
 template <class P>
 __global__ __launch_bounds__(kWave) void stream_lane_major(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 #pragma unroll
             for (int i = 0; i < TS; i++) tin[i * RPI + lrow][lcol] = stage[i];
         }
-        __syncthreads();
+        lds_wave_sync();
         if (t0 + TS < frames) fetch(t0 + TS);  // next tile in flight during the arithmetic
 
         if (active) {
@@ -197,13 +198,13 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
                 }
             }
         }
-        __syncthreads();
+        lds_wave_sync();
         // row-contiguous stores: one instruction = 64 consecutive words of one lane
         const size_t nw = ncols * OW;
         for (size_t r = 0; r < nrows; r++) {
             if (size_t(lid) < nw) yw[((lane0 + r) * frames + t0) * OW + lid] = tout[r][lid];
         }
-        __syncthreads();
+        lds_wave_sync();
     }
     if (active) p.store(prm, st, lanes, lane);
 }
