@@ -1,0 +1,188 @@
+"""BASELINE.json configurations at FULL size on the GPU (C2, C3, C4, C5 shapes):
+parity against the CPU oracle on a lane subset that the oracle finishes in
+seconds (all lanes for C2), plus size-independent properties over the whole
+tensor: chunked calls == one call (streaming continuity), LANE_MAJOR ==
+transposed FRAME_MAJOR, and for the decimator a DC-gain check."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from idsp_amd import _abi
+from tests import _harness as H
+
+pytestmark = pytest.mark.gpu
+FM, LM = H.FM, H.LM
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def eng(gpu):
+    return gpu
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def lowpass_i32(frac=30, f0=0.01):
+    o = H.oracle()
+    q = _abi.BiquadI32()
+    assert o.fn["biquad_i32_from_sos"]((C.c_double * 6)(*o.lowpass_sos(f0)), frac, C.byref(q)) == 0
+    return (_abi.BiquadI32 * 1)(q)
+
+
+def test_c2_i32_df1_65536_lanes_full_parity(eng):
+    lanes, frames = 65536, 4096
+    o = H.oracle()
+    cfg = lowpass_i32()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(2)
+    x = torch.randint(-(1 << 24), 1 << 24, (frames, lanes), dtype=torch.int32, device=DEV, generator=g)
+    y = torch.empty_like(x)
+    st = torch.zeros((4, lanes), dtype=torch.int32, device=DEV)
+    assert eng.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, FM) == 0
+    torch.cuda.synchronize()
+    # oracle over ALL lanes (threaded over lane blocks), bit-exact incl. final state
+    xh = x.cpu().numpy()
+    yh = np.empty_like(xh)
+    sh = np.zeros((4, lanes), np.uint32)
+    rc = o.lib.idsp_ref_biquad_i32_df1_mt(C.cast(cfg, C.c_void_p), 1, sh.ctypes.data, xh.ctypes.data, yh.ctypes.data,
+                                          lanes, frames, FM, 64)
+    assert rc == 0
+    assert np.array_equal(y.cpu().numpy(), yh)
+    assert np.array_equal(st.cpu().numpy().view(np.uint32), sh)
+    # chunked == whole (three ragged pieces), on the GPU at full width
+    y2 = torch.empty_like(x)
+    st2 = torch.zeros_like(st)
+    for a, b in ((0, 1000), (1000, 1001), (1001, 4096)):
+        assert eng.stream("biquad_i32_df1", cfg, 1, st2, x[a:b], y2[a:b], lanes, b - a, FM) == 0
+    assert torch.equal(y, y2) and torch.equal(st, st2)
+    # LANE_MAJOR on the transposed tensor gives the transposed result; in place
+    xt = x.t().contiguous()
+    st3 = torch.zeros_like(st)
+    assert eng.stream("biquad_i32_df1", cfg, 1, st3, xt, xt, lanes, frames, LM) == 0
+    assert torch.equal(xt.t(), y) and torch.equal(st, st3)
+
+
+def test_c3_hbf_dec16_16384_lanes(eng):
+    lanes, frames, R = 16384, 4096, 16
+    o = H.oracle()
+    cfg = _abi.HbfCascadeF32()
+    assert o.fn["hbf_dec_cascade"](0, 4, C.byref(cfg)) == 0
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    x = torch.randn((lanes, frames * R), dtype=torch.float32, device=DEV, generator=g)  # LANE_MAJOR streams
+    y = torch.empty((lanes, frames), dtype=torch.float32, device=DEV)
+    st = torch.zeros((118, lanes), dtype=torch.int32, device=DEV)
+    assert eng.cfgcall("hbf_dec_f32", cfg, st, x, y, lanes, frames, LM) == 0
+    torch.cuda.synchronize()
+    idx = np.unique(np.concatenate([np.arange(0, lanes, 127), [0, 1, lanes - 1]]))
+    xs = np.ascontiguousarray(x.cpu().numpy()[idx])
+    ys = np.empty((idx.size, frames), np.float32)
+    ss = np.zeros((118, idx.size), np.uint32)
+    assert o.cfgcall("hbf_dec_f32", cfg, ss, xs, ys, idx.size, frames, LM) == 0
+    assert H.ulp_diff_f32(y.cpu().numpy()[idx], ys).max() == 0
+    assert np.array_equal(st.cpu().numpy().view(np.uint32)[:, idx], ss)
+    # chunked == whole over all lanes (ragged split that is not a multiple of the kernel chunk)
+    y2 = torch.empty_like(y)
+    st2 = torch.zeros_like(st)
+    cut = 1500
+    xa = x.view(lanes, frames, R)
+    # LANE_MAJOR chunks of each lane are not contiguous inside x: copy the two time segments out
+    for a, b in ((0, cut), (cut, frames)):
+        xc = xa[:, a:b].contiguous()
+        yc = torch.empty((lanes, b - a), dtype=torch.float32, device=DEV)
+        assert eng.cfgcall("hbf_dec_f32", cfg, st2, xc, yc, lanes, b - a, LM) == 0
+        y2[:, a:b] = yc
+    assert torch.equal(y.view(torch.int32), y2.view(torch.int32)) and torch.equal(st, st2)
+    # FRAME_MAJOR ([f][lane][R]) on the permuted tensor gives the same samples
+    xf = xa.permute(1, 0, 2).contiguous()
+    yf = torch.empty((frames, lanes), dtype=torch.float32, device=DEV)
+    st3 = torch.zeros_like(st)
+    assert eng.cfgcall("hbf_dec_f32", cfg, st3, xf, yf, lanes, frames, FM) == 0
+    assert torch.equal(yf.t().contiguous().view(torch.int32), y.view(torch.int32))
+    # property: DC gain 2 per stage (src/hbf.rs:548-555 KAT scaled up): constant input -> 16x
+    x.fill_(1.0)
+    st.zero_()
+    assert eng.cfgcall("hbf_dec_f32", cfg, st, x, y, lanes, frames, LM) == 0
+    assert torch.allclose(y[:, 100:], torch.full_like(y[:, 100:], 16.0), atol=1e-4)
+
+
+def test_c4_lockin_32768_lanes(eng):
+    lanes, frames = 32768, 4096
+    o = H.oracle()
+    k = math.pi * (1 << 31) * 1e-3
+    lp = [int(k * k / (1 << 32)), -int(k * math.sqrt(2.0))]
+    cfg = H.lockin_cfg([lp, lp])
+    words = 18
+    g = torch.Generator(device=DEV)
+    g.manual_seed(4)
+    x = torch.randint(-(1 << 28), 1 << 28, (frames, lanes), dtype=torch.int32, device=DEV, generator=g)
+    st0 = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)
+    st0[1] = torch.randint(-(1 << 31), (1 << 31) - 1, (lanes,), dtype=torch.int64, device=DEV, generator=g).to(torch.int32)
+    st = st0.clone()
+    y = torch.empty((frames, lanes, 2), dtype=torch.int32, device=DEV)
+    assert eng.cfgcall("lockin_i32_process", cfg, st, x, y, lanes, frames, FM) == 0
+    torch.cuda.synchronize()
+    idx = np.unique(np.concatenate([np.arange(0, lanes, 61), [lanes - 1]]))
+    xs = np.ascontiguousarray(x.cpu().numpy()[:, idx])
+    ss = np.ascontiguousarray(st0.cpu().numpy().view(np.uint32)[:, idx])
+    ys = np.empty((frames, idx.size, 2), np.int32)
+    assert o.cfgcall("lockin_i32_process", cfg, ss, xs, ys, idx.size, frames, FM) == 0
+    assert np.array_equal(y.cpu().numpy()[:, idx], ys)
+    assert np.array_equal(st.cpu().numpy().view(np.uint32)[:, idx], ss)
+    # chunked == whole, all lanes
+    st2 = st0.clone()
+    y2 = torch.empty_like(y)
+    for a, b in ((0, 7), (7, 2048), (2048, 4096)):
+        assert eng.cfgcall("lockin_i32_process", cfg, st2, x[a:b], y2[a:b], lanes, b - a, FM) == 0
+    assert torch.equal(y, y2) and torch.equal(st, st2)
+    # LANE_MAJOR equals transposed FRAME_MAJOR
+    st3 = st0.clone()
+    yl = torch.empty((lanes, frames, 2), dtype=torch.int32, device=DEV)
+    assert eng.cfgcall("lockin_i32_process", cfg, st3, x.t().contiguous(), yl, lanes, frames, LM) == 0
+    assert torch.equal(yl.permute(1, 0, 2), y) and torch.equal(st, st3)
+
+
+def test_c5_f32_df2t_one_million_lanes(eng):
+    """The whole C5 tensor (2^20 lanes x 4096, 16 GiB in + 16 GiB out) on ONE GPU, and the
+    8-way lane split of it: shard results concatenate to the unsharded result."""
+    from idsp_amd.sharding import lane_shard
+
+    lanes, frames = 1 << 20, 4096
+    o = H.oracle()
+    q = _abi.BiquadF32()
+    assert o.fn["biquad_f32_from_sos_f64"]((C.c_double * 6)(*o.lowpass_sos(0.01)), C.byref(q)) == 0
+    cfg = (_abi.BiquadF32 * 1)(q)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    x = torch.randn((frames, lanes), dtype=torch.float32, device=DEV, generator=g)
+    y = torch.empty_like(x)
+    st = torch.zeros((2, lanes), dtype=torch.int32, device=DEV)
+    assert eng.stream("biquad_f32_df2t", cfg, 1, st, x, y, lanes, frames, FM) == 0
+    torch.cuda.synchronize()
+    idx = np.unique(np.concatenate([np.arange(0, lanes, 2039), [1, lanes - 1]]))
+    tidx = torch.from_numpy(idx).to(DEV)
+    xs = np.ascontiguousarray(x[:, tidx].cpu().numpy())
+    ys = np.empty_like(xs)
+    ss = np.zeros((2, idx.size), np.uint32)
+    assert o.stream("biquad_f32_df2t", cfg, 1, ss, xs, ys, idx.size, frames, FM) == 0
+    assert H.ulp_diff_f32(y[:, tidx].cpu().numpy(), ys).max() == 0  # bar: 0 ULP (allowed: 1)
+    assert np.array_equal(st[:, tidx].cpu().numpy().view(np.uint32), ss)
+    # 8-way lane split (what each rank of an 8-GPU run computes), LANE_MAJOR shards of 512 frames
+    fr = 512
+    xt = x[:fr].t().contiguous()  # [lanes, fr]
+    whole = torch.empty_like(xt)
+    stw = torch.zeros((2, lanes), dtype=torch.int32, device=DEV)
+    assert eng.stream("biquad_f32_df2t", cfg, 1, stw, xt, whole, lanes, fr, LM) == 0
+    for r in range(8):
+        lo, hi = lane_shard(lanes, r, 8)
+        ysh = torch.empty((hi - lo, fr), dtype=torch.float32, device=DEV)
+        sts = torch.zeros((2, hi - lo), dtype=torch.int32, device=DEV)
+        assert eng.stream("biquad_f32_df2t", cfg, 1, sts, xt[lo:hi], ysh, hi - lo, fr, LM) == 0
+        assert torch.equal(ysh.view(torch.int32), whole[lo:hi].view(torch.int32))
+        assert torch.equal(sts, stw[:, lo:hi])
+    assert torch.equal(whole.t().contiguous().view(torch.int32), y[:fr].view(torch.int32))
