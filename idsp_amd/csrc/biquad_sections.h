@@ -191,6 +191,7 @@ struct Chain {
     using Out = typename Sec::T;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
+    static constexpr int IN_DIV = 1;
     static constexpr int COST = N * Sec::COST;
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
@@ -226,6 +227,7 @@ struct CascadeDf1 {
     using Out = T;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
+    static constexpr int IN_DIV = 1;
     static constexpr int COST = N * (std::is_same<T, float>::value ? 24 : 50);
     using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32, SecI32>::type;
     using Params = ChainParams<SecT, N>;

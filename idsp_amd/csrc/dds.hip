@@ -21,6 +21,8 @@ __device__ const uint32_t d_cossin_table[1 << kCossinDepth] = {
 #undef T8
 };
 
+constexpr size_t kSplitMaxLanes = 40960;  // split only while it fills SIMDs that would otherwise have no wave (measured: no gain beyond)
+
 struct Cplx {
     int32_t re, im;
 };
@@ -60,28 +62,23 @@ __device__ __forceinline__ void fill_cossin(uint32_t *sh, int tid, int nthreads)
     for (int i = tid; i < (1 << kCossinDepth); i += nthreads) sh[i] = d_cossin_table[i];
 }
 
-// i32::saturating_sub
-__device__ __forceinline__ int32_t sat_sub(int32_t a, int32_t b)
-{
-    const int64_t d = int64_t(a) - int64_t(b);
-    return d > INT32_MAX ? INT32_MAX : (d < INT32_MIN ? INT32_MIN : int32_t(d));
-}
-
-// src/lowpass.rs:47-78; all i64 arithmetic wraps.
+// src/lowpass.rs:47-78; all i64 arithmetic wraps (the library is built with
+// -fwrapv, so plain signed arithmetic has Rust release semantics and the two
+// products map onto v_mad_i64_i32).
 template <int N>
-__device__ __forceinline__ int32_t lowpass_step(const int32_t (&k)[2], uint64_t (&s)[N], int32_t x)
+__device__ __forceinline__ int32_t lowpass_step(const int32_t (&k)[2], int64_t (&s)[N], int32_t x)
 {
-    uint64_t d = uint64_t(int64_t(sat_sub(x, int32_t(uint32_t(s[0] >> 32)))) * int64_t(k[0]));
+    int64_t d = int64_t(__builtin_elementwise_sub_sat(x, int32_t(s[0] >> 32))) * int64_t(k[0]);
     int32_t y;
     if constexpr (N == 1) {
         s[0] += d;
-        y = int32_t(uint32_t(s[0] >> 32));
+        y = int32_t(s[0] >> 32);
         s[0] += d;
     } else {
-        d += uint64_t(int64_t(int32_t(uint32_t(s[1] >> 32))) * int64_t(k[1]));
+        d += int64_t(int32_t(s[1] >> 32)) * int64_t(k[1]);
         s[1] += d;
         s[0] += s[1];
-        y = int32_t(uint32_t(s[0] >> 32));
+        y = int32_t(s[0] >> 32);
         s[0] += s[1];
         s[1] += d;
     }
@@ -94,7 +91,7 @@ struct LpParams {
 
 template <int N, int K>
 struct LpBank {
-    uint64_t s[K][N];
+    int64_t s[K][N];
     __device__ __forceinline__ void load(const uint32_t *st, size_t lanes, size_t lane, int word0)
     {
 #pragma unroll
@@ -102,7 +99,7 @@ struct LpBank {
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 const size_t w = size_t(word0 + (c * N + j) * 2);
-                s[c][j] = uint64_t(st[w * lanes + lane]) | (uint64_t(st[(w + 1) * lanes + lane]) << 32);
+                s[c][j] = int64_t(uint64_t(st[w * lanes + lane]) | (uint64_t(st[(w + 1) * lanes + lane]) << 32));
             }
     }
     __device__ __forceinline__ void store(uint32_t *st, size_t lanes, size_t lane, int word0) const
@@ -112,8 +109,8 @@ struct LpBank {
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 const size_t w = size_t(word0 + (c * N + j) * 2);
-                st[w * lanes + lane] = uint32_t(s[c][j]);
-                st[(w + 1) * lanes + lane] = uint32_t(s[c][j] >> 32);
+                st[w * lanes + lane] = uint32_t(uint64_t(s[c][j]));
+                st[(w + 1) * lanes + lane] = uint32_t(uint64_t(s[c][j]) >> 32);
             }
     }
     // `[Lowpass<N>; K]` array composition (dsp-process/src/compose.rs:84-93)
@@ -132,6 +129,7 @@ struct LowpassProc {
     using Out = int32_t;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
+    static constexpr int IN_DIV = 1;
     static constexpr int COST = 40 * N * K;
     using Params = LpParams;
     LpBank<N, K> b;
@@ -146,6 +144,7 @@ struct DdsProc {
     using Out = Cplx;
     static constexpr bool HAS_IN = false;
     static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int IN_DIV = 1;
     static constexpr int COST = 100;
     struct Params {
         int32_t unused;
@@ -175,6 +174,7 @@ struct LockinProc {
     using Out = Cplx;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int IN_DIV = 1;
     static constexpr int COST = 110 + 80 * N * K;
     using Params = LpParams;
     const uint32_t *lut;
@@ -195,14 +195,100 @@ struct LockinProc {
         bi.store(st, lanes, lane, 2);
         bq.store(st, lanes, lane, 2 + 2 * N * K);
     }
-    __device__ __forceinline__ Out step(const Params &p, In x)
+    static constexpr int BATCH = 4;
+    using Pre = Cplx;
+    __device__ __forceinline__ Pre pre(const Params &)
     {
         acc += inc;
-        const Cplx lo = cossin_dev(int32_t(acc), lut);
+        return cossin_dev(int32_t(acc), lut);
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo)
+    {
         const int32_t xi = __mulhi(lo.re, x);
         const int32_t xq = __mulhi(lo.im, x);
         return Cplx{bi.step(p, xi), bq.step(p, xq)};
     }
+};
+
+// I/Q arms on two adjacent threads ("virtual lanes" 2*lane + iq): used when the
+// lane count alone cannot give every SIMD a wave (C4: 32768 lanes = 512 waves).
+// Both threads step the same phase accumulator and evaluate cossin; each runs
+// one arm of the mixer + lowpass cascade and writes one word of Complex<i32>,
+// so a wave still stores 256 contiguous bytes per frame.
+template <int N, int K>
+struct LockinSplitProc {
+    using In = int32_t;
+    using Out = int32_t;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int IN_DIV = 2;
+    static constexpr int COST = 70 + 40 * N * K;
+    using Params = LpParams;
+    const uint32_t *lut;
+    uint32_t acc, inc;
+    bool q;
+    LpBank<N, K> b;
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
+    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t vlanes, size_t vlane)
+    {
+        const size_t lanes = vlanes / 2, lane = vlane / 2;
+        q = vlane & 1;
+        acc = st[lane];
+        inc = st[lanes + lane];
+        b.load(st, lanes, lane, 2 + (q ? 2 * N * K : 0));
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t vlanes, size_t vlane)
+    {
+        const size_t lanes = vlanes / 2, lane = vlane / 2;
+        if (!q) st[lane] = acc;
+        b.store(st, lanes, lane, 2 + (q ? 2 * N * K : 0));
+    }
+    static constexpr int BATCH = 4;
+    using Pre = int32_t;  // this arm's LO component
+    __device__ __forceinline__ Pre pre(const Params &)
+    {
+        acc += inc;
+        const Cplx lo = cossin_dev(int32_t(acc), lut);
+        return q ? lo.im : lo.re;
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo) { return b.step(p, __mulhi(lo, x)); }
+};
+
+struct DdsSplitProc {
+    using In = int32_t;  // unused
+    using Out = int32_t;
+    static constexpr bool HAS_IN = false;
+    static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int IN_DIV = 2;
+    static constexpr int COST = 100;
+    struct Params {
+        int32_t unused;
+    };
+    const uint32_t *lut;
+    uint32_t acc, inc;
+    bool q;
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
+    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t vlanes, size_t vlane)
+    {
+        q = vlane & 1;
+        acc = st[vlane / 2];
+        inc = st[vlanes / 2 + vlane / 2];
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t, size_t vlane)
+    {
+        if (!q) st[vlane / 2] = acc;
+    }
+    static constexpr int BATCH = 4;
+    using Pre = int32_t;
+    __device__ __forceinline__ Pre pre(const Params &)
+    {
+        acc += inc;
+        const Cplx c = cossin_dev(int32_t(acc), lut);
+        return q ? c.im : c.re;
+    }
+    __device__ __forceinline__ Out step(const Params &, In, const Pre &v) { return v; }
 };
 
 __global__ __launch_bounds__(256) void cossin_kernel(const int32_t *phase, Cplx *out, size_t n)
@@ -274,6 +360,11 @@ int idsp_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int lay
     if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return fail(IDSP_EINVAL, "bad layout %d", layout);
     if (lanes && (!state || (frames && !out))) return fail(IDSP_EINVAL, "state or out is NULL");
     if (lanes == 0) return IDSP_OK;
+    if (layout == IDSP_FRAME_MAJOR && lanes <= kSplitMaxLanes) {
+        DdsSplitProc::Params ps{0};
+        return launch_stream<DdsSplitProc>(ps, state, static_cast<const int32_t *>(nullptr), out, 2 * lanes, frames, layout,
+                                           as_stream(stream));
+    }
     DdsProc::Params p{0};
     return launch_stream<DdsProc>(p, state, static_cast<const int32_t *>(nullptr), reinterpret_cast<Cplx *>(out), lanes,
                                   frames, layout, as_stream(stream));
@@ -292,6 +383,9 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
     if (rc) return rc;
     if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
     if (lanes == 0) return IDSP_OK;
+    // fewer than one wave per SIMD even after doubling: put the I and Q arms on separate threads
+    if (layout == IDSP_FRAME_MAJOR && lanes <= kSplitMaxLanes)
+        return dispatch_nk<LockinSplitProc, int32_t>(cfg, state, x, y, 2 * lanes, frames, layout, as_stream(stream));
     return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, as_stream(stream));
 }
 

@@ -28,11 +28,42 @@
 //   static constexpr int LDS_WORDS;   read-only table words (0 = none), filled
 //   by static fill_shared(uint32_t*) with the whole block and handed to the
 //   processor through set_shared(const uint32_t*).
+//   static constexpr int BATCH; Pre pre(prm); Out step(prm, x, pre)   (optional,
+//   BATCH > 1): the part of a sample's work that does not depend on the
+//   recurrence state (the DDS phase -> cossin chain) is evaluated for BATCH
+//   consecutive frames back to back, which gives the scheduler independent
+//   dependency chains to interleave — at one wave per SIMD the per-frame
+//   dependent-chain latency, not throughput, is what bounds these kernels.
+//   static constexpr int IN_DIV;      FRAME_MAJOR only: IN_DIV adjacent threads
+//   ("virtual lanes") share one input lane — used to split the I and Q arms of
+//   the lock-in / DDS over two threads when there are too few lanes to give
+//   every SIMD a wave; `lanes` then counts virtual lanes.
 #pragma once
+
+#include <type_traits>
 
 #include "common.h"
 
 namespace idsp {
+
+template <class P, class = void>
+struct BatchOf {
+    static constexpr int value = 1;
+};
+template <class P>
+struct BatchOf<P, std::void_t<decltype(P::BATCH)>> {
+    static constexpr int value = P::BATCH;
+};
+
+// one sample through processors with or without a state-independent pre-stage
+template <class P>
+__device__ __forceinline__ typename P::Out step1(P &p, const typename P::Params &prm, typename P::In v)
+{
+    if constexpr (BatchOf<P>::value > 1)
+        return p.step(prm, v, p.pre(prm));
+    else
+        return p.step(prm, v);
+}
 
 constexpr int kWave = 64;
 constexpr int kFmBlock = 256;  // 4 waves: one per SIMD of a CU, 1 KiB row segment per block
@@ -57,7 +88,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
     if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
     p.load(prm, st, lanes, lane);
 
-    const In *xp = x + lane;
+    const size_t xl = lanes / P::IN_DIV;  // input row pitch (IN_DIV virtual lanes share an input lane)
+    const In *xp = x + lane / P::IN_DIV;
     Out *yp = y + lane;
 
     if constexpr (P::HAS_IN) {
@@ -69,16 +101,32 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
         In ring[U];
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (size_t(u) < frames) ring[u] = xp[size_t(u) * lanes];
+            if (size_t(u) < frames) ring[u] = xp[size_t(u) * xl];
         size_t f = 0;
         for (; f + 2 * U <= frames; f += U) {
-            const In *xn = xp + (f + U) * lanes;
+            const In *xn = xp + (f + U) * xl;
             Out *yn = yp + f * lanes;
+            constexpr int B = BatchOf<P>::value;
+            static_assert(U % B == 0, "window depth must be a multiple of the batch");
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const In v = ring[u];
-                ring[u] = xn[size_t(u) * lanes];
-                yn[size_t(u) * lanes] = p.step(prm, v);
+            for (int u0 = 0; u0 < U; u0 += B) {
+                if constexpr (B > 1) {
+                    typename P::Pre pre[B];
+#pragma unroll
+                    for (int b = 0; b < B; b++) pre[b] = p.pre(prm);
+#pragma unroll
+                    for (int b = 0; b < B; b++) {
+                        const int u = u0 + b;
+                        const In v = ring[u];
+                        ring[u] = xn[size_t(u) * xl];
+                        yn[size_t(u) * lanes] = p.step(prm, v, pre[b]);
+                    }
+                } else {
+                    const int u = u0;
+                    const In v = ring[u];
+                    ring[u] = xn[size_t(u) * xl];
+                    yn[size_t(u) * lanes] = p.step(prm, v);
+                }
             }
         }
         // drain: fewer than 2U frames left, predicates are wave-uniform
@@ -87,19 +135,31 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
             const size_t fr = f + u;
             if (fr < frames) {
                 const In v = ring[u];
-                if (fr + U < frames) ring[u] = xp[(fr + U) * lanes];
-                yp[fr * lanes] = p.step(prm, v);
+                if (fr + U < frames) ring[u] = xp[(fr + U) * xl];
+                yp[fr * lanes] = step1(p, prm, v);
             }
         }
         f += U;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t fr = f + u;
-            if (fr < frames) yp[fr * lanes] = p.step(prm, ring[u]);
+            if (fr < frames) yp[fr * lanes] = step1(p, prm, ring[u]);
         }
     } else {
-        for (size_t f = 0; f < frames; f++) {
-            *yp = p.step(prm, In{});
+        constexpr int B = BatchOf<P>::value;
+        size_t f = 0;
+        if constexpr (B > 1) {
+            for (; f + B <= frames; f += B) {
+                typename P::Pre pre[B];
+#pragma unroll
+                for (int b = 0; b < B; b++) pre[b] = p.pre(prm);
+#pragma unroll
+                for (int b = 0; b < B; b++) yp[size_t(b) * lanes] = p.step(prm, In{}, pre[b]);
+                yp += size_t(B) * lanes;
+            }
+        }
+        for (; f < frames; f++) {
+            *yp = step1(p, prm, In{});
             yp += lanes;
         }
     }
@@ -174,7 +234,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
                 for (int j = 0; j < TS; j++) {
                     In v{};
                     if constexpr (P::HAS_IN) v = __builtin_bit_cast(In, tin[lid][j]);
-                    const Out o = p.step(prm, v);
+                    const Out o = step1(p, prm, v);
                     if constexpr (OW == 1) {
                         tout[lid][j] = __builtin_bit_cast(uint32_t, o);
                     } else {
@@ -187,7 +247,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
                 for (size_t j = 0; j < ncols; j++) {
                     In v{};
                     if constexpr (P::HAS_IN) v = __builtin_bit_cast(In, tin[lid][j]);
-                    const Out o = p.step(prm, v);
+                    const Out o = step1(p, prm, v);
                     if constexpr (OW == 1) {
                         tout[lid][j] = __builtin_bit_cast(uint32_t, o);
                     } else {
