@@ -41,6 +41,11 @@ $(ORACLE_NAT): oracle/idsp_oracle.c oracle/idsp_oracle.h include/idsp_hip.h
 	@mkdir -p $(dir $@)
 	$(CC) $(ORCFLAGS) -march=native -shared -o $@ oracle/idsp_oracle.c -lm -lpthread
 
+# C++ host layer (include/idsp_hip.hpp) test program: plain g++, links the C ABI only
+build/test_host: tests/cpp/test_host.cpp include/idsp_hip.hpp include/idsp_hip.h $(LIB)
+	@mkdir -p build
+	g++ -std=c++17 -O1 -Wall -Iinclude tests/cpp/test_host.cpp -Lidsp_amd/lib -lidsp_hip -Wl,-rpath,'$$ORIGIN/../idsp_amd/lib' -o $@
+
 clean:
 	rm -f $(HIP_OBJS) $(LIB) $(ORACLE) $(ORACLE_NAT)
 

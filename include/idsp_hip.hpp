@@ -1,0 +1,420 @@
+// idsp_hip.hpp — header-only C++17 host layer above the C ABI (idsp_hip.h).
+//
+// The reference is compiled code (Rust) and no Rust toolchain exists in the
+// build image, so the host side that mirrors its operator interface is C++:
+// the same names, argument meaning and error behaviour as `dsp_process` /
+// `idsp`, resolved statically like the reference's traits.  Needs only the C
+// ABI (no HIP headers): buffers are owned through idsp_device_alloc.
+//
+//   reference                                                   here
+//   ----------------------------------------------------------  --------------------------------
+//   Biquad<Q32<F>> / Biquad<f32>        (src/iir/biquad.rs:96)  Biquad<Q32<F>> / Biquad<float>
+//   BiquadClamp<C, T>                   (src/iir/biquad.rs:121) BiquadClamp<C>
+//   DirectForm1<T> / DirectForm2Transposed<T> / DirectForm1Wide / DirectForm1Dither   (state tags)
+//   Split::new(cfg, S::default()).lanes::<N>()  (split.rs:272)  Split(cfg, S{}).lanes(n)
+//   Process::block / Inplace::inplace           (process.rs:34) .block(x, y) / .inplace(xy)   FrameMajor
+//   ViewProcess::process_view(View<LaneMajor>)  (view.rs:245)   .process_view(View, ViewMut)
+//   HBF_DEC_CASCADE + HbfDec2..32 / HBF_INT_CASCADE (hbf.rs)    HbfDecCascade / HbfIntCascade
+//   Lockin<[Lowpass<N>; K]> + Accu      (lockin.rs, accu.rs)    Lockin<N, K>
+//   cossin(phase)                       (cossin.rs:14)          cossin(phases, out)
+//
+// Misuse that is a `debug_assert!`/panic in the reference throws idsp_hip::Error.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "idsp_hip.h"
+
+namespace idsp_hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+inline void check(int rc)
+{
+    if (rc < 0) throw Error(rc, std::string("idsp status ") + std::to_string(rc) + ": " + idsp_last_error());
+}
+inline void require(bool ok, const char *what)
+{
+    if (!ok) throw Error(IDSP_EINVAL, what);
+}
+
+// ------------------------------------------------------------------ memory
+/// Device-resident slice `[T]` (the engine never allocates behind the caller's back).
+template <class T>
+class DeviceBuffer {
+public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t n, bool zero = true) : n_(n)
+    {
+        if (n) {
+            check(idsp_device_alloc(reinterpret_cast<void **>(&p_), n * sizeof(T)));
+            if (zero) check(idsp_device_memset(p_, 0, n * sizeof(T), nullptr));
+        }
+    }
+    explicit DeviceBuffer(const std::vector<T> &host) : DeviceBuffer(host.size(), false) { upload(host); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    DeviceBuffer(DeviceBuffer &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr, o.n_ = 0; }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept
+    {
+        std::swap(p_, o.p_);
+        std::swap(n_, o.n_);
+        return *this;
+    }
+    ~DeviceBuffer()
+    {
+        if (p_) idsp_device_free(p_);
+    }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    size_t len() const { return n_; }
+    void upload(const std::vector<T> &host)
+    {
+        require(host.size() == n_, "upload: length mismatch");
+        if (n_) {
+            check(idsp_device_h2d(p_, host.data(), n_ * sizeof(T), nullptr));
+            check(idsp_stream_sync(nullptr));
+        }
+    }
+    std::vector<T> to_host() const
+    {
+        std::vector<T> h(n_);
+        if (n_) {
+            check(idsp_device_d2h(h.data(), p_, n_ * sizeof(T), nullptr));
+            check(idsp_stream_sync(nullptr));
+        }
+        return h;
+    }
+
+private:
+    T *p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// ------------------------------------------------------------------- views
+struct FrameMajor {  // dsp-process/src/view.rs:10
+    static constexpr int value = IDSP_FRAME_MAJOR;
+};
+struct LaneMajor {  // dsp-process/src/view.rs:17
+    static constexpr int value = IDSP_LANE_MAJOR;
+};
+
+/// `View<'_, T, Layout, L>` with a runtime lane count (dsp-process/src/view.rs:24-28).
+template <class T, class Layout>
+struct View {
+    const T *flat;
+    size_t frames, lanes;
+    /// `from_flat`: `assert_eq!(flat.len(), frames * L)` (view.rs:182)
+    static View from_flat(const DeviceBuffer<T> &b, size_t lanes, size_t width = 1)
+    {
+        require(lanes && b.len() % (lanes * width) == 0, "flat.len() is not frames * L");
+        return View{b.data(), b.len() / (lanes * width), lanes};
+    }
+};
+template <class T, class Layout>
+struct ViewMut {
+    T *flat;
+    size_t frames, lanes;
+    static ViewMut from_flat(DeviceBuffer<T> &b, size_t lanes, size_t width = 1)
+    {
+        require(lanes && b.len() % (lanes * width) == 0, "flat.len() is not frames * L");
+        return ViewMut{b.data(), b.len() / (lanes * width), lanes};
+    }
+    operator View<T, Layout>() const { return View<T, Layout>{flat, frames, lanes}; }
+};
+
+// ---------------------------------------------------------- configurations
+/// Coefficient type tag `Q32<F>` = `Q<i32, i64, F>` (dsp-fixedpoint/src/lib.rs:474-492).
+template <int F>
+struct Q32 {
+    static_assert(F >= 0 && F < 32, "0 <= F < 32");
+    static constexpr int frac = F;
+};
+
+template <class C>
+struct Biquad;  // src/iir/biquad.rs:96-116: ba = [b0, b1, b2, a1, a2], a1/a2 as used
+
+template <int F>
+struct Biquad<Q32<F>> {
+    using Sample = int32_t;
+    std::array<int32_t, 5> ba{};  // raw Q bits
+    /// `Biquad::from([[b0,b1,b2],[a0,a1,a2]])` (biquad.rs:545-566) + f64 -> Q32<F> (num_traits_impl.rs:32-46)
+    static Biquad from_sos(const std::array<double, 6> &sos)
+    {
+        idsp_biquad_i32 q;
+        check(idsp_biquad_i32_from_sos(sos.data(), F, &q));
+        Biquad b;
+        std::memcpy(b.ba.data(), q.ba, sizeof(q.ba));
+        return b;
+    }
+    static Biquad proportional(int32_t k) { return Biquad{{k, 0, 0, 0, 0}}; }          // biquad.rs:196-200
+    static Biquad identity() { return proportional(int32_t(1) << F); }                   // biquad.rs:184
+    static Biquad hold() { return Biquad{{0, 0, 0, int32_t(1) << F, 0}}; }               // biquad.rs:212-214
+    int32_t forward_gain() const { return int32_t(uint32_t(ba[0]) + uint32_t(ba[1]) + uint32_t(ba[2])); }
+    idsp_biquad_i32 abi() const
+    {
+        idsp_biquad_i32 q;
+        std::memcpy(q.ba, ba.data(), sizeof(q.ba));
+        q.frac = F;
+        return q;
+    }
+};
+
+template <>
+struct Biquad<float> {
+    using Sample = float;
+    std::array<float, 5> ba{};
+    static Biquad from_sos(const std::array<float, 6> &sos)
+    {
+        idsp_biquad_f32 q;
+        check(idsp_biquad_f32_from_sos(sos.data(), &q));
+        Biquad b;
+        std::memcpy(b.ba.data(), q.ba, sizeof(q.ba));
+        return b;
+    }
+    static Biquad from_sos(const std::array<double, 6> &sos)
+    {
+        idsp_biquad_f32 q;
+        check(idsp_biquad_f32_from_sos_f64(sos.data(), &q));
+        Biquad b;
+        std::memcpy(b.ba.data(), q.ba, sizeof(q.ba));
+        return b;
+    }
+    static Biquad proportional(float k) { return Biquad{{k, 0, 0, 0, 0}}; }
+    static Biquad identity() { return proportional(1.0f); }
+    static Biquad hold() { return Biquad{{0, 0, 0, 1.0f, 0}}; }
+    float forward_gain() const { return ba[0] + ba[1] + ba[2]; }
+    idsp_biquad_f32 abi() const
+    {
+        idsp_biquad_f32 q;
+        std::memcpy(q.ba, ba.data(), sizeof(q.ba));
+        return q;
+    }
+};
+
+/// `BiquadClamp<C, T>` (biquad.rs:121-171); defaults u = 0, min = T::MIN, max = T::MAX
+/// (+-inf for floats, src/num.rs:33-52).
+template <class C>
+struct BiquadClamp {
+    using Sample = typename Biquad<C>::Sample;
+    Biquad<C> coeff{};
+    Sample u = Sample(0);
+    Sample min = std::numeric_limits<Sample>::has_infinity ? -std::numeric_limits<Sample>::infinity()
+                                                           : std::numeric_limits<Sample>::lowest();
+    Sample max = std::numeric_limits<Sample>::has_infinity ? std::numeric_limits<Sample>::infinity()
+                                                           : std::numeric_limits<Sample>::max();
+    BiquadClamp() = default;
+    BiquadClamp(const Biquad<C> &c) : coeff(c) {}  // `From<F: Into<Biquad<C>>>` (biquad.rs:578-588)
+};
+
+// state kinds (tags): words per lane and section
+struct DirectForm1 { static constexpr int words = 4; };            // biquad.rs:319
+struct DirectForm2Transposed { static constexpr int words = 2; };  // biquad.rs:407
+struct DirectForm1Wide { static constexpr int words = 6; };        // biquad.rs:445-454
+struct DirectForm1Dither { static constexpr int words = 5; };      // biquad.rs:484-491
+
+namespace detail {
+using StreamI32 = int (*)(const idsp_biquad_i32 *, size_t, void *, const int32_t *, int32_t *, size_t, size_t, int, void *);
+using StreamClampI32 = int (*)(const idsp_biquad_clamp_i32 *, size_t, void *, const int32_t *, int32_t *, size_t, size_t, int, void *);
+using StreamF32 = int (*)(const idsp_biquad_f32 *, size_t, void *, const float *, float *, size_t, size_t, int, void *);
+using StreamClampF32 = int (*)(const idsp_biquad_clamp_f32 *, size_t, void *, const float *, float *, size_t, size_t, int, void *);
+
+// (configuration, state) -> C entry point; a missing specialisation is the reference's
+// "trait not implemented" compile error.
+template <class Cfg, class S>
+struct Entry;
+template <int F> struct Entry<Biquad<Q32<F>>, DirectForm1> { static constexpr StreamI32 fn = idsp_biquad_i32_df1; };
+template <int F> struct Entry<Biquad<Q32<F>>, DirectForm1Dither> { static constexpr StreamI32 fn = idsp_biquad_i32_dither; };
+template <int F> struct Entry<Biquad<Q32<F>>, DirectForm1Wide> { static constexpr StreamI32 fn = idsp_biquad_i32_wide; };
+template <int F> struct Entry<BiquadClamp<Q32<F>>, DirectForm1> { static constexpr StreamClampI32 fn = idsp_biquad_i32_df1_clamp; };
+template <int F> struct Entry<BiquadClamp<Q32<F>>, DirectForm1Dither> { static constexpr StreamClampI32 fn = idsp_biquad_i32_dither_clamp; };
+template <int F> struct Entry<BiquadClamp<Q32<F>>, DirectForm1Wide> { static constexpr StreamClampI32 fn = idsp_biquad_i32_wide_clamp; };
+template <> struct Entry<Biquad<float>, DirectForm1> { static constexpr StreamF32 fn = idsp_biquad_f32_df1; };
+template <> struct Entry<Biquad<float>, DirectForm2Transposed> { static constexpr StreamF32 fn = idsp_biquad_f32_df2t; };
+template <> struct Entry<BiquadClamp<float>, DirectForm1> { static constexpr StreamClampF32 fn = idsp_biquad_f32_df1_clamp; };
+template <> struct Entry<BiquadClamp<float>, DirectForm2Transposed> { static constexpr StreamClampF32 fn = idsp_biquad_f32_df2t_clamp; };
+
+template <int F> idsp_biquad_i32 to_abi(const Biquad<Q32<F>> &b) { return b.abi(); }
+inline idsp_biquad_f32 to_abi(const Biquad<float> &b) { return b.abi(); }
+template <int F>
+idsp_biquad_clamp_i32 to_abi(const BiquadClamp<Q32<F>> &c)
+{
+    idsp_biquad_clamp_i32 q;
+    std::memcpy(q.ba, c.coeff.ba.data(), sizeof(q.ba));
+    q.frac = F, q.u = c.u, q.min = c.min, q.max = c.max;
+    return q;
+}
+inline idsp_biquad_clamp_f32 to_abi(const BiquadClamp<float> &c)
+{
+    idsp_biquad_clamp_f32 q;
+    std::memcpy(q.ba, c.coeff.ba.data(), sizeof(q.ba));
+    q.u = c.u, q.min = c.min, q.max = c.max;
+    return q;
+}
+}  // namespace detail
+
+/// `Split<Lanes<C>, [S; lanes]>` resident on the GPU: one shared configuration (or a serial
+/// slice of sections, `[C] x [S]`, dsp-process/src/compose.rs:43-77), `lanes` independent states.
+template <class Cfg, class S>
+class Lanes {
+public:
+    using Sample = typename Cfg::Sample;
+    using Abi = decltype(detail::to_abi(std::declval<Cfg>()));
+
+    Lanes(const std::vector<Cfg> &sections, size_t lanes, void *stream = nullptr)
+        : lanes_(lanes), stream_(stream), state_(size_t(S::words) * (sections.empty() ? 1 : sections.size()) * lanes)
+    {
+        for (const auto &c : sections) abi_.push_back(detail::to_abi(c));
+    }
+    size_t lanes() const { return lanes_; }
+    /// per-lane state words, word-plane-major; zero == `Default::default()`
+    DeviceBuffer<uint32_t> &state() { return state_; }
+
+    /// `Process::block(&mut self, x: &[[X; N]], y: &mut [[Y; N]])` — FrameMajor (process.rs:44-49)
+    void block(const DeviceBuffer<Sample> &x, DeviceBuffer<Sample> &y)
+    {
+        require(x.len() == y.len(), "x.len() != y.len()");  // process.rs:45 debug_assert_eq!
+        require(lanes_ && x.len() % lanes_ == 0, "slice is not a whole number of frames");
+        run(x.data(), y.data(), x.len() / lanes_, IDSP_FRAME_MAJOR);
+    }
+    /// `Inplace::inplace(&mut self, xy: &mut [[X; N]])` (process.rs:61-65)
+    void inplace(DeviceBuffer<Sample> &xy)
+    {
+        require(lanes_ && xy.len() % lanes_ == 0, "slice is not a whole number of frames");
+        run(xy.data(), xy.data(), xy.len() / lanes_, IDSP_FRAME_MAJOR);
+    }
+    /// `ViewProcess::process_view` (view.rs:245-248; `Lanes` lane-slice path compose.rs:478-494)
+    template <class Layout>
+    void process_view(View<Sample, Layout> x, ViewMut<Sample, Layout> y)
+    {
+        require(x.frames == y.frames, "x.frames() != y.frames()");  // compose.rs:488
+        require(x.lanes == lanes_ && y.lanes == lanes_, "view lane count != Lanes lane count");
+        run(x.flat, y.flat, x.frames, Layout::value);
+    }
+    template <class Layout>
+    void inplace_view(ViewMut<Sample, Layout> xy)
+    {
+        require(xy.lanes == lanes_, "view lane count != Lanes lane count");
+        run(xy.flat, xy.flat, xy.frames, Layout::value);
+    }
+
+private:
+    void run(const Sample *x, Sample *y, size_t frames, int layout)
+    {
+        check(detail::Entry<Cfg, S>::fn(abi_.data(), abi_.size(), state_.data(), x, y, lanes_, frames, layout, stream_));
+    }
+    size_t lanes_;
+    void *stream_;
+    std::vector<Abi> abi_;
+    DeviceBuffer<uint32_t> state_;
+};
+
+/// `Split<C, S>` (dsp-process/src/split.rs:29-34).
+template <class Cfg, class S>
+struct SplitT {
+    std::vector<Cfg> sections;
+    /// `.lanes::<N>()` (split.rs:272-277)
+    Lanes<Cfg, S> lanes(size_t n, void *stream = nullptr) const { return Lanes<Cfg, S>(sections, n, stream); }
+};
+template <class Cfg, class S>
+SplitT<Cfg, S> Split(const Cfg &cfg, S)
+{
+    return SplitT<Cfg, S>{{cfg}};
+}
+template <class Cfg, class S>
+SplitT<Cfg, S> Split(const std::vector<Cfg> &sections, S)
+{
+    return SplitT<Cfg, S>{sections};
+}
+
+// ----------------------------------------------------------------- half-band
+enum class HbfTaps { Taps140 = 0 /* HBF_TAPS, hbf.rs:308-349 */, Taps98 = 1 /* HBF_TAPS_98, hbf.rs:258-292 */ };
+
+template <bool DEC>
+class HbfCascade {
+public:
+    /// `HBF_DEC_CASCADE` / `HBF_INT_CASCADE` restricted to a 2^stages rate change with
+    /// `HbfDec2..32` / `HbfInt2..32` state for `lanes` streams (hbf.rs:363-421,454-512).
+    HbfCascade(int stages, size_t lanes, HbfTaps taps = HbfTaps::Taps140, void *stream = nullptr)
+        : lanes_(lanes), stream_(stream)
+    {
+        check(DEC ? idsp_hbf_dec_cascade(int(taps), stages, &cfg_) : idsp_hbf_int_cascade(int(taps), stages, &cfg_));
+        state_ = DeviceBuffer<uint32_t>((DEC ? idsp_hbf_dec_state_words(&cfg_) : idsp_hbf_int_state_words(&cfg_)) * lanes);
+    }
+    size_t rate() const { return size_t(1) << cfg_.stages; }
+    /// `hbf_dec_response_length` / `hbf_int_response_length` (hbf.rs:424-448,515-539)
+    int response_length() const { return DEC ? idsp_hbf_dec_response_length(&cfg_) : idsp_hbf_int_response_length(&cfg_); }
+    DeviceBuffer<uint32_t> &state() { return state_; }
+    /// decimator: x = `[[f32; R]]` chunks, y = `[f32]`; interpolator: the reverse
+    template <class Layout>
+    void process_view(View<float, Layout> x, ViewMut<float, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        check(DEC ? idsp_hbf_dec_f32(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_)
+                  : idsp_hbf_int_f32(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
+
+private:
+    idsp_hbf_cascade_f32 cfg_{};
+    size_t lanes_;
+    void *stream_;
+    DeviceBuffer<uint32_t> state_;
+};
+using HbfDecCascade = HbfCascade<true>;
+using HbfIntCascade = HbfCascade<false>;
+
+// ------------------------------------------------------------ DDS / lock-in
+/// `cossin(p: i32[N]) -> i32[N, 2]` (src/py.rs:10-28)
+inline void cossin(const DeviceBuffer<int32_t> &phase, DeviceBuffer<int32_t> &out, void *stream = nullptr)
+{
+    require(out.len() == 2 * phase.len(), "out.len() != 2 * phase.len()");
+    check(idsp_cossin_i32(phase.data(), out.data(), phase.len(), stream));
+}
+
+/// `Lockin<[Lowpass<N>; K]>` fed by a per-lane `Accu<Wrapping<i32>>` (src/lockin.rs:30-39).
+template <int N, int K>
+class Lockin {
+    static_assert(N == 1 || N == 2, "Lowpass order must be 1 or 2 (src/lowpass.rs:75)");
+    static_assert(K >= 1 && K <= IDSP_LOCKIN_MAX_CASCADE, "1..4 cascaded lowpasses");
+
+public:
+    Lockin(const std::array<std::array<int32_t, N>, K> &k, const std::vector<int32_t> &accu_state,
+           const std::vector<int32_t> &accu_step, void *stream = nullptr)
+        : lanes_(accu_step.size()), stream_(stream)
+    {
+        require(accu_state.size() == lanes_, "one Accu per lane");
+        cfg_.order = N, cfg_.cascade = K;
+        for (int c = 0; c < K; c++)
+            for (int j = 0; j < N; j++) cfg_.k[c][j] = k[c][j];
+        std::vector<uint32_t> st(idsp_lockin_state_words(&cfg_) * lanes_, 0u);
+        for (size_t l = 0; l < lanes_; l++) st[l] = uint32_t(accu_state[l]), st[lanes_ + l] = uint32_t(accu_step[l]);
+        state_ = DeviceBuffer<uint32_t>(st);
+    }
+    DeviceBuffer<uint32_t> &state() { return state_; }
+    /// x: real samples, y: `Complex<i32>` = [re, im] per sample
+    template <class Layout>
+    void process_view(View<int32_t, Layout> x, ViewMut<int32_t, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        check(idsp_lockin_i32_process(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
+
+private:
+    idsp_lockin_i32 cfg_{};
+    size_t lanes_;
+    void *stream_;
+    DeviceBuffer<uint32_t> state_;
+};
+
+}  // namespace idsp_hip
