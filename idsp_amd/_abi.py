@@ -39,6 +39,14 @@ class BiquadClampF32(C.Structure):
     _fields_ = [("ba", C.c_float * 5), ("u", C.c_float), ("min", C.c_float), ("max", C.c_float)]
 
 
+class BiquadF64(C.Structure):
+    _fields_ = [("ba", C.c_double * 5)]
+
+
+class BiquadClampF64(C.Structure):
+    _fields_ = [("ba", C.c_double * 5), ("u", C.c_double), ("min", C.c_double), ("max", C.c_double)]
+
+
 class HbfCascadeF32(C.Structure):
     _fields_ = [
         ("stages", C.c_int32),
@@ -73,6 +81,11 @@ PROCESSING = {
     "biquad_f32_df2t": _STREAM_SIG,
     "biquad_f32_df2t_clamp": _STREAM_SIG,
     "cascade_f32_df1": _STREAM_SIG,
+    "biquad_f64_df1": _STREAM_SIG,
+    "biquad_f64_df1_clamp": _STREAM_SIG,
+    "biquad_f64_df2t": _STREAM_SIG,
+    "biquad_f64_df2t_clamp": _STREAM_SIG,
+    "cascade_f64_df1": _STREAM_SIG,
     "hbf_dec_f32": _CFG_SIG,
     "hbf_int_f32": _CFG_SIG,
     "cossin_i32": [_P, _P, _SZ, _P],
@@ -86,6 +99,7 @@ HELPERS = {
     "biquad_i32_from_sos": (_I, [_P, _I, _P]),
     "biquad_f32_from_sos": (_I, [_P, _P]),
     "biquad_f32_from_sos_f64": (_I, [_P, _P]),
+    "biquad_f64_from_sos": (_I, [_P, _P]),
     "hbf_dec_cascade": (_I, [_I, _I, _P]),
     "hbf_int_cascade": (_I, [_I, _I, _P]),
     "hbf_dec_response_length": (_I, [_P]),

@@ -159,6 +159,18 @@ int idsp_biquad_f32_from_sos_f64(const double sos[6], idsp_biquad_f32 *out)
     return IDSP_OK;
 }
 
+int idsp_biquad_f64_from_sos(const double sos[6], idsp_biquad_f64 *out)
+{
+    if (!sos || !out) return fail(IDSP_EINVAL, "sos or out is NULL");
+    const double a0 = 1.0 / sos[3];
+    out->ba[0] = sos[0] * a0;
+    out->ba[1] = sos[1] * a0;
+    out->ba[2] = sos[2] * a0;
+    out->ba[3] = -sos[4] * a0;
+    out->ba[4] = -sos[5] * a0;
+    return IDSP_OK;
+}
+
 int idsp_hbf_dec_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out) { return hbf_fill(tap_set, stages, true, out); }
 int idsp_hbf_int_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out) { return hbf_fill(tap_set, stages, false, out); }
 

@@ -1,0 +1,41 @@
+// biquad_f64.hip — C-ABI entry points (include/idsp_hip.h) of the f64 biquad family; device code in biquad_sections.h.
+#include "biquad_sections.h"
+
+using namespace idsp;
+using namespace idsp::bq;
+
+extern "C" {
+
+int idsp_biquad_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, double *y,
+                        size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f64<Df1F64<false>, idsp_biquad_f64, FillF64>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_f64_df1_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state, const double *x, double *y,
+                              size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f64<Df1F64<true>, idsp_biquad_clamp_f64, FillClampF64>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_f64_df2t(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, double *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f64<Df2tF64<false>, idsp_biquad_f64, FillF64>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_biquad_f64_df2t_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state, const double *x, double *y,
+                               size_t lanes, size_t frames, int layout, void *stream)
+{
+    return entry_f64<Df2tF64<true>, idsp_biquad_clamp_f64, FillClampF64>(cfg, n, state, x, y, lanes, frames, layout, stream);
+}
+
+int idsp_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, double *y,
+                         size_t lanes, size_t frames, int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    return run_cascade<double>(FillF64{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+}  // extern "C"

@@ -47,6 +47,10 @@ struct SecF32 {
     float ba[5];
     float u, mn, mx;
 };
+struct SecF64 {
+    double ba[5];
+    double u, mn, mx;
+};
 template <class S, int N>
 struct ChainParams {
     S sec[N];
@@ -183,6 +187,59 @@ struct Df2tF32 {
     }
 };
 
+// ------------------------------------------------------------ f64 sections
+// Same generic impls with C = T = A = f64; a value is two state words (low first).
+__device__ __forceinline__ double ldd(const uint32_t *s, int i)
+{
+    return __builtin_bit_cast(double, uint64_t(s[2 * i]) | (uint64_t(s[2 * i + 1]) << 32));
+}
+__device__ __forceinline__ void std_(uint32_t *s, int i, double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    s[2 * i] = uint32_t(u), s[2 * i + 1] = uint32_t(u >> 32);
+}
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <bool CLAMP>
+struct Df1F64 {
+    using T = double;
+    using Sec = SecF64;
+    static constexpr int W = 8;
+    static constexpr int COST = 60;
+    static __device__ __forceinline__ double step(const SecF64 &c, uint32_t (&s)[W], double x0)
+    {
+        double acc = c.ba[0] * x0;
+        acc = acc + c.ba[1] * ldd(s, 0);
+        acc = acc + c.ba[2] * ldd(s, 1);
+        acc = acc + c.ba[3] * ldd(s, 2);
+        acc = acc + c.ba[4] * ldd(s, 3);
+        if (CLAMP) acc = clampd(acc + c.u, c.mn, c.mx);
+        s[2] = s[0], s[3] = s[1];
+        std_(s, 0, x0);
+        s[6] = s[4], s[7] = s[5];
+        std_(s, 2, acc);
+        return acc;
+    }
+};
+
+template <bool CLAMP>
+struct Df2tF64 {
+    using T = double;
+    using Sec = SecF64;
+    static constexpr int W = 4;
+    static constexpr int COST = 55;
+    static __device__ __forceinline__ double step(const SecF64 &c, uint32_t (&s)[W], double x0)
+    {
+        double y0 = ldd(s, 0) + c.ba[0] * x0;
+        if (CLAMP) y0 = clampd(y0 + c.u, c.mn, c.mx);
+        const double n0 = (ldd(s, 1) + c.ba[1] * x0) + c.ba[3] * y0;
+        const double n1 = c.ba[2] * x0 + c.ba[4] * y0;
+        std_(s, 0, n0);
+        std_(s, 1, n1);
+        return y0;
+    }
+};
+
 // ------------------------------------------------------------ processors
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
 template <class Sec, int N>
@@ -220,7 +277,7 @@ struct Chain {
 
 // `Cascade<[Biquad<C>; N]>` x `DirectForm<T, N>` (biquad.rs:339-364): the input
 // history of section k is the output history of section k-1.
-// Words: h[0..1] = x, h[2+2k..3+2k] = y[k].
+// Values: h[0..1] = x, h[2+2k..3+2k] = y[k]; sizeof(T)/4 state words per value.
 template <class T, int N>
 struct CascadeDf1 {
     using In = T;
@@ -228,47 +285,60 @@ struct CascadeDf1 {
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
     static constexpr int IN_DIV = 1;
-    static constexpr int COST = N * (std::is_same<T, float>::value ? 24 : 50);
-    using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32, SecI32>::type;
+    static constexpr bool kFloat = std::is_floating_point<T>::value;
+    static constexpr int COST = N * (std::is_same<T, float>::value ? 24 : (kFloat ? 60 : 50));
+    using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32,
+                                           typename std::conditional<kFloat, SecF64, SecI32>::type>::type;
     using Params = ChainParams<SecT, N>;
-    static constexpr int W = 2 + 2 * N;
-    uint32_t h[W];
+    static constexpr int V = 2 + 2 * N;       // values
+    static constexpr int VW = sizeof(T) / 4;  // words per value
+    T h[V];
 
     __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
     {
 #pragma unroll
-        for (int w = 0; w < W; w++) h[w] = st[size_t(w) * lanes + lane];
+        for (int v = 0; v < V; v++) {
+            uint32_t w[VW];
+#pragma unroll
+            for (int k = 0; k < VW; k++) w[k] = st[size_t(v * VW + k) * lanes + lane];
+            h[v] = words_to<T>(w);
+        }
     }
     __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
     {
 #pragma unroll
-        for (int w = 0; w < W; w++) st[size_t(w) * lanes + lane] = h[w];
+        for (int v = 0; v < V; v++) {
+            uint32_t w[VW];
+            to_words<T>(h[v], w);
+#pragma unroll
+            for (int k = 0; k < VW; k++) st[size_t(v * VW + k) * lanes + lane] = w[k];
+        }
     }
     __device__ __forceinline__ Out step(const Params &p, In x0)
     {
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            uint32_t *xh = &h[2 * k];
-            const uint32_t *yh = &h[2 * k + 2];
+            T *xh = &h[2 * k];
+            const T *yh = &h[2 * k + 2];
             T y0;
-            if constexpr (std::is_same<T, float>::value) {
-                const SecF32 &c = p.sec[k];
-                float acc = c.ba[0] * x0;
-                acc = acc + c.ba[1] * __uint_as_float(xh[0]);
-                acc = acc + c.ba[2] * __uint_as_float(xh[1]);
-                acc = acc + c.ba[3] * __uint_as_float(yh[0]);
-                acc = acc + c.ba[4] * __uint_as_float(yh[1]);
+            if constexpr (kFloat) {
+                const SecT &c = p.sec[k];
+                T acc = c.ba[0] * x0;
+                acc = acc + c.ba[1] * xh[0];
+                acc = acc + c.ba[2] * xh[1];
+                acc = acc + c.ba[3] * yh[0];
+                acc = acc + c.ba[4] * yh[1];
                 y0 = acc;
             } else {
                 const SecI32 &c = p.sec[k];
-                y0 = shr_lo(sum5(c, x0, int32_t(xh[0]), int32_t(xh[1]), int32_t(yh[0]), int32_t(yh[1])), c.frac);
+                y0 = shr_lo(sum5(c, x0, xh[0], xh[1], yh[0], yh[1]), c.frac);
             }
             xh[1] = xh[0];
-            xh[0] = __builtin_bit_cast(uint32_t, x0);
+            xh[0] = x0;
             x0 = y0;
         }
         h[2 * N + 1] = h[2 * N];
-        h[2 * N] = __builtin_bit_cast(uint32_t, x0);
+        h[2 * N] = x0;
         return x0;
     }
 };
@@ -390,6 +460,27 @@ struct FillClampF32 {
     }
 };
 
+struct FillF64 {
+    const idsp_biquad_f64 *c;
+    void operator()(SecF64 &d, size_t k) const
+    {
+        for (int i = 0; i < 5; i++) d.ba[i] = c[k].ba[i];
+        d.u = 0.0;
+        d.mn = -__builtin_inf();
+        d.mx = __builtin_inf();
+    }
+};
+struct FillClampF64 {
+    const idsp_biquad_clamp_f64 *c;
+    void operator()(SecF64 &d, size_t k) const
+    {
+        for (int i = 0; i < 5; i++) d.ba[i] = c[k].ba[i];
+        d.u = c[k].u;
+        d.mn = c[k].min;
+        d.mx = c[k].max;
+    }
+};
+
 template <class Sec, class Cfg, class Fill>
 int entry_i32(const Cfg *cfg, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
               int layout, void *stream)
@@ -398,6 +489,15 @@ int entry_i32(const Cfg *cfg, size_t n, void *state, const int32_t *x, int32_t *
     if (rc) return rc;
     for (size_t k = 0; k < n; k++)
         if ((rc = check_frac(cfg[k].frac, k))) return rc;
+    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+template <class Sec, class Cfg, class Fill>
+int entry_f64(const Cfg *cfg, size_t n, void *state, const double *x, double *y, size_t lanes, size_t frames,
+              int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
     return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 

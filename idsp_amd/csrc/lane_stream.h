@@ -170,6 +170,28 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
 // One wave per workgroup; tiles are wave-private, so the syncs below only
 // order this wave's own LDS traffic (lds_wave_sync: no vmcnt drain, the next
 // tile's global loads stay in flight).
+// words <-> sample helpers (1- or 2-word element types)
+template <class T>
+__device__ __forceinline__ T words_to(const uint32_t *w)
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, w[0]);
+    } else {
+        const uint64_t u = uint64_t(w[0]) | (uint64_t(w[1]) << 32);
+        return __builtin_bit_cast(T, u);
+    }
+}
+template <class T>
+__device__ __forceinline__ void to_words(const T &v, uint32_t *w)
+{
+    if constexpr (sizeof(T) == 4) {
+        w[0] = __builtin_bit_cast(uint32_t, v);
+    } else {
+        const uint64_t u = __builtin_bit_cast(uint64_t, v);
+        w[0] = uint32_t(u), w[1] = uint32_t(u >> 32);
+    }
+}
+
 template <class P>
 __global__ __launch_bounds__(kWave) void stream_lane_major(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
@@ -177,16 +199,17 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 {
     using In = typename P::In;
     using Out = typename P::Out;
-    static_assert(sizeof(In) == 4, "inputs are one 32-bit word");
-    constexpr int OW = sizeof(Out) / 4;  // output words per sample
-    static_assert(OW == 1 || OW == 2, "outputs are one or two 32-bit words");
-    constexpr int TS = kWave / OW;       // samples per tile and lane; out row = 64 words
-    constexpr int RPI = kWave / TS;      // tile rows covered by one load instruction
-    constexpr bool kAlias = P::HAS_IN && OW == 1;
+    constexpr int IW = sizeof(In) / 4, OW = sizeof(Out) / 4;  // words per input / output sample
+    static_assert((IW == 1 || IW == 2) && (OW == 1 || OW == 2), "samples are one or two 32-bit words");
+    constexpr int MW = IW > OW ? IW : OW;
+    constexpr int TS = kWave / MW;            // samples per tile and lane (widest row = 64 words)
+    constexpr int RWI = TS * IW, RWO = TS * OW;  // words per tile row
+    constexpr int RPI = kWave / RWI;          // tile rows covered by one load instruction
+    constexpr bool kAlias = P::HAS_IN && RWI == RWO;
 
-    __shared__ uint32_t tin[P::HAS_IN ? kWave : 1][TS + 1];
-    __shared__ uint32_t tout_[kAlias ? 1 : kWave][kWave + 1];
-    uint32_t(*tout)[kWave + 1] = kAlias ? reinterpret_cast<uint32_t(*)[kWave + 1]>(tin) : tout_;
+    __shared__ uint32_t tin[P::HAS_IN ? kWave : 1][RWI + 1];
+    __shared__ uint32_t tout_[kAlias ? 1 : kWave][RWO + 1];
+    uint32_t(*tout)[RWO + 1] = kAlias ? reinterpret_cast<uint32_t(*)[RWO + 1]>(tin) : tout_;
 
     const int lid = threadIdx.x;
     const size_t lane0 = size_t(blockIdx.x) * kWave;
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
     const size_t nrows = lanes - lane0 < size_t(kWave) ? lanes - lane0 : size_t(kWave);
 
     __shared__ uint32_t ptab[P::LDS_WORDS ? P::LDS_WORDS : 1];
-    if constexpr (P::LDS_WORDS > 0) P::fill_shared(ptab, lid, kWave);  // published by the first tile barrier
+    if constexpr (P::LDS_WORDS > 0) P::fill_shared(ptab, lid, kWave);  // published by the first tile sync
 
     P p;
     if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
@@ -203,19 +226,26 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 
     const uint32_t *xw = reinterpret_cast<const uint32_t *>(x);
     uint32_t *yw = reinterpret_cast<uint32_t *>(y);
-    // element (row r, col c) handled by this thread in load instruction i
-    const int lrow = lid / TS, lcol = lid % TS;
+    // word (row r, col c) handled by this thread in load instruction i: r = i*RPI + lrow, c = lcol
+    const int lrow = lid / RWI, lcol = lid % RWI;
 
-    uint32_t stage[TS];
+    uint32_t stage[RWI];
     auto fetch = [&](size_t t0) {
         if constexpr (P::HAS_IN) {
-            const size_t ncols = frames - t0 < size_t(TS) ? frames - t0 : size_t(TS);
+            const size_t nw = (frames - t0 < size_t(TS) ? frames - t0 : size_t(TS)) * IW;
 #pragma unroll
-            for (int i = 0; i < TS; i++) {
+            for (int i = 0; i < RWI; i++) {
                 const size_t r = size_t(i) * RPI + lrow;
-                stage[i] = (r < nrows && size_t(lcol) < ncols) ? xw[(lane0 + r) * frames + t0 + lcol] : 0u;
+                stage[i] = (r < nrows && size_t(lcol) < nw) ? xw[((lane0 + r) * frames + t0) * IW + lcol] : 0u;
             }
         }
+    };
+
+    auto one = [&](size_t j) {
+        In v{};
+        if constexpr (P::HAS_IN) v = words_to<In>(&tin[lid][j * IW]);
+        const Out o = step1(p, prm, v);
+        to_words<Out>(o, &tout[lid][j * OW]);
     };
 
     fetch(0);
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
         const size_t ncols = frames - t0 < size_t(TS) ? frames - t0 : size_t(TS);
         if constexpr (P::HAS_IN) {
 #pragma unroll
-            for (int i = 0; i < TS; i++) tin[i * RPI + lrow][lcol] = stage[i];
+            for (int i = 0; i < RWI; i++) tin[i * RPI + lrow][lcol] = stage[i];
         }
         lds_wave_sync();
         if (t0 + TS < frames) fetch(t0 + TS);  // next tile in flight during the arithmetic
@@ -231,35 +261,13 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
         if (active) {
             if (ncols == size_t(TS)) {
 #pragma unroll
-                for (int j = 0; j < TS; j++) {
-                    In v{};
-                    if constexpr (P::HAS_IN) v = __builtin_bit_cast(In, tin[lid][j]);
-                    const Out o = step1(p, prm, v);
-                    if constexpr (OW == 1) {
-                        tout[lid][j] = __builtin_bit_cast(uint32_t, o);
-                    } else {
-                        const uint2 w = __builtin_bit_cast(uint2, o);
-                        tout[lid][2 * j] = w.x;
-                        tout[lid][2 * j + 1] = w.y;
-                    }
-                }
+                for (int j = 0; j < TS; j++) one(size_t(j));
             } else {
-                for (size_t j = 0; j < ncols; j++) {
-                    In v{};
-                    if constexpr (P::HAS_IN) v = __builtin_bit_cast(In, tin[lid][j]);
-                    const Out o = step1(p, prm, v);
-                    if constexpr (OW == 1) {
-                        tout[lid][j] = __builtin_bit_cast(uint32_t, o);
-                    } else {
-                        const uint2 w = __builtin_bit_cast(uint2, o);
-                        tout[lid][2 * j] = w.x;
-                        tout[lid][2 * j + 1] = w.y;
-                    }
-                }
+                for (size_t j = 0; j < ncols; j++) one(j);
             }
         }
         lds_wave_sync();
-        // row-contiguous stores: one instruction = 64 consecutive words of one lane
+        // row-contiguous stores: one instruction = up to 64 consecutive words of one lane
         const size_t nw = ncols * OW;
         for (size_t r = 0; r < nrows; r++) {
             if (size_t(lid) < nw) yw[((lane0 + r) * frames + t0) * OW + lid] = tout[r][lid];

@@ -123,6 +123,19 @@ typedef struct idsp_biquad_clamp_f32 {
     float max;
 } idsp_biquad_clamp_f32;
 
+/* `Biquad<f64>` / `BiquadClamp<f64, f64>` (the generic impl of src/iir/biquad.rs:366-440 with
+ * C = T = A = f64). */
+typedef struct idsp_biquad_f64 {
+    double ba[5];
+} idsp_biquad_f64;
+
+typedef struct idsp_biquad_clamp_f64 {
+    double ba[5];
+    double u;
+    double min;
+    double max;
+} idsp_biquad_clamp_f64;
+
 /* Coefficient ingestion, host side, once per configuration.
  * `From<[[f64;3];2]> for Biquad<C>` (src/iir/biquad.rs:545-566) followed by the
  * float -> Q conversion `round(v * 2^F)` saturating, NaN -> 0
@@ -135,6 +148,8 @@ int idsp_biquad_f32_from_sos(const float sos[6], idsp_biquad_f32 *out);
 /* Same normalisation evaluated in f64, then each coefficient cast `as f32`
  * (`From<[f64;5]> for Biquad<f32>`, src/iir/biquad.rs:570-576). */
 int idsp_biquad_f32_from_sos_f64(const double sos[6], idsp_biquad_f32 *out);
+/* `From<[[f64;3];2]> for Biquad<f64>`. */
+int idsp_biquad_f64_from_sos(const double sos[6], idsp_biquad_f64 *out);
 
 /* All idsp_biquad_* / idsp_cascade_* calls process `n` serial sections
  * (1 <= n <= IDSP_MAX_SECTIONS; `cfg` points at n host-side records; n == 0 is
@@ -204,6 +219,27 @@ int idsp_biquad_f32_df2t_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void 
 /* `Cascade<[Biquad<f32>; n]>` x `DirectForm<f32, n>` (src/iir/biquad.rs:339-364). */
 int idsp_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state,
                          const float *x, float *y, size_t lanes, size_t frames,
+                         int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* iir::Biquad — f64 (same generic impls; every value is two state words,   */
+/* low word first: DF1 W=8 {x0,x1,y0,y1}, DF2T W=4 {s0,s1}, Cascade 4+4n)   */
+/* ------------------------------------------------------------------------ */
+
+int idsp_biquad_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state,
+                        const double *x, double *y, size_t lanes, size_t frames,
+                        int layout, void *stream);
+int idsp_biquad_f64_df1_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state,
+                              const double *x, double *y, size_t lanes, size_t frames,
+                              int layout, void *stream);
+int idsp_biquad_f64_df2t(const idsp_biquad_f64 *cfg, size_t n, void *state,
+                         const double *x, double *y, size_t lanes, size_t frames,
+                         int layout, void *stream);
+int idsp_biquad_f64_df2t_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state,
+                               const double *x, double *y, size_t lanes, size_t frames,
+                               int layout, void *stream);
+int idsp_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state,
+                         const double *x, double *y, size_t lanes, size_t frames,
                          int layout, void *stream);
 
 /* ------------------------------------------------------------------------ */

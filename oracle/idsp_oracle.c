@@ -96,6 +96,18 @@ int idsp_ref_biquad_f32_from_sos_f64(const double sos[6], idsp_biquad_f32 *out)
     return IDSP_OK;
 }
 
+int idsp_ref_biquad_f64_from_sos(const double sos[6], idsp_biquad_f64 *out)
+{
+    if (!sos || !out) return IDSP_EINVAL;
+    double a0 = 1.0 / sos[3];
+    out->ba[0] = sos[0] * a0;
+    out->ba[1] = sos[1] * a0;
+    out->ba[2] = sos[2] * a0;
+    out->ba[3] = -sos[4] * a0;
+    out->ba[4] = -sos[5] * a0;
+    return IDSP_OK;
+}
+
 /* src/iir/coefficients.rs:259-283: fcos_alpha() and lowpass(). */
 void idsp_ref_filter_lowpass(double w0, double gain, double q, double sos[6])
 {
@@ -243,6 +255,65 @@ static inline float df2t_clamp_f32(const idsp_biquad_clamp_f32 *c, uint32_t *s, 
     return y0;
 }
 
+/* f64: the same generic impls (src/iir/biquad.rs:366-383,418-440) with C = T = A = f64;
+ * every value occupies two state words, low word first. */
+static inline double f64_from_words(const uint32_t *s, int i)
+{
+    uint64_t u = (uint64_t)s[2 * i] | ((uint64_t)s[2 * i + 1] << 32);
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+static inline void f64_to_words(uint32_t *s, int i, double d)
+{
+    uint64_t u;
+    memcpy(&u, &d, 8);
+    s[2 * i] = (uint32_t)u;
+    s[2 * i + 1] = (uint32_t)(u >> 32);
+}
+static inline double clamp_f64(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static inline double df1_f64(const double ba[5], uint32_t *s, double x0)
+{
+    double x1 = f64_from_words(s, 0), x2 = f64_from_words(s, 1);
+    double y1 = f64_from_words(s, 2), y2 = f64_from_words(s, 3);
+    double acc = ba[0] * x0;
+    acc = acc + ba[1] * x1;
+    acc = acc + ba[2] * x2;
+    acc = acc + ba[3] * y1;
+    acc = acc + ba[4] * y2;
+    f64_to_words(s, 1, x1); f64_to_words(s, 0, x0);
+    f64_to_words(s, 3, y1); f64_to_words(s, 2, acc);
+    return acc;
+}
+
+static inline double df1_clamp_f64(const idsp_biquad_clamp_f64 *c, uint32_t *s, double x0)
+{
+    double y0 = clamp_f64(df1_f64(c->ba, s, x0) + c->u, c->min, c->max);
+    f64_to_words(s, 2, y0);
+    return y0;
+}
+
+static inline double df2t_f64(const double ba[5], uint32_t *s, double x0)
+{
+    double s0 = f64_from_words(s, 0), s1 = f64_from_words(s, 1);
+    double y0 = s0 + ba[0] * x0;
+    double n0 = (s1 + ba[1] * x0) + ba[3] * y0;
+    double n1 = ba[2] * x0 + ba[4] * y0;
+    f64_to_words(s, 0, n0); f64_to_words(s, 1, n1);
+    return y0;
+}
+
+static inline double df2t_clamp_f64(const idsp_biquad_clamp_f64 *c, uint32_t *s, double x0)
+{
+    double s0 = f64_from_words(s, 0), s1 = f64_from_words(s, 1);
+    double y0 = clamp_f64((s0 + c->ba[0] * x0) + c->u, c->min, c->max);
+    double n0 = (s1 + c->ba[1] * x0) + c->ba[3] * y0;
+    double n1 = c->ba[2] * x0 + c->ba[4] * y0;
+    f64_to_words(s, 0, n0); f64_to_words(s, 1, n1);
+    return y0;
+}
+
 static int frac_ok_i32(const idsp_biquad_i32 *c, size_t n)
 {
     for (size_t i = 0; i < n; i++) if (c[i].frac < 0 || c[i].frac > 31) return 0;
@@ -314,6 +385,10 @@ LANE_DRIVER(idsp_ref_biquad_f32_df1, idsp_biquad_f32, float, 4, 1, df1_f32(c->ba
 LANE_DRIVER(idsp_ref_biquad_f32_df1_clamp, idsp_biquad_clamp_f32, float, 4, 1, df1_clamp_f32(c, s, x0))
 LANE_DRIVER(idsp_ref_biquad_f32_df2t, idsp_biquad_f32, float, 2, 1, df2t_f32(c->ba, s, x0))
 LANE_DRIVER(idsp_ref_biquad_f32_df2t_clamp, idsp_biquad_clamp_f32, float, 2, 1, df2t_clamp_f32(c, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f64_df1, idsp_biquad_f64, double, 8, 1, df1_f64(c->ba, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f64_df1_clamp, idsp_biquad_clamp_f64, double, 8, 1, df1_clamp_f64(c, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f64_df2t, idsp_biquad_f64, double, 4, 1, df2t_f64(c->ba, s, x0))
+LANE_DRIVER(idsp_ref_biquad_f64_df2t_clamp, idsp_biquad_clamp_f64, double, 4, 1, df2t_clamp_f64(c, s, x0))
 
 /* `Cascade<[Biquad<C>; N]>` x `DirectForm<T, N>` (src/iir/biquad.rs:339-364):
  * sample-major fold over sections; section k's input history is the output
@@ -377,6 +452,48 @@ int idsp_ref_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, 
             y[i] = x0;
         }
         for (size_t w = 0; w < W; w++) st[w * lanes + l] = f32_to_bits(s[w]);
+    }
+    return IDSP_OK;
+}
+
+int idsp_ref_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x,
+                             double *y, size_t lanes, size_t frames, int layout)
+{
+    int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (n < 1 || n > 8) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    size_t V = 2 + 2 * n;
+    for (size_t l = 0; l < lanes; l++) {
+        double s[18];
+        for (size_t v = 0; v < V; v++) {
+            uint32_t w[2] = {st[(2 * v) * lanes + l], st[(2 * v + 1) * lanes + l]};
+            s[v] = f64_from_words(w, 0);
+        }
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            double x0 = x[i];
+            double *xh = &s[0];
+            for (size_t k = 0; k < n; k++) {
+                double *yh = &s[2 + 2 * k];
+                const double *ba = cfg[k].ba;
+                double acc = ba[0] * x0;
+                acc = acc + ba[1] * xh[0];
+                acc = acc + ba[2] * xh[1];
+                acc = acc + ba[3] * yh[0];
+                acc = acc + ba[4] * yh[1];
+                xh[1] = xh[0]; xh[0] = x0;
+                x0 = acc; xh = yh;
+            }
+            xh[1] = xh[0]; xh[0] = x0;
+            y[i] = x0;
+        }
+        for (size_t v = 0; v < V; v++) {
+            uint32_t w[2];
+            f64_to_words(w, 0, s[v]);
+            st[(2 * v) * lanes + l] = w[0];
+            st[(2 * v + 1) * lanes + l] = w[1];
+        }
     }
     return IDSP_OK;
 }

@@ -72,6 +72,18 @@ int idsp_ref_biquad_f32_df2t_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, v
 int idsp_ref_cascade_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state,
                              const float *x, float *y, size_t lanes, size_t frames, int layout);
 
+int idsp_ref_biquad_f64_from_sos(const double sos[6], idsp_biquad_f64 *out);
+int idsp_ref_biquad_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state,
+                            const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f64_df1_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state,
+                                  const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f64_df2t(const idsp_biquad_f64 *cfg, size_t n, void *state,
+                             const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f64_df2t_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state,
+                                   const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state,
+                             const double *x, double *y, size_t lanes, size_t frames, int layout);
+
 int idsp_ref_hbf_dec_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out);
 int idsp_ref_hbf_int_cascade(int tap_set, int stages, idsp_hbf_cascade_f32 *out);
 int idsp_ref_hbf_dec_response_length(const idsp_hbf_cascade_f32 *cfg);

@@ -127,6 +127,31 @@ def biquad_clamp_f32(rows):
     return arr
 
 
+def biquad_f64(rows):
+    arr = (_abi.BiquadF64 * max(len(rows), 1))()
+    for a, ba in zip(arr, rows):
+        a.ba[:] = [float(v) for v in ba]
+    return arr
+
+
+def biquad_clamp_f64(rows):
+    arr = (_abi.BiquadClampF64 * max(len(rows), 1))()
+    for a, (ba, u, lo, hi) in zip(arr, rows):
+        a.ba[:] = [float(v) for v in ba]
+        a.u, a.min, a.max = u, lo, hi
+    return arr
+
+
+def ulp_diff_f64(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    ia, ib = a.view(np.int64), b.view(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFFFFFFFFFF), ia).astype(object)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFFFFFFFFFF), ib).astype(object)
+    d = np.abs(ia - ib)
+    return np.where(np.isnan(a) & np.isnan(b), 0, d)
+
+
 def hbf_cfg(taps_list):
     cfg = _abi.HbfCascadeF32()
     cfg.stages = len(taps_list)

@@ -176,6 +176,64 @@ def test_cascade_f32_parity(bes, layout):
         run_both(bes, "cascade_f32_df1", cfg, n, 2 + 2 * n, x, lanes, frames, layout, rng, is_float=True)
 
 
+F64_OPS = [("biquad_f64_df1", 8, False), ("biquad_f64_df1_clamp", 8, True),
+           ("biquad_f64_df2t", 4, False), ("biquad_f64_df2t_clamp", 4, True)]
+
+
+def adversarial_f64(rng, shape):
+    x = rng.standard_normal(size=shape)
+    flat = x.reshape(-1)
+    if flat.size >= 8:
+        k = max(1, flat.size // 10)
+        idx = rng.choice(flat.size, size=k, replace=False)
+        flat[idx] = rng.choice(np.array([0.0, -0.0, 1e-310, -3e-320, 1e300, -1e300, 1.0]), size=k)
+    return x
+
+
+@pytest.mark.parametrize("op,words,clamp", F64_OPS)
+@pytest.mark.parametrize("layout", [FM, LM])
+def test_biquad_f64_parity(bes, op, words, clamp, layout):
+    """`Biquad<f64>`: the same generic impls; held to 0 ULP (allowed: 1)."""
+    ob, gb = bes
+    rng = np.random.default_rng(zlib.crc32(f"{op}-{layout}-d".encode()))
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 1, 3, 4, 1, 5, 1, 9, 2, 1, 1, 2, 1]):
+        rows = random_f32_sections(rng, n, clamp)  # f32-representable coefficients are valid f64 ones
+        rows = [(r[0], r[1], r[2], r[3]) if clamp else r for r in rows]
+        cfg = H.biquad_clamp_f64(rows) if clamp else H.biquad_f64(rows)
+        x = adversarial_f64(rng, lanes * frames)
+        init = rng.standard_normal(size=(words * n // 2, lanes)).view(np.uint32).reshape(words * n // 2, lanes, 2)
+        init = np.ascontiguousarray(init.transpose(0, 2, 1)).reshape(words * n, lanes)  # value v -> words 2v (lo), 2v+1 (hi)
+        for inplace in (False, True):
+            so, sg = init.copy(), init.copy()
+            rco, yo = ob.stream(op, cfg, n, so, x.copy(), lanes, frames, layout, inplace=inplace)
+            rcg, yg = gb.stream(op, cfg, n, sg, x.copy(), lanes, frames, layout, inplace=inplace)
+            assert rco == 0 and rcg == 0, H.engine().err()
+            assert H.ulp_diff_f64(yo, yg).max(initial=0) <= F32_ULP_TOL
+            assert np.array_equal(so, sg)
+            rco, yo = ob.stream(op, cfg, n, so, x[::-1].copy(), lanes, frames, layout)
+            rcg, yg = gb.stream(op, cfg, n, sg, x[::-1].copy(), lanes, frames, layout)
+            assert H.ulp_diff_f64(yo, yg).max(initial=0) <= F32_ULP_TOL and np.array_equal(so, sg)
+
+
+@pytest.mark.parametrize("layout", [FM, LM])
+def test_cascade_f64_parity(bes, layout):
+    ob, gb = bes
+    rng = np.random.default_rng(17 + layout)
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 3, 4, 5, 6, 7, 8, 1, 4, 8, 1, 2, 3]):
+        cfg = H.biquad_f64(random_f32_sections(rng, n, False))
+        x = adversarial_f64(rng, lanes * frames)
+        so, sg = np.zeros((4 + 4 * n, lanes), np.uint32), np.zeros((4 + 4 * n, lanes), np.uint32)
+        for rep in range(2):
+            rco, yo = ob.stream("cascade_f64_df1", cfg, n, so, x, lanes, frames, layout)
+            rcg, yg = gb.stream("cascade_f64_df1", cfg, n, sg, x, lanes, frames, layout)
+            assert rco == 0 and rcg == 0
+            assert H.ulp_diff_f64(yo, yg).max(initial=0) <= F32_ULP_TOL and np.array_equal(so, sg)
+        # same samples as n separate DF1 sections
+        _, yr = gb.stream("biquad_f64_df1", cfg, n, np.zeros((8 * n, lanes), np.uint32), x, lanes, frames, layout)
+        _, yc = gb.stream("cascade_f64_df1", cfg, n, np.zeros((4 + 4 * n, lanes), np.uint32), x, lanes, frames, layout)
+        assert np.array_equal(yr.view(np.uint64), yc.view(np.uint64))
+
+
 def test_f32_nonfinite_and_denormal_tail(bes):
     """inf/NaN propagate like the reference (NaN compares as NaN); an impulse
     response decaying into denormals stays bit-identical (denormals enabled)."""

@@ -112,6 +112,47 @@ def test_f32_sections(o):
             assert np.array_equal(y.view(np.uint32), want.view(np.uint32)), (op, trial)
 
 
+def test_f64_sections(o):
+    """`Biquad<f64>` (same generic impls): Python floats are IEEE f64, every operation rounded once."""
+    rng = np.random.default_rng(6)
+    n = 300
+    ba = (rng.standard_normal(5) * 0.5).tolist()
+    u, lo, hi = 0.0625, -0.7, 0.9
+    x = rng.standard_normal(n)
+    x[::13] = 1e-310
+
+    def df1(s, v, clamp):
+        acc = ba[0] * v
+        acc = acc + ba[1] * s[0]
+        acc = acc + ba[2] * s[1]
+        acc = acc + ba[3] * s[2]
+        acc = acc + ba[4] * s[3]
+        if clamp:
+            acc = spec.clamp(acc + u, lo, hi)
+        s[1], s[0], s[3], s[2] = s[0], v, s[2], acc
+        return acc
+
+    def df2t(s, v, clamp):
+        y0 = s[0] + ba[0] * v
+        if clamp:
+            y0 = spec.clamp(y0 + u, lo, hi)
+        s[0] = s[1] + ba[1] * v + ba[3] * y0
+        s[1] = ba[2] * v + ba[4] * y0
+        return y0
+
+    for op, words, cfg, fn, clamp in [
+        ("biquad_f64_df1", 8, H.biquad_f64([ba]), df1, False),
+        ("biquad_f64_df1_clamp", 8, H.biquad_clamp_f64([(ba, u, lo, hi)]), df1, True),
+        ("biquad_f64_df2t", 4, H.biquad_f64([ba]), df2t, False),
+        ("biquad_f64_df2t_clamp", 4, H.biquad_clamp_f64([(ba, u, lo, hi)]), df2t, True),
+    ]:
+        y = np.empty_like(x)
+        assert o.stream(op, cfg, 1, np.zeros((words, 1), np.uint32), x, y, 1, n, LM) == 0
+        s = [0.0] * 4
+        want = np.array([fn(s, float(v), clamp) for v in x])
+        assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), op
+
+
 @pytest.mark.parametrize("taps_name,stages", [("HBF_TAPS", 4), ("HBF_TAPS", 5), ("HBF_TAPS_98", 3), ("HBF_TAPS_98", 5)])
 def test_hbf_cascades(o, taps_name, stages):
     tap_set = 0 if taps_name == "HBF_TAPS" else 1
