@@ -55,6 +55,10 @@ class HbfCascadeF32(C.Structure):
     ]
 
 
+class FirSymF32(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("m", C.c_int32), ("taps", C.c_float * HBF_MAX_TAPS)]
+
+
 class LockinI32(C.Structure):
     _fields_ = [("order", C.c_int32), ("cascade", C.c_int32), ("k", (C.c_int32 * 2) * LOCKIN_MAX_CASCADE)]
 
@@ -88,6 +92,7 @@ PROCESSING = {
     "cascade_f64_df1": _STREAM_SIG,
     "hbf_dec_f32": _CFG_SIG,
     "hbf_int_f32": _CFG_SIG,
+    "fir_sym_f32_process": _CFG_SIG,
     "cossin_i32": [_P, _P, _SZ, _P],
     "dds_i32": [_P, _P, _SZ, _SZ, _I, _P],
     "lockin_i32_process": _CFG_SIG,
@@ -107,6 +112,7 @@ HELPERS = {
     "hbf_dec_state_words": (_SZ, [_P]),
     "hbf_int_state_words": (_SZ, [_P]),
     "lockin_state_words": (_SZ, [_P]),
+    "fir_sym_state_words": (_SZ, [_P]),
 }
 
 # product-only utilities

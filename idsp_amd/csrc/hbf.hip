@@ -443,6 +443,59 @@ __global__ __launch_bounds__(kThreads) void hbf_int_kernel(const HbfArgs a, uint
     }
 }
 
+// ------------------------------------------------------ same-rate symmetric FIR
+// `type_fir!` (src/hbf.rs:70-138): one 256-thread workgroup per lane, kChunk samples per
+// chunk in LDS behind the LEN-sample history; thread i produces output i (stride-1 LDS reads).
+struct FirArgs {
+    int32_t m, odd, sym;
+    float taps[IDSP_HBF_MAX_TAPS];
+};
+
+__global__ __launch_bounds__(kThreads) void fir_sym_kernel(const FirArgs a, uint32_t *st, const float *x, float *y,
+                                                           const size_t lanes, const size_t frames, const int lane_major)
+{
+    __shared__ float buf[2 * IDSP_HBF_MAX_TAPS + kChunk + 8];
+    const int tid = threadIdx.x;
+    const size_t lane = blockIdx.x;
+    const int M = a.m, len = 2 * M - 1 + a.odd, win = 2 * M + a.odd;
+    for (int w = tid; w < len; w += kThreads) buf[w] = __uint_as_float(st[size_t(w) * lanes + lane]);
+    for (size_t f0 = 0; f0 < frames; f0 += kChunk) {
+        const int n = int(frames - f0 < size_t(kChunk) ? frames - f0 : size_t(kChunk));
+        for (int i = tid; i < n; i += kThreads)
+            buf[len + i] = lane_major ? x[lane * frames + f0 + size_t(i)] : x[(f0 + size_t(i)) * lanes + lane];
+        lds_barrier();
+        float out[kChunk / kThreads];
+#pragma unroll
+        for (int j = 0; j < kChunk / kThreads; j++) {
+            const int i = tid + j * kThreads;
+            if (i < n) {
+                const float *w = buf + i;
+                float acc = -0.0f;  // f32::sum
+                for (int k = 0; k < M; k++) {
+                    const float nw = w[win - 1 - k], od = w[k];
+                    acc = acc + (a.sym ? nw + od : nw - od) * a.taps[k];
+                }
+                out[j] = (a.odd && a.sym) ? acc + w[M] : acc;
+            }
+        }
+        float keep = tid < len ? buf[n + tid] : 0.f;  // len <= 64 < kThreads
+        lds_barrier();
+        if (tid < len) buf[tid] = keep;
+#pragma unroll
+        for (int j = 0; j < kChunk / kThreads; j++) {
+            const int i = tid + j * kThreads;
+            if (i < n) {
+                if (lane_major)
+                    y[lane * frames + f0 + size_t(i)] = out[j];
+                else
+                    y[(f0 + size_t(i)) * lanes + lane] = out[j];
+            }
+        }
+        lds_barrier();
+    }
+    for (int w = tid; w < len; w += kThreads) st[size_t(w) * lanes + lane] = __float_as_uint(buf[w]);
+}
+
 // ------------------------------------------------------------------- host
 int fill_args(const idsp_hbf_cascade_f32 *cfg, bool dec, HbfArgs &a, int &lds_words)
 {
@@ -541,6 +594,30 @@ int idsp_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *
                      size_t frames, int layout, void *stream)
 {
     return launch_hbf(hbf_int_kernel, cfg, false, state, x, y, lanes, frames, layout, stream);
+}
+
+size_t idsp_fir_sym_state_words(const idsp_fir_sym_f32 *cfg)
+{
+    if (!cfg || cfg->kind < 0 || cfg->kind > 3 || cfg->m < 1 || cfg->m > IDSP_HBF_MAX_TAPS) return 0;
+    return size_t(2 * cfg->m - 1 + (cfg->kind == IDSP_FIR_ODD_SYMMETRIC || cfg->kind == IDSP_FIR_ODD_ANTISYMMETRIC ? 1 : 0));
+}
+
+int idsp_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const float *x, float *y, size_t lanes,
+                             size_t frames, int layout, void *stream)
+{
+    if (!idsp_fir_sym_state_words(cfg)) return fail(IDSP_EINVAL, "invalid FIR configuration (kind 0..3, m 1..32)");
+    if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return fail(IDSP_EINVAL, "bad layout %d", layout);
+    if (lanes && (!state || (frames && (!x || !y)))) return fail(IDSP_EINVAL, "state, x or y is NULL");
+    if (lanes > (size_t(1) << 31) - 1) return fail(IDSP_EINVAL, "lanes out of range");
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+    FirArgs a;
+    a.m = cfg->m;
+    a.odd = (cfg->kind == IDSP_FIR_ODD_SYMMETRIC || cfg->kind == IDSP_FIR_ODD_ANTISYMMETRIC) ? 1 : 0;
+    a.sym = (cfg->kind == IDSP_FIR_ODD_SYMMETRIC || cfg->kind == IDSP_FIR_EVEN_SYMMETRIC) ? 1 : 0;
+    for (int k = 0; k < IDSP_HBF_MAX_TAPS; k++) a.taps[k] = k < cfg->m ? cfg->taps[k] : 0.f;
+    hipLaunchKernelGGL(fir_sym_kernel, dim3(unsigned(lanes)), dim3(kThreads), 0, as_stream(stream), a,
+                       static_cast<uint32_t *>(state), x, y, lanes, frames, layout == IDSP_LANE_MAJOR ? 1 : 0);
+    return launch_status();
 }
 
 }  // extern "C"

@@ -295,6 +295,29 @@ int idsp_hbf_dec_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *
 int idsp_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
                      size_t lanes, size_t frames, int layout, void *stream);
 
+/* Same-rate linear-phase FIR, `SplitProcess<f32, f32, [f32; N]>` for the four
+ * symmetry types of `type_fir!` (src/hbf.rs:70-138, `get()` :46-68):
+ *   window w of 2M + odd samples ending at the current input,
+ *   y = sum_k (w[2M-1+odd-k] +/- w[k]) * tap[k]  (+ w[M] for ODD_SYMMETRIC: unity centre tap)
+ * State words per lane: the last LEN = 2M - 1 + odd inputs, oldest first
+ * (what `copy_within` keeps, src/hbf.rs:103,121). */
+typedef enum idsp_fir_kind {
+    IDSP_FIR_ODD_SYMMETRIC = 0,     /* Type I,   `OddSymmetric`      src/hbf.rs:129 */
+    IDSP_FIR_EVEN_SYMMETRIC = 1,    /* Type II,  `EvenSymmetric`     src/hbf.rs:131 */
+    IDSP_FIR_ODD_ANTISYMMETRIC = 2, /* Type III, `OddAntiSymmetric`  src/hbf.rs:134 */
+    IDSP_FIR_EVEN_ANTISYMMETRIC = 3 /* Type IV,  `EvenAntiSymmetric` src/hbf.rs:136 */
+} idsp_fir_kind;
+
+typedef struct idsp_fir_sym_f32 {
+    int32_t kind; /* idsp_fir_kind */
+    int32_t m;    /* one-sided tap count, 1..IDSP_HBF_MAX_TAPS */
+    float taps[IDSP_HBF_MAX_TAPS];
+} idsp_fir_sym_f32;
+
+size_t idsp_fir_sym_state_words(const idsp_fir_sym_f32 *cfg);
+int idsp_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const float *x, float *y,
+                             size_t lanes, size_t frames, int layout, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* cossin / Accu DDS / Lockin                                               */
 /* ------------------------------------------------------------------------ */

@@ -739,6 +739,47 @@ int idsp_ref_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const flo
     return IDSP_OK;
 }
 
+/* `type_fir!` same-rate FIR (src/hbf.rs:70-138) with `get::<_,_,M,ODD,SYM>` (:46-68):
+ * literal block loop incl. copy_within; st = last LEN inputs. */
+size_t idsp_ref_fir_sym_state_words(const idsp_fir_sym_f32 *c)
+{
+    if (!c || c->kind < 0 || c->kind > 3 || c->m < 1 || c->m > IDSP_HBF_MAX_TAPS) return 0;
+    int odd = (c->kind == IDSP_FIR_ODD_SYMMETRIC || c->kind == IDSP_FIR_ODD_ANTISYMMETRIC);
+    return (size_t)(2 * c->m - 1 + odd);
+}
+
+int idsp_ref_fir_sym_f32_process(const idsp_fir_sym_f32 *c, void *state, const float *x, float *y,
+                                 size_t lanes, size_t frames, int layout)
+{
+    size_t len = idsp_ref_fir_sym_state_words(c);
+    if (!len || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    int m = c->m;
+    int odd = (c->kind == IDSP_FIR_ODD_SYMMETRIC || c->kind == IDSP_FIR_ODD_ANTISYMMETRIC);
+    int sym = (c->kind == IDSP_FIR_ODD_SYMMETRIC || c->kind == IDSP_FIR_EVEN_SYMMETRIC);
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        float buf[2 * IDSP_HBF_MAX_TAPS + HBF_BLOCK];
+        for (size_t w = 0; w < len; w++) buf[w] = f32_from_bits(st[w * lanes + l]);
+        for (size_t p = 0; p < frames; p += HBF_BLOCK) {
+            size_t n = frames - p < HBF_BLOCK ? frames - p : HBF_BLOCK;
+            for (size_t i = 0; i < n; i++) buf[len + i] = x[idx_of(p + i, l, lanes, frames, layout)];
+            for (size_t i = 0; i < n; i++) {
+                const float *w = buf + i; /* window of 2M + odd samples */
+                float acc = -0.0f;
+                for (int k = 0; k < m; k++) {
+                    float nw = w[2 * m - 1 + odd - k], od = w[k];
+                    acc = acc + (sym ? nw + od : nw - od) * c->taps[k];
+                }
+                y[idx_of(p + i, l, lanes, frames, layout)] = (odd && sym) ? acc + w[m] : acc;
+            }
+            memmove(buf, buf + n, sizeof(float) * len);
+        }
+        for (size_t w = 0; w < len; w++) st[w * lanes + l] = f32_to_bits(buf[w]);
+    }
+    return IDSP_OK;
+}
+
 /* ----------------------------------------------------------------- cossin */
 
 #define COSSIN_DEPTH 7

@@ -95,6 +95,10 @@ int idsp_ref_hbf_dec_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const flo
 int idsp_ref_hbf_int_f32(const idsp_hbf_cascade_f32 *cfg, void *state, const float *x, float *y,
                          size_t lanes, size_t frames, int layout);
 
+size_t idsp_ref_fir_sym_state_words(const idsp_fir_sym_f32 *cfg);
+int idsp_ref_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const float *x, float *y,
+                                 size_t lanes, size_t frames, int layout);
+
 int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n);
 int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout);
 size_t idsp_ref_lockin_state_words(const idsp_lockin_i32 *cfg);

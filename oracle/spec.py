@@ -305,6 +305,26 @@ def _get(taps, x: Sequence) -> list:
     return out
 
 
+def fir_sym(taps, odd: bool, sym: bool, hist: list, x: Sequence) -> list:
+    """`type_fir!` same-rate FIR (hbf.rs:70-138) via `get::<_,_,M,ODD,SYM>` (hbf.rs:46-68);
+    `hist` holds the last LEN = 2M-1+odd inputs and is updated in place."""
+    m = len(taps)
+    ln = 2 * m - 1 + int(odd)
+    assert len(hist) == ln
+    buf = [f32(v) for v in hist] + [f32(v) for v in x]
+    out = []
+    for i in range(len(x)):
+        w = buf[i:i + 2 * m + int(odd)]
+        old, new = w[:m], w[len(w) - m:]
+        acc = f32(-0.0)
+        for k in range(m):
+            nw, od = new[m - 1 - k], old[k]
+            acc = acc + ((nw + od) if sym else (nw - od)) * f32(taps[k])
+        out.append(acc + w[m] if (odd and sym) else acc)
+    hist[:] = buf[len(x):len(x) + ln]
+    return out
+
+
 class HbfDec:
     """`HbfDec<[f32; N]>` (hbf.rs:142-155) with the reference's array sizes."""
 

@@ -339,6 +339,30 @@ def test_hbf_custom_taps_generic_path(bes, kind):
         assert np.array_equal(so, sg)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("layout", [LM, FM])
+def test_fir_sym_parity(bes, kind, layout):
+    """Same-rate Type I-IV linear-phase FIR (src/hbf.rs:70-138)."""
+    ob, gb = bes
+    rng = np.random.default_rng(300 + 10 * kind + layout)
+    for m in (1, 4, 23, 32):
+        cfg = _abi.FirSymF32()
+        cfg.kind, cfg.m = kind, m
+        for k, v in enumerate((rng.standard_normal(m) * 0.3).astype(np.float32)):
+            cfg.taps[k] = v
+        words = H.oracle().fn["fir_sym_state_words"](C.byref(cfg))
+        for lanes, frames in [(1, 1), (3, 255), (2, 4096), (5, 4097), (17, 9000)]:
+            init = rng.standard_normal(size=(words, lanes)).astype(np.float32).view(np.uint32)
+            so, sg = init.copy(), init.copy()
+            for rep in range(2):
+                x = adversarial_f32(rng, lanes * frames)
+                rco, yo = ob.cfgcall("fir_sym_f32_process", cfg, so, x, (lanes * frames,), np.float32, lanes, frames, layout)
+                rcg, yg = gb.cfgcall("fir_sym_f32_process", cfg, sg, x, (lanes * frames,), np.float32, lanes, frames, layout)
+                assert rco == 0 and rcg == 0, H.engine().err()
+                assert H.ulp_diff_f32(yo, yg).max(initial=0) <= F32_ULP_TOL
+                assert np.array_equal(so, sg)
+
+
 # ------------------------------------------------------- dds / lowpass / lockin
 def test_cossin_parity_all_octants(bes):
     ob, gb = bes

@@ -220,3 +220,49 @@ def test_lowpass_and_lockin(o, order, cascade):
     want = [spec.lockin(ks, siq, int(v), acc.next()) for v in x]
     assert y.reshape(-1, 2).tolist() == [list(w) for w in want]
     assert spec.i32(int(st[0, 0])) == acc.state
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_fir_sym(o, kind):
+    """Same-rate `type_fir!` FIRs (src/hbf.rs:70-138): C oracle vs spec, incl. chunked continuation."""
+    rng = np.random.default_rng(40 + kind)
+    odd, sym = kind in (0, 2), kind in (0, 1)
+    for m in (1, 3, 8, 23):
+        taps = (rng.standard_normal(m) * 0.3).astype(np.float32)
+        cfg = _abi.FirSymF32()
+        cfg.kind, cfg.m = kind, m
+        for k, v in enumerate(taps):
+            cfg.taps[k] = v
+        words = o.fn["fir_sym_state_words"](C.byref(cfg))
+        assert words == 2 * m - 1 + int(odd)
+        st = np.zeros((words, 1), np.uint32)
+        hist = [np.float32(0)] * words
+        for n in (1, 50, 33):
+            x = rng.standard_normal(n).astype(np.float32)
+            y = np.empty_like(x)
+            assert o.cfgcall("fir_sym_f32_process", cfg, st, x, y, 1, n, LM) == 0
+            want = np.array(spec.fir_sym(taps.tolist(), odd, sym, hist, x), dtype=np.float32)
+            assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
+            assert np.array_equal(st[:, 0], np.array(hist, np.float32).view(np.uint32))
+
+
+def test_fir_even_symmetric_equals_hbf_odd_branch(o):
+    """The half-band decimator is built on the EvenSymmetric FIR (src/hbf.rs:177): feeding the odd
+    samples through the same-rate FIR and adding the delayed even samples reproduces HbfDec."""
+    rng = np.random.default_rng(77)
+    taps = list(spec.HBF_TAPS[3])
+    m, n = len(taps), 40
+    x = rng.standard_normal(2 * n).astype(np.float32)
+    cfg = _abi.FirSymF32()
+    cfg.kind, cfg.m = 1, m
+    for k, v in enumerate(taps):
+        cfg.taps[k] = v
+    st = np.zeros((2 * m - 1, 1), np.uint32)
+    odd = np.ascontiguousarray(x[1::2])
+    yo = np.empty_like(odd)
+    assert o.cfgcall("fir_sym_f32_process", cfg, st, odd, yo, 1, n, LM) == 0
+    even_delayed = np.concatenate([np.zeros(m - 1, np.float32), x[0::2]])[:n]
+    h = H.hbf_cfg([taps])
+    yd = np.empty(n, np.float32)
+    assert o.cfgcall("hbf_dec_f32", h, np.zeros((3 * m - 2, 1), np.uint32), x, yd, 1, n, LM) == 0
+    assert np.array_equal((yo + even_delayed).view(np.uint32), yd.view(np.uint32))
