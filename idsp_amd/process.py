@@ -39,7 +39,7 @@ from ._lib import IdspError, call, load
 __all__ = [
     "FrameMajor", "LaneMajor", "View", "ViewMut", "Biquad", "BiquadClamp", "Cascade",
     "DirectForm1", "DirectForm2Transposed", "DirectForm1Wide", "DirectForm1Dither", "DirectForm",
-    "Split", "Lanes", "HbfDecCascade", "HbfIntCascade", "HBF_TAPS", "HBF_TAPS_98",
+    "Split", "Lanes", "HbfDecCascade", "HbfIntCascade", "FirSym", "HBF_TAPS", "HBF_TAPS_98",
     "Lowpass", "Lockin", "Accu", "Dds", "cossin", "sos", "sos_clamp_wide", "IdspError",
 ]
 
@@ -96,10 +96,13 @@ class Biquad:
     (src/iir/biquad.rs:96-116).  `frac=F` selects `Q32<F>` fixed point
     (raw integer bits), `frac=None` selects `f32`."""
 
-    def __init__(self, ba: Sequence, frac: Optional[int] = None):
+    def __init__(self, ba: Sequence, frac: Optional[int] = None, f64: bool = False):
         if len(ba) != 5:
             raise ValueError("ba must hold 5 coefficients")
+        if frac is not None and f64:
+            raise ValueError("choose Q32<F> or f64, not both")
         self.frac = frac
+        self.f64 = f64  # `Biquad<f64>` instead of `Biquad<f32>`
         self.ba = [int(v) for v in ba] if frac is not None else [float(v) for v in ba]
 
     @property
@@ -107,7 +110,7 @@ class Biquad:
         return self.frac is not None
 
     @classmethod
-    def from_sos(cls, sos: Sequence[float], frac: Optional[int] = None, f32_math: bool = False) -> "Biquad":
+    def from_sos(cls, sos: Sequence[float], frac: Optional[int] = None, f32_math: bool = False, f64: bool = False) -> "Biquad":
         """`Biquad::from([[b0,b1,b2],[a0,a1,a2]])` (src/iir/biquad.rs:545-566);
         with `frac` the coefficients are quantised like `f64 -> Q32<F>`
         (dsp-fixedpoint/src/num_traits_impl.rs:32-46)."""
@@ -116,6 +119,10 @@ class Biquad:
             out = _abi.BiquadI32()
             call("biquad_i32_from_sos", (C.c_double * 6)(*sos), frac, C.byref(out))
             return cls(list(out.ba), frac)
+        if f64:
+            out = _abi.BiquadF64()
+            call("biquad_f64_from_sos", (C.c_double * 6)(*sos), C.byref(out))
+            return cls(list(out.ba), None, f64=True)
         out = _abi.BiquadF32()
         if f32_math:
             call("biquad_f32_from_sos", (C.c_float * 6)(*sos), C.byref(out))
@@ -161,6 +168,10 @@ class BiquadClamp:
     @property
     def is_fixed(self) -> bool:
         return self.coeff.is_fixed
+
+    @property
+    def f64(self) -> bool:
+        return self.coeff.f64
 
 
 class Cascade:
@@ -230,6 +241,20 @@ def _biquad_entry(sections, kind: _StateKind):
     if kind.name not in table:
         raise ValueError(f"no SplitProcess impl for Biquad<f32> on {kind}")
     name = table[kind.name] + ("_clamp" if clamp else "")
+    if first.f64:
+        if any(not s.f64 for s in sections):
+            raise ValueError("sections of one slice composition must share one type")
+        name = name.replace("f32", "f64")
+        if clamp:
+            arr = (_abi.BiquadClampF64 * n)()
+            for a, s in zip(arr, sections):
+                a.ba[:] = s.coeff.ba
+                a.u, a.min, a.max = s.u, s.min, s.max
+        else:
+            arr = (_abi.BiquadF64 * n)()
+            for a, s in zip(arr, sections):
+                a.ba[:] = s.ba
+        return name, arr, torch.float64
     if clamp:
         arr = (_abi.BiquadClampF32 * n)()
         for a, s in zip(arr, sections):
@@ -326,19 +351,23 @@ class Lanes(_LaneOp):
             if state_kind is not None and state_kind.words != kind.words:
                 raise ValueError("Cascade<[Biquad; N]> needs DirectForm<T, N>")
             fixed = secs[0].is_fixed
-            self._name = "cascade_i32_df1" if fixed else "cascade_f32_df1"
+            self._name = "cascade_i32_df1" if fixed else ("cascade_f64_df1" if secs[0].f64 else "cascade_f32_df1")
             if fixed:
                 arr = (_abi.BiquadI32 * len(secs))()
                 for a, s in zip(arr, secs):
                     a.ba[:] = s.ba
                     a.frac = s.frac
+            elif secs[0].f64:
+                arr = (_abi.BiquadF64 * len(secs))()
+                for a, s in zip(arr, secs):
+                    a.ba[:] = s.ba
             else:
                 arr = (_abi.BiquadF32 * len(secs))()
                 for a, s in zip(arr, secs):
                     a.ba[:] = s.ba
-            self._cfg, dt = arr, (torch.int32 if fixed else torch.float32)
+            self._cfg, dt = arr, (torch.int32 if fixed else (torch.float64 if secs[0].f64 else torch.float32))
             self._n = len(secs)
-            words = kind.words
+            words = kind.words * (2 if dt == torch.float64 else 1)
         else:
             secs = list(config) if isinstance(config, (list, tuple)) else [config]
             if state_kind is None:
@@ -348,7 +377,7 @@ class Lanes(_LaneOp):
                 self._name, self._cfg, dt = _biquad_entry(secs, state_kind)
             else:  # empty slice: identity (compose.rs:63-65); dtype fixed by the caller
                 self._name, self._cfg, dt = "biquad_i32_df1", None, torch.int32
-            words = state_kind.words * max(self._n, 1)
+            words = state_kind.words * max(self._n, 1) * (2 if dt == torch.float64 else 1)
         self.dtype_in = self.dtype_out = dt
         super().__init__(n_lanes, words, device)
 
@@ -412,6 +441,31 @@ class HbfIntCascade(_Hbf):
     """`HBF_INT_CASCADE` / `HbfInt2..32` (src/hbf.rs:454-512).  Input `f32`, output `[f32; R]`."""
 
     _dec = False
+
+
+class FirSym(_LaneOp):
+    """Same-rate linear-phase FIR `OddSymmetric / EvenSymmetric / OddAntiSymmetric /
+    EvenAntiSymmetric<[f32; M]>` as `SplitProcess<f32, f32, [f32; N]>` (src/hbf.rs:70-138)."""
+
+    dtype_in = dtype_out = torch.float32
+    KINDS = {"OddSymmetric": 0, "EvenSymmetric": 1, "OddAntiSymmetric": 2, "EvenAntiSymmetric": 3}
+
+    def __init__(self, kind: str, taps: Sequence[float]):
+        load()
+        if kind not in self.KINDS or not 1 <= len(taps) <= _abi.HBF_MAX_TAPS:
+            raise ValueError("kind must name one of the four type_fir! types, 1..32 taps")
+        self.cfg = _abi.FirSymF32()
+        self.cfg.kind, self.cfg.m = self.KINDS[kind], len(taps)
+        for k, v in enumerate(taps):
+            self.cfg.taps[k] = v
+
+    def lanes(self, n: int, device="cuda") -> "FirSym":
+        _LaneOp.__init__(self, n, call("fir_sym_state_words", C.byref(self.cfg)), device)
+        return self
+
+    def _run(self, x, y, frames, layout):
+        call("fir_sym_f32_process", C.byref(self.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
+             C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
 
 
 # --------------------------------------------------------------------------

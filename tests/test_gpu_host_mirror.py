@@ -129,3 +129,18 @@ def test_lockin_recovers_dc_iq():
     iq = y[12288:].double().mean(dim=0).cpu().numpy() / amp
     assert np.allclose(iq[:, 0], 0.25 * math.cos(phi), atol=3e-3)
     assert np.allclose(iq[:, 1], 0.25 * math.sin(phi), atol=3e-3)
+
+
+def test_f64_biquad_and_fir_through_the_mirror():
+    """`Biquad<f64>` lanes and a same-rate `EvenSymmetric` FIR."""
+    b = ia.Biquad.from_sos([0.2, 0.3, 0.1, 1.0, -0.5, 0.2], f64=True)
+    x = torch.randn(50, 3, device="cuda", dtype=torch.float64)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    ia.Split(b, ia.DirectForm1).lanes(3).block(x, y1)
+    ia.Split(b, ia.DirectForm2Transposed).lanes(3).block(x, y2)
+    assert torch.allclose(y1, y2, atol=1e-12)
+    xi = torch.zeros(10, 1, device="cuda")
+    xi[0] = 1.0
+    yi = torch.empty_like(xi)
+    ia.FirSym("EvenSymmetric", [0.25, 0.5]).lanes(1).block(xi, yi)
+    assert yi.flatten().tolist()[:5] == [0.25, 0.5, 0.5, 0.25, 0.0]  # taps mirror around the window centre
