@@ -198,7 +198,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "stream_frame_major<Chain<Df1I32,1>>" if layout == 0 else "stream_lane_major<Chain<Df1I32,1>>",
+                "kernel": "stream_frame_major_lds<Chain<Df1I32<false>,1>>" if layout == 0 else "stream_lane_major<Chain<Df1I32<false>,1>>",
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": alg_bytes,
             },
         }

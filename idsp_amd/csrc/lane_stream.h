@@ -40,6 +40,7 @@
 //   every SIMD a wave; `lanes` then counts virtual lanes.
 #pragma once
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -63,6 +64,28 @@ __device__ __forceinline__ typename P::Out step1(P &p, const typename P::Params 
         return p.step(prm, v, p.pre(prm));
     else
         return p.step(prm, v);
+}
+
+// words <-> sample helpers (1- or 2-word element types)
+template <class T>
+__device__ __forceinline__ T words_to(const uint32_t *w)
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, w[0]);
+    } else {
+        const uint64_t u = uint64_t(w[0]) | (uint64_t(w[1]) << 32);
+        return __builtin_bit_cast(T, u);
+    }
+}
+template <class T>
+__device__ __forceinline__ void to_words(const T &v, uint32_t *w)
+{
+    if constexpr (sizeof(T) == 4) {
+        w[0] = __builtin_bit_cast(uint32_t, v);
+    } else {
+        const uint64_t u = __builtin_bit_cast(uint64_t, v);
+        w[0] = uint32_t(u), w[1] = uint32_t(u >> 32);
+    }
 }
 
 constexpr int kWave = 64;
@@ -166,32 +189,154 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
     p.store(prm, st, lanes, lane);
 }
 
+// ------------------------------------------------- FRAME_MAJOR through LDS (DMA)
+// At <= 2 waves per SIMD the register-window kernel above is limited by what a
+// 4-byte-per-lane access stream can pull from HBM (~5.3-5.5 TB/s measured at 65536
+// lanes).  This variant moves the same rows with 16-byte-per-lane accesses while
+// keeping one lane per thread (all four SIMDs of a CU compute): a 256-thread
+// block owns 256 lanes (1 KiB per frame row); its waves pull whole rows straight
+// into an LDS ring with `global_load_lds_dwordx4` (no VGPR staging, NB tiles of T
+// rows in flight), every thread then walks its own column with conflict-free
+// ds_read_b32, and results leave through a double-buffered LDS tile as
+// row-contiguous dwordx4 stores.  +10 % at C2 (6.07 vs 5.52 TB/s, tools/exp_lds.hip).
+//
+// The DMA loads are issued from inline asm (the compiler neither counts nor
+// drains them), so their completion is tracked by hand: vmcnt is in-order, and
+// in steady state exactly kYoung younger operations (this wave's later DMA rows
+// and its dwordx4 stores) are allowed to remain outstanding when tile i is
+// needed; start-up, drain and ragged tiles simply wait for everything.
+constexpr int kLdsT = 8;    // frames per tile
+constexpr int kLdsNB = 8;   // input tiles in the ring (64 KiB)
+
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
+{
+    // LDS destination = wave-uniform byte address (M0) + lane * 16
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <class P>
+__global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const size_t lanes, const size_t frames)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4, "LDS path: one 4-byte input per lane and frame");
+    constexpr int T = kLdsT, NB = kLdsNB, OW = sizeof(Out) / 4, B = BatchOf<P>::value;
+    constexpr int RPW = T / 4;  // rows per wave and tile
+    constexpr int kYoung = RPW * OW + (NB - 1) * (RPW + RPW * OW);
+    static_assert(kYoung <= 63 && T % 4 == 0 && T % B == 0, "vmcnt range / tile shape");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *tin = smem;                              // [NB][T][256]
+    uint32_t *tout = smem + NB * T * kFmBlock;         // [2][T][256 * OW]
+    uint32_t *ptab = tout + 2 * T * kFmBlock * OW;     // [P::LDS_WORDS]
+    const int tid = threadIdx.x, lid = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t lane0 = size_t(blockIdx.x) * kFmBlock;
+    const size_t lane = lane0 + tid;  // lanes % 256 == 0 (launcher)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem;
+
+    P p;
+    if constexpr (P::LDS_WORDS > 0) {
+        P::fill_shared(ptab, tid, kFmBlock);  // published by the first tile barrier
+        p.set_shared(ptab);
+    }
+    p.load(prm, st, lanes, lane);
+
+    const size_t ntiles = (frames + T - 1) / T;
+    auto rows_of = [&](size_t tile) { return int(frames - tile * T < size_t(T) ? frames - tile * T : size_t(T)); };
+    auto issue = [&](size_t tile, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const int slot = int(tile % NB), nr = FULL ? T : rows_of(tile);
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int r = wave + 4 * j;
+            if (FULL || r < nr) glds16(x + (tile * T + r) * lanes + lane0 + lid * 4, lds_base + uint32_t((slot * T + r) * kFmBlock * 4));
+        }
+    };
+    auto store = [&](size_t tile, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const uint32_t *o = tout + (tile & 1) * T * kFmBlock * OW;
+        const int nr = FULL ? T : rows_of(tile);
+        uint32_t *yw = reinterpret_cast<uint32_t *>(y);
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int r = wave + 4 * j;
+            if (FULL || r < nr) {
+#pragma unroll
+                for (int h = 0; h < OW; h++) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(o + (r * OW + h) * kFmBlock + lid * 4);
+                    *reinterpret_cast<u32x4 *>(yw + ((tile * T + r) * lanes + lane0) * OW + h * kFmBlock + lid * 4) = v;
+                }
+            }
+        }
+    };
+    auto compute = [&](size_t tile, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const uint32_t *in = tin + (tile % NB) * T * kFmBlock;
+        uint32_t *o = tout + (tile & 1) * T * kFmBlock * OW;
+        const int nr = FULL ? T : rows_of(tile);
+#pragma unroll
+        for (int r0 = 0; r0 < T; r0 += B) {
+            if (!FULL && r0 >= nr) break;
+            if constexpr (B > 1) {
+                typename P::Pre pre[B];
+#pragma unroll
+                for (int b = 0; b < B; b++)
+                    if (FULL || r0 + b < nr) pre[b] = p.pre(prm);
+#pragma unroll
+                for (int b = 0; b < B; b++) {
+                    const int r = r0 + b;
+                    if (FULL || r < nr) to_words<Out>(p.step(prm, __builtin_bit_cast(In, in[r * kFmBlock + tid]), pre[b]), o + (r * kFmBlock + tid) * OW);
+                }
+            } else {
+                to_words<Out>(p.step(prm, __builtin_bit_cast(In, in[r0 * kFmBlock + tid])), o + (r0 * kFmBlock + tid) * OW);
+            }
+        }
+    };
+
+    using Full = std::true_type;
+    using Ragged = std::false_type;
+    for (size_t t = 0; t < size_t(NB) && t < ntiles; t++) issue(t, Ragged{});
+    size_t i = 0;
+    auto slow_iter = [&]() {  // start-up, drain and ragged tiles: wait for everything
+        wait_vmcnt<0>();
+        lds_barrier();
+        compute(i, Ragged{});
+        lds_barrier();
+        if (i + NB < ntiles) issue(i + NB, Ragged{});
+        store(i, Ragged{});
+    };
+    for (; i < ntiles && i < size_t(NB); i++) slow_iter();
+    // steady state: all tiles involved are full, and every wave has issued exactly RPW loads
+    // and RPW*OW stores per past tile, so kYoung younger operations may stay in flight
+    for (; i + NB + 1 < ntiles; i++) {
+        wait_vmcnt<kYoung>();
+        lds_barrier();  // all four waves' rows of tile i have landed
+        compute(i, Full{});
+        lds_barrier();  // out tile complete; ring slot i % NB is free again
+        issue(i + NB, Full{});
+        store(i, Full{});
+    }
+    for (; i < ntiles; i++) slow_iter();
+    p.store(prm, st, lanes, lane);
+}
+
 // ----------------------------------------------------------------- LANE_MAJOR
 // One wave per workgroup; tiles are wave-private, so the syncs below only
 // order this wave's own LDS traffic (lds_wave_sync: no vmcnt drain, the next
 // tile's global loads stay in flight).
-// words <-> sample helpers (1- or 2-word element types)
-template <class T>
-__device__ __forceinline__ T words_to(const uint32_t *w)
-{
-    if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, w[0]);
-    } else {
-        const uint64_t u = uint64_t(w[0]) | (uint64_t(w[1]) << 32);
-        return __builtin_bit_cast(T, u);
-    }
-}
-template <class T>
-__device__ __forceinline__ void to_words(const T &v, uint32_t *w)
-{
-    if constexpr (sizeof(T) == 4) {
-        w[0] = __builtin_bit_cast(uint32_t, v);
-    } else {
-        const uint64_t u = __builtin_bit_cast(uint64_t, v);
-        w[0] = uint32_t(u), w[1] = uint32_t(u >> 32);
-    }
-}
-
 template <class P>
 __global__ __launch_bounds__(kWave) void stream_lane_major(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
@@ -290,8 +435,27 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
         hipLaunchKernelGGL((stream_lane_major<P>), dim3(grid), dim3(kWave), 0, s, prm, st, x, y, lanes, frames);
     } else {
-        const unsigned grid = unsigned((lanes + kFmBlock - 1) / kFmBlock);
         const size_t waves = (lanes + kWave - 1) / kWave;
+        if constexpr (P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4) {
+            // cheap per-sample arithmetic (the extra LDS hop and the two barriers per tile cost issue
+            // slots), <= 2 waves per SIMD, whole 256-lane blocks, 16-byte aligned rows: LDS-DMA path
+            if (P::COST <= 60 && waves <= 2048 && lanes % kFmBlock == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                reinterpret_cast<uintptr_t>(y) % 16 == 0 && !getenv("IDSP_NO_LDS_PATH")) {
+                constexpr size_t ow = sizeof(typename P::Out) / 4;
+                constexpr size_t bytes = (size_t(kLdsNB) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
+                static bool attr_done = false;  // per instantiation
+                if (!attr_done) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_lds<P>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+                    if (e != hipSuccess) return fail(IDSP_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                    attr_done = true;
+                }
+                hipLaunchKernelGGL((stream_frame_major_lds<P>), dim3(unsigned(lanes / kFmBlock)), dim3(kFmBlock), bytes, s,
+                                   prm, st, x, y, lanes, frames);
+                return launch_status();
+            }
+        }
+        const unsigned grid = unsigned((lanes + kFmBlock - 1) / kFmBlock);
         if (waves <= 2048)
             hipLaunchKernelGGL((stream_frame_major<P, 24>), dim3(grid), dim3(kFmBlock), 0, s, prm, st, x, y, lanes, frames);
         else
