@@ -175,6 +175,17 @@ def main():
     alg_bytes = samples_step * BYTES_PER_SAMPLE + 2 * STATE_WORDS * 4 * lanes
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+    # (profiles/bench_c2_traffic.json; FETCH_SIZE x2 gfx950 correction, WRITE_SIZE as is)
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "bench_c2_traffic.json")) as f:
+            tj = json.load(f)
+        if layout == _abi.FRAME_MAJOR:
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "i32_df1_biquad_64k_lanes_throughput",
@@ -197,7 +208,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "stream_frame_major_lds<Chain<Df1I32<false>,1>>" if layout == 0 else "stream_lane_major<Chain<Df1I32<false>,1>>",
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": alg_bytes,
             },
