@@ -210,9 +210,10 @@ constexpr int kLdsNB = 8;   // input tiles in the ring (64 KiB)
 
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {
-    // LDS destination = wave-uniform byte address (M0) + lane * 16
+    // LDS destination = wave-uniform byte address (M0) + lane * 16; `nt`: streamed once, do not
+    // keep it in L2/MALL (+5 % with nontemporal loads and stores, tools/exp_lds.hip)
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(o + (r * OW + h) * kFmBlock + lid * 4);
-                    *reinterpret_cast<u32x4 *>(yw + ((tile * T + r) * lanes + lane0) * OW + h * kFmBlock + lid * 4) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(yw + ((tile * T + r) * lanes + lane0) * OW + h * kFmBlock + lid * 4));
                 }
             }
         }

@@ -62,13 +62,20 @@ __global__ __launch_bounds__(256) void k_ref(const Sec c, const int32_t *x, int3
 }
 
 // 16-byte-per-lane LDS-DMA load: LDS destination = wave-uniform byte address + lane*16
+template <bool NT>
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
 }
 
 template <int N>
@@ -79,7 +86,7 @@ __device__ __forceinline__ void wait_vm()
 __device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // T frames per tile, NB input tiles in the ring; 256 lanes per block
-template <int T, int NB>
+template <int T, int NB, bool LNT = false, bool SNT = false>
 __global__ __launch_bounds__(256) void k_lds(const Sec c, const int32_t *x, int32_t *y, size_t lanes, size_t frames)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void k_lds(const Sec c, const int32_t *x, int3
         for (int j = 0; j < RPW; j++) {
             const int r = wave + 4 * j;
             const int32_t *g = x + (tile * T + r) * lanes + lane0 + lid * 4;
-            glds16(g, lds_base + uint32_t(((slot * T + r) * 256) * 4));
+            glds16<LNT>(g, lds_base + uint32_t(((slot * T + r) * 256) * 4));
         }
     };
     auto store = [&](size_t tile) {
@@ -107,7 +114,10 @@ __global__ __launch_bounds__(256) void k_lds(const Sec c, const int32_t *x, int3
         for (int j = 0; j < RPW; j++) {
             const int r = wave + 4 * j;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(o + r * 256 + lid * 4);
-            *reinterpret_cast<u32x4 *>(y + (tile * T + r) * lanes + lane0 + lid * 4) = v;
+            if constexpr (SNT)
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(y + (tile * T + r) * lanes + lane0 + lid * 4));
+            else
+                *reinterpret_cast<u32x4 *>(y + (tile * T + r) * lanes + lane0 + lid * 4) = v;
         }
     };
     int32_t s[4] = {};
@@ -157,13 +167,13 @@ float timeit(F launch, int it = 10)
     return best;
 }
 
-template <int T, int NB>
+template <int T, int NB, bool LNT = false, bool SNT = false>
 void run_lds(const char *name, const Sec &c, const int32_t *x, int32_t *y, const int32_t *yref, size_t lanes, size_t frames)
 {
     const size_t bytes = size_t(NB + 2) * T * 256 * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds<T, NB, LNT, SNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
     CK(hipMemset(y, 0xff, lanes * frames * 4));
-    auto launch = [&] { hipLaunchKernelGGL((k_lds<T, NB>), dim3(unsigned(lanes / 256)), dim3(256), bytes, 0, c, x, y, lanes, frames); };
+    auto launch = [&] { hipLaunchKernelGGL((k_lds<T, NB, LNT, SNT>), dim3(unsigned(lanes / 256)), dim3(256), bytes, 0, c, x, y, lanes, frames); };
     launch();
     CK(hipDeviceSynchronize());
     // correctness against the reference kernel's output
@@ -190,17 +200,20 @@ int main()
     for (auto &v : h) v = (rand() % (1 << 25)) - (1 << 24);
     for (size_t o = 0; o < n; o += h.size()) CK(hipMemcpy(x + o, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     Sec c{{1055, 2110, 1055, 2052218165, -982680842}, 30};
-    for (size_t lanes : {size_t(65536), size_t(262144)}) {
+    for (size_t lanes : {size_t(65536), size_t(131072)}) {
         const size_t frames = n / lanes;
         auto ref = [&] { hipLaunchKernelGGL((k_ref<16>), dim3(unsigned(lanes / 256)), dim3(256), 0, 0, c, x, yref, lanes, frames); };
         const float ms = timeit(ref);
         printf("%-22s lanes %-8zu min %.4f ms  %.0f GB/s\n", "ref U16", lanes, ms, 8.0 * n / ms / 1e6);
-        run_lds<16, 4>("lds T16 NB4", c, x, y, yref, lanes, frames);
-        run_lds<16, 6>("lds T16 NB6", c, x, y, yref, lanes, frames);
-        run_lds<8, 4>("lds T8 NB4", c, x, y, yref, lanes, frames);
-        run_lds<8, 8>("lds T8 NB8", c, x, y, yref, lanes, frames);
-        run_lds<32, 3>("lds T32 NB3", c, x, y, yref, lanes, frames);
-        run_lds<4, 8>("lds T4 NB8", c, x, y, yref, lanes, frames);
+        for (int rep = 0; rep < 2; rep++) {
+            run_lds<8, 8>("lds T8 NB8", c, x, y, yref, lanes, frames);
+            run_lds<8, 8, true, false>("lds T8 NB8 ldNT", c, x, y, yref, lanes, frames);
+            run_lds<8, 8, false, true>("lds T8 NB8 stNT", c, x, y, yref, lanes, frames);
+            run_lds<8, 8, true, true>("lds T8 NB8 ld+stNT", c, x, y, yref, lanes, frames);
+            run_lds<16, 4, true, true>("lds T16 NB4 ld+stNT", c, x, y, yref, lanes, frames);
+            run_lds<8, 12, true, true>("lds T8 NB12 ld+stNT", c, x, y, yref, lanes, frames);
+            run_lds<4, 16, true, true>("lds T4 NB16 ld+stNT", c, x, y, yref, lanes, frames);
+        }
     }
     return 0;
 }
