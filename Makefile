@@ -25,8 +25,15 @@ all: $(LIB) $(ORACLE)
 lib: $(LIB)
 oracle: $(ORACLE)
 
+# The SLP vectoriser packs two independent i64 MACs into <2 x i64> operations, which the back end
+# lowers to generic 64-bit multiplies (v_mul_lo_u32 / v_mad_u64_u32 chains) instead of
+# v_mad_i64_i32 — seen to come and go with unrelated edits.  It stays on only for the half-band
+# FIR files, where it produces the packed f32 adds/multiplies.
+NOSLP_FLAGS := -fno-slp-vectorize
+$(CSRC)/hbf%.o: NOSLP_FLAGS :=
+
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(NOSLP_FLAGS) -c $< -o $@
 
 $(LIB): $(HIP_OBJS)
 	@mkdir -p $(dir $@)

@@ -9,7 +9,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libidsp_hip.so")
+# IDSP_HIP_LIB overrides the path (A/B-testing a differently built engine); still no fallback.
+LIB_PATH = os.environ.get("IDSP_HIP_LIB") or os.path.join(_HERE, "lib", "libidsp_hip.so")
 
 
 class IdspError(RuntimeError):

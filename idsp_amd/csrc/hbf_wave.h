@@ -221,7 +221,9 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
 #pragma unroll
         for (int i = 0; i < kPre; i++) {
             const int q = lid + i * kW;
-            if (q < nf * R / 4) pre[i] = *piece(f0, q);
+            // contiguous 1 KiB per wave instruction in LANE_MAJOR: streamed once -> nontemporal;
+            // FRAME_MAJOR pieces are 64-byte fragments that rely on L2 to merge neighbours
+            if (q < nf * R / 4) pre[i] = LM ? __builtin_nontemporal_load(piece(f0, q)) : *piece(f0, q);
         }
     };
     fetch(0);
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(kW) void hbf_int_wave(uint32_t *st, const float *x,
 #pragma unroll
         for (int i = 0; i < kPre; i++) {
             const int j = lid + i * kW;
-            if (j < nf) pre[i] = LM ? x[lane * frames + f0 + size_t(j)] : x[(f0 + size_t(j)) * lanes + lane];
+            if (j < nf) pre[i] = __builtin_nontemporal_load(LM ? x + lane * frames + f0 + size_t(j) : x + (f0 + size_t(j)) * lanes + lane);
         }
     };
     fetch(0);

@@ -88,6 +88,30 @@ __device__ __forceinline__ void to_words(const T &v, uint32_t *w)
     }
 }
 
+// streamed-once data: nontemporal loads/stores (struct outputs go out as a 2-word vector).
+// NT = false for arithmetic-bound processors, where the longer nontemporal load latency
+// showed up as a slowdown (8-section cascade) instead of a bandwidth gain.
+template <bool NT, class T>
+__device__ __forceinline__ T nt_load(const T *p)
+{
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+template <bool NT, class T>
+__device__ __forceinline__ void nt_store(T *p, const T &v)
+{
+    if constexpr (!NT) {
+        *p = v;
+    } else if constexpr (sizeof(T) == 4) {
+        __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), reinterpret_cast<uint32_t *>(p));
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2 *>(p));
+    }
+}
+
 constexpr int kWave = 64;
 constexpr int kFmBlock = 256;  // 4 waves: one per SIMD of a CU, 1 KiB row segment per block
 
@@ -111,6 +135,11 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
     if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
     p.load(prm, st, lanes, lane);
 
+#ifdef IDSP_NO_NT
+    constexpr bool kNT = false;
+#else
+    constexpr bool kNT = P::COST <= 220;
+#endif
     const size_t xl = lanes / P::IN_DIV;  // input row pitch (IN_DIV virtual lanes share an input lane)
     const In *xp = x + lane / P::IN_DIV;
     Out *yp = y + lane;
@@ -124,7 +153,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
         In ring[U];
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (size_t(u) < frames) ring[u] = xp[size_t(u) * xl];
+            if (size_t(u) < frames) ring[u] = nt_load<kNT>(xp + size_t(u) * xl);
         size_t f = 0;
         for (; f + 2 * U <= frames; f += U) {
             const In *xn = xp + (f + U) * xl;
@@ -141,14 +170,14 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
                     for (int b = 0; b < B; b++) {
                         const int u = u0 + b;
                         const In v = ring[u];
-                        ring[u] = xn[size_t(u) * xl];
-                        yn[size_t(u) * lanes] = p.step(prm, v, pre[b]);
+                        ring[u] = nt_load<kNT>(xn + size_t(u) * xl);
+                        nt_store<kNT>(yn + size_t(u) * lanes, p.step(prm, v, pre[b]));
                     }
                 } else {
                     const int u = u0;
                     const In v = ring[u];
-                    ring[u] = xn[size_t(u) * xl];
-                    yn[size_t(u) * lanes] = p.step(prm, v);
+                    ring[u] = nt_load<kNT>(xn + size_t(u) * xl);
+                    nt_store<kNT>(yn + size_t(u) * lanes, p.step(prm, v));
                 }
             }
         }
@@ -158,15 +187,15 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
             const size_t fr = f + u;
             if (fr < frames) {
                 const In v = ring[u];
-                if (fr + U < frames) ring[u] = xp[(fr + U) * xl];
-                yp[fr * lanes] = step1(p, prm, v);
+                if (fr + U < frames) ring[u] = nt_load<kNT>(xp + (fr + U) * xl);
+                nt_store<kNT>(yp + fr * lanes, step1(p, prm, v));
             }
         }
         f += U;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t fr = f + u;
-            if (fr < frames) yp[fr * lanes] = step1(p, prm, ring[u]);
+            if (fr < frames) nt_store<kNT>(yp + fr * lanes, step1(p, prm, ring[u]));
         }
     } else {
         constexpr int B = BatchOf<P>::value;
@@ -177,12 +206,12 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
 #pragma unroll
                 for (int b = 0; b < B; b++) pre[b] = p.pre(prm);
 #pragma unroll
-                for (int b = 0; b < B; b++) yp[size_t(b) * lanes] = p.step(prm, In{}, pre[b]);
+                for (int b = 0; b < B; b++) nt_store<kNT>(yp + size_t(b) * lanes, p.step(prm, In{}, pre[b]));
                 yp += size_t(B) * lanes;
             }
         }
         for (; f < frames; f++) {
-            *yp = step1(p, prm, In{});
+            nt_store<kNT>(yp, step1(p, prm, In{}));
             yp += lanes;
         }
     }
