@@ -1,8 +1,9 @@
 """ctypes view of the C ABI declared in ``include/idsp_hip.h``.
 
 The structures and prototypes below are shared by the product library
-(``libidsp_hip.so``, symbols ``idsp_*``) and — for the tests only — by its CPU
-oracle twin (``idsp_ref_*``, host pointers, no ``stream`` argument).  Nothing
+(``libidsp_hip.so``, symbols ``idsp_*``); ``bind()`` takes the symbol prefix as an
+argument so that the test suite can attach the same prototypes to its checker
+library (host pointers, no ``stream`` argument).  Nothing
 in here computes anything.
 """
 from __future__ import annotations
@@ -68,7 +69,7 @@ _SZ = C.c_size_t
 _I = C.c_int
 
 # name -> (restype, argtypes) for the processing entry points; `stream` (the
-# last void*) is dropped for the oracle twins.
+# last void*) is dropped when binding the checker library.
 _STREAM_SIG = [_P, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]  # cfg, n, state, x, y, lanes, frames, layout, stream
 _CFG_SIG = [_P, _P, _P, _P, _SZ, _SZ, _I, _P]          # cfg, state, x, y, lanes, frames, layout, stream
 

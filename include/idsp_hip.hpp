@@ -203,6 +203,30 @@ struct Biquad<float> {
     }
 };
 
+template <>
+struct Biquad<double> {
+    using Sample = double;
+    std::array<double, 5> ba{};
+    static Biquad from_sos(const std::array<double, 6> &sos)
+    {
+        idsp_biquad_f64 q;
+        check(idsp_biquad_f64_from_sos(sos.data(), &q));
+        Biquad b;
+        std::memcpy(b.ba.data(), q.ba, sizeof(q.ba));
+        return b;
+    }
+    static Biquad proportional(double k) { return Biquad{{k, 0, 0, 0, 0}}; }
+    static Biquad identity() { return proportional(1.0); }
+    static Biquad hold() { return Biquad{{0, 0, 0, 1.0, 0}}; }
+    double forward_gain() const { return ba[0] + ba[1] + ba[2]; }
+    idsp_biquad_f64 abi() const
+    {
+        idsp_biquad_f64 q;
+        std::memcpy(q.ba, ba.data(), sizeof(q.ba));
+        return q;
+    }
+};
+
 /// `BiquadClamp<C, T>` (biquad.rs:121-171); defaults u = 0, min = T::MIN, max = T::MAX
 /// (+-inf for floats, src/num.rs:33-52).
 template <class C>
@@ -219,6 +243,7 @@ struct BiquadClamp {
 };
 
 // state kinds (tags): words per lane and section
+// words are per 32-bit value; f64 states take twice as many (Lanes multiplies by sizeof(Sample)/4)
 struct DirectForm1 { static constexpr int words = 4; };            // biquad.rs:319
 struct DirectForm2Transposed { static constexpr int words = 2; };  // biquad.rs:407
 struct DirectForm1Wide { static constexpr int words = 6; };        // biquad.rs:445-454
@@ -229,6 +254,8 @@ using StreamI32 = int (*)(const idsp_biquad_i32 *, size_t, void *, const int32_t
 using StreamClampI32 = int (*)(const idsp_biquad_clamp_i32 *, size_t, void *, const int32_t *, int32_t *, size_t, size_t, int, void *);
 using StreamF32 = int (*)(const idsp_biquad_f32 *, size_t, void *, const float *, float *, size_t, size_t, int, void *);
 using StreamClampF32 = int (*)(const idsp_biquad_clamp_f32 *, size_t, void *, const float *, float *, size_t, size_t, int, void *);
+using StreamF64 = int (*)(const idsp_biquad_f64 *, size_t, void *, const double *, double *, size_t, size_t, int, void *);
+using StreamClampF64 = int (*)(const idsp_biquad_clamp_f64 *, size_t, void *, const double *, double *, size_t, size_t, int, void *);
 
 // (configuration, state) -> C entry point; a missing specialisation is the reference's
 // "trait not implemented" compile error.
@@ -245,6 +272,19 @@ template <> struct Entry<Biquad<float>, DirectForm2Transposed> { static constexp
 template <> struct Entry<BiquadClamp<float>, DirectForm1> { static constexpr StreamClampF32 fn = idsp_biquad_f32_df1_clamp; };
 template <> struct Entry<BiquadClamp<float>, DirectForm2Transposed> { static constexpr StreamClampF32 fn = idsp_biquad_f32_df2t_clamp; };
 
+template <> struct Entry<Biquad<double>, DirectForm1> { static constexpr StreamF64 fn = idsp_biquad_f64_df1; };
+template <> struct Entry<Biquad<double>, DirectForm2Transposed> { static constexpr StreamF64 fn = idsp_biquad_f64_df2t; };
+template <> struct Entry<BiquadClamp<double>, DirectForm1> { static constexpr StreamClampF64 fn = idsp_biquad_f64_df1_clamp; };
+template <> struct Entry<BiquadClamp<double>, DirectForm2Transposed> { static constexpr StreamClampF64 fn = idsp_biquad_f64_df2t_clamp; };
+
+inline idsp_biquad_f64 to_abi(const Biquad<double> &b) { return b.abi(); }
+inline idsp_biquad_clamp_f64 to_abi(const BiquadClamp<double> &c)
+{
+    idsp_biquad_clamp_f64 q;
+    std::memcpy(q.ba, c.coeff.ba.data(), sizeof(q.ba));
+    q.u = c.u, q.min = c.min, q.max = c.max;
+    return q;
+}
 template <int F> idsp_biquad_i32 to_abi(const Biquad<Q32<F>> &b) { return b.abi(); }
 inline idsp_biquad_f32 to_abi(const Biquad<float> &b) { return b.abi(); }
 template <int F>
@@ -273,7 +313,8 @@ public:
     using Abi = decltype(detail::to_abi(std::declval<Cfg>()));
 
     Lanes(const std::vector<Cfg> &sections, size_t lanes, void *stream = nullptr)
-        : lanes_(lanes), stream_(stream), state_(size_t(S::words) * (sections.empty() ? 1 : sections.size()) * lanes)
+        : lanes_(lanes), stream_(stream),
+          state_(size_t(S::words) * (sizeof(Sample) / 4) * (sections.empty() ? 1 : sections.size()) * lanes)
     {
         for (const auto &c : sections) abi_.push_back(detail::to_abi(c));
     }
@@ -337,6 +378,33 @@ SplitT<Cfg, S> Split(const std::vector<Cfg> &sections, S)
 {
     return SplitT<Cfg, S>{sections};
 }
+
+/// Same-rate linear-phase FIR `type_fir!` (src/hbf.rs:70-138): OddSymmetric / EvenSymmetric /
+/// OddAntiSymmetric / EvenAntiSymmetric `<[f32; M]>` as `SplitProcess<f32, f32, [f32; N]>`.
+class FirSym {
+public:
+    FirSym(idsp_fir_kind kind, const std::vector<float> &taps, size_t lanes, void *stream = nullptr)
+        : lanes_(lanes), stream_(stream)
+    {
+        require(!taps.empty() && taps.size() <= IDSP_HBF_MAX_TAPS, "1..32 taps");
+        cfg_.kind = kind, cfg_.m = int32_t(taps.size());
+        for (size_t k = 0; k < taps.size(); k++) cfg_.taps[k] = taps[k];
+        state_ = DeviceBuffer<uint32_t>(idsp_fir_sym_state_words(&cfg_) * lanes);
+    }
+    DeviceBuffer<uint32_t> &state() { return state_; }
+    template <class Layout>
+    void process_view(View<float, Layout> x, ViewMut<float, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        check(idsp_fir_sym_f32_process(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
+
+private:
+    idsp_fir_sym_f32 cfg_{};
+    size_t lanes_;
+    void *stream_;
+    DeviceBuffer<uint32_t> state_;
+};
 
 // ----------------------------------------------------------------- half-band
 enum class HbfTaps { Taps140 = 0 /* HBF_TAPS, hbf.rs:308-349 */, Taps98 = 1 /* HBF_TAPS_98, hbf.rs:258-292 */ };

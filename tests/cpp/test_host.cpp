@@ -150,6 +150,19 @@ int main()
         si /= (n - 6144) * amp, sq /= (n - 6144) * amp;
         EXPECT(std::fabs(si - 0.25 * std::cos(phi)) < 3e-3 && std::fabs(sq - 0.25 * std::sin(phi)) < 3e-3);
     }
+    // `Biquad<f64>` DF1 vs DF2T (shape of src/iir/biquad.rs:672-682) and a same-rate EvenSymmetric FIR
+    {
+        auto b = Biquad<double>::from_sos({0.7, -0.4, 0.1, 1.0, -0.2, 0.05});
+        DeviceBuffer<double> x(std::vector<double>{-1.0, 0.25, 0.75, -0.5, 0.125, 0.0, 0.5, -0.25}), y1(8), y2(8);
+        Split(b, DirectForm1{}).lanes(1).block(x, y1);
+        Split(b, DirectForm2Transposed{}).lanes(1).block(x, y2);
+        auto a = y1.to_host(), c = y2.to_host();
+        for (int i = 0; i < 8; i++) EXPECT(std::fabs(a[i] - c[i]) < 1e-12);
+        FirSym fir(IDSP_FIR_EVEN_SYMMETRIC, {0.25f, 0.5f}, 1);
+        DeviceBuffer<float> xi(std::vector<float>{1, 0, 0, 0, 0, 0}), yi(6);
+        fir.process_view(View<float, LaneMajor>::from_flat(xi, 1), ViewMut<float, LaneMajor>::from_flat(yi, 1));
+        EXPECT((yi.to_host() == std::vector<float>{0.25f, 0.5f, 0.5f, 0.25f, 0.0f, 0.0f}));
+    }
     // contract violations are reported as errors, never aborts
     {
         bool threw = false;

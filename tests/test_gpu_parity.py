@@ -426,3 +426,36 @@ def test_lowpass_and_lockin_parity(bes, order, cascade, layout):
             _, yo = ob.cfgcall("lockin_i32_process", cfg, so, x, (lanes * frames * 2,), np.int32, lanes, frames, layout)
             rc, yg = gb.cfgcall("lockin_i32_process", cfg, sg, x, (lanes * frames * 2,), np.int32, lanes, frames, layout)
             assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg)
+
+
+def test_concurrent_streams_distinct_states(bes):
+    """Thread-safety contract of the ABI: calls on different streams with distinct state buffers
+    are independent (the reference's `&self` config / `&mut S` state split, process.rs:70-80)."""
+    import torch
+
+    ob, _ = bes
+    e = H.engine()
+    rng = np.random.default_rng(99)
+    lanes, frames = 4096, 700
+    cfg = H.biquad_i32(random_i32_sections(rng, 2, False))
+    xs = [adversarial_i32(rng, lanes * frames) for _ in range(4)]
+    want = []
+    for x in xs:
+        so = np.zeros((8, lanes), np.uint32)
+        _, y = ob.stream("biquad_i32_df1", cfg, 2, so, x, lanes, frames, FM)
+        want.append((y, so))
+    streams = [torch.cuda.Stream() for _ in xs]
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    yd = [torch.empty_like(t) for t in xd]
+    sd = [torch.zeros((8, lanes), dtype=torch.int32, device="cuda") for _ in xs]
+    torch.cuda.synchronize()
+    for rep in range(3):  # interleave launches over the streams, 3 chunks each
+        a, b = rep * 233, min(frames, (rep + 1) * 233 + (1 if rep == 2 else 0))
+        b = frames if rep == 2 else b
+        for s, x, y, st in zip(streams, xd, yd, sd):
+            xv, yv = x.view(frames, lanes)[a:b], y.view(frames, lanes)[a:b]
+            assert e.stream("biquad_i32_df1", cfg, 2, st, xv, yv, lanes, b - a, FM, C.c_void_p(s.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    for (y, so), yg, sg in zip(want, yd, sd):
+        assert np.array_equal(yg.cpu().numpy(), y)
+        assert np.array_equal(sg.cpu().numpy().view(np.uint32), so)
