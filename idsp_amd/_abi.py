@@ -95,6 +95,7 @@ PROCESSING = {
     "hbf_int_f32": _CFG_SIG,
     "fir_sym_f32_process": _CFG_SIG,
     "cossin_i32": [_P, _P, _SZ, _P],
+    "atan2_i32": [_P, _P, _SZ, _P],
     "dds_i32": [_P, _P, _SZ, _SZ, _I, _P],
     "lockin_i32_process": _CFG_SIG,
     "lowpass_i32": _CFG_SIG,

@@ -7,6 +7,7 @@
 // divergent constant-memory fetch.  Everything after the gather is ~40 VALU
 // ops in registers, fused in the lock-in kernel with the mixer and the
 // lowpass cascade so a phase never touches memory.
+#include "atan2_table.h"
 #include "cossin_table.h"
 #include "lane_stream.h"
 
@@ -300,6 +301,68 @@ __global__ __launch_bounds__(256) void cossin_kernel(const int32_t *phase, Cplx 
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) out[i] = cossin_dev(phase[i], lut);
 }
 
+// src/atan2.rs:6-82, all integer.  tab[0..16) = reciprocal bases, tab[16..32) = slopes.
+__device__ __forceinline__ uint32_t mul_q31(uint32_t x, uint32_t y) { return uint32_t((uint64_t(x) * uint64_t(y)) >> 31); }
+
+__device__ __forceinline__ int32_t atan2_dev(int32_t y, int32_t x, const uint32_t *tab)
+{
+    uint32_t k = 0;
+    if (y < 0) {
+        y = y == INT32_MIN ? INT32_MAX : -y;  // saturating_neg
+        k ^= 0xffffffffu;
+    }
+    if (x < 0) {
+        x = x == INT32_MIN ? INT32_MAX : -x;
+        k ^= 0x7fffffffu;
+    }
+    if (y > x) {
+        const int32_t t = y;
+        y = x;
+        x = t;
+        k ^= 0x3fffffffu;
+    }
+    // divi(y, x), y <= x: normalise x to [1, 2) in Q1.31, LUT reciprocal seed + one Newton step
+    uint32_t q = 0;
+    if (x != 0) {
+        const int shift = __builtin_clz(uint32_t(x));
+        const uint32_t yn = uint32_t(y) << shift, xn = uint32_t(x) << shift;
+        constexpr int kFrac = 31 - kAtan2DiviDepth;
+        const uint32_t rem = xn & ((1u << kFrac) - 1u);
+        const uint32_t idx = (xn << 1) >> (1 + kFrac);
+        const uint32_t step = uint32_t((int64_t(int32_t(tab[16 + idx])) * int64_t(rem)) >> kFrac);
+        const uint32_t r0 = tab[idx] + step;
+        q = mul_q31(yn, mul_q31(r0, 0u - mul_q31(xn, r0)));
+    }
+    // atani(q): odd polynomial q * P(q^2 / 4), Horner in Q32<32> from the highest coefficient
+    const int32_t x2 = int32_t((int64_t(q) * int64_t(q)) >> 32);
+    int32_t r = 0;
+    constexpr int32_t kAtani[6] = {0x0517c2cd, -0x06c6496b, 0x0fbdb021, -0x25b32e0a, 0x43b34c81, -0x3bc823dd};
+#pragma unroll
+    for (int i = 5; i >= 0; i--) r = int32_t(uint32_t(int32_t((int64_t(r) * int64_t(x2)) >> 32)) + uint32_t(kAtani[i]));
+    const uint32_t a = uint32_t((int64_t(r) * int64_t(q)) >> 28);
+    return int32_t(a ^ k);
+}
+
+__device__ const uint32_t d_atan2_table[32] = {
+    kAtan2Base[0], kAtan2Base[1], kAtan2Base[2], kAtan2Base[3], kAtan2Base[4], kAtan2Base[5], kAtan2Base[6], kAtan2Base[7],
+    kAtan2Base[8], kAtan2Base[9], kAtan2Base[10], kAtan2Base[11], kAtan2Base[12], kAtan2Base[13], kAtan2Base[14], kAtan2Base[15],
+    uint32_t(kAtan2Slope[0]), uint32_t(kAtan2Slope[1]), uint32_t(kAtan2Slope[2]), uint32_t(kAtan2Slope[3]),
+    uint32_t(kAtan2Slope[4]), uint32_t(kAtan2Slope[5]), uint32_t(kAtan2Slope[6]), uint32_t(kAtan2Slope[7]),
+    uint32_t(kAtan2Slope[8]), uint32_t(kAtan2Slope[9]), uint32_t(kAtan2Slope[10]), uint32_t(kAtan2Slope[11]),
+    uint32_t(kAtan2Slope[12]), uint32_t(kAtan2Slope[13]), uint32_t(kAtan2Slope[14]), uint32_t(kAtan2Slope[15])};
+
+__global__ __launch_bounds__(256) void atan2_kernel(const Cplx *xy, int32_t *out, size_t n)
+{
+    __shared__ uint32_t tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
+    __syncthreads();
+    const size_t stride = size_t(gridDim.x) * 256;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        const Cplx v = xy[i];  // [x, y] = [re, im]
+        out[i] = atan2_dev(v.im, v.re, tab);
+    }
+}
+
 int lockin_cfg_check(const idsp_lockin_i32 *c)
 {
     if (!c) return fail(IDSP_EINVAL, "cfg is NULL");
@@ -352,6 +415,17 @@ int idsp_cossin_i32(const int32_t *phase, int32_t *out, size_t n, void *stream)
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(cossin_kernel, dim3(unsigned(blocks)), dim3(256), 0, as_stream(stream), phase,
                        reinterpret_cast<Cplx *>(out), n);
+    return launch_status();
+}
+
+int idsp_atan2_i32(const int32_t *xy, int32_t *out, size_t n, void *stream)
+{
+    if (n && (!xy || !out)) return fail(IDSP_EINVAL, "xy or out is NULL");
+    if (n == 0) return IDSP_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(atan2_kernel, dim3(unsigned(blocks)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const Cplx *>(xy), out, n);
     return launch_status();
 }
 

@@ -19,6 +19,7 @@ own:
     HBF_DEC_CASCADE / HbfDec16 ...       (hbf.rs:363-421) HbfDecCascade(stages).lanes(N)
     Lockin<[Lowpass<N>; K]>, Accu        (lockin.rs, accu.rs) Lockin([...]).lanes(N, step=...)
     cossin(phase)                        (cossin.rs:14)  cossin(phases)
+    atan2(y, x) / Complex::arg           (atan2.rs:66)   atan2(xy)
 
 Buffers are torch tensors on the GPU (torch is plumbing: device memory and
 streams); every call goes through the C ABI of ``libidsp_hip.so`` on the
@@ -40,7 +41,7 @@ __all__ = [
     "FrameMajor", "LaneMajor", "View", "ViewMut", "Biquad", "BiquadClamp", "Cascade",
     "DirectForm1", "DirectForm2Transposed", "DirectForm1Wide", "DirectForm1Dither", "DirectForm",
     "Split", "Lanes", "HbfDecCascade", "HbfIntCascade", "FirSym", "HBF_TAPS", "HBF_TAPS_98",
-    "Lowpass", "Lockin", "Accu", "Dds", "cossin", "sos", "sos_clamp_wide", "IdspError",
+    "Lowpass", "Lockin", "Accu", "Dds", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
 ]
 
 FrameMajor = _abi.FRAME_MAJOR  # dsp-process/src/view.rs:10
@@ -568,6 +569,18 @@ def cossin(p: torch.Tensor) -> torch.Tensor:
     _check(p, torch.int32, "p")
     out = torch.empty((p.numel(), 2), dtype=torch.int32, device=p.device)
     call("cossin_i32", C.c_void_p(p.data_ptr()), C.c_void_p(out.data_ptr()), p.numel(), _stream_ptr(p))
+    return out
+
+
+def atan2(xy: torch.Tensor) -> torch.Tensor:
+    """`atan2(xy: i32[N, 2]) -> i32[N]` — the pyo3 function of src/py.rs:30-47; rows
+    are `[x, y]`, the result is the angle in turns (2^31 = pi).  On a `[re, im]` tensor
+    this is `Complex<i32>::arg` (src/complex.rs:254-256)."""
+    _check(xy, torch.int32, "xy")
+    if xy.dim() != 2 or xy.shape[1] != 2:
+        raise ValueError("xy must have shape [N, 2]")
+    out = torch.empty(xy.shape[0], dtype=torch.int32, device=xy.device)
+    call("atan2_i32", C.c_void_p(xy.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(), _stream_ptr(xy))
     return out
 
 

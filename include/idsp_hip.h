@@ -326,6 +326,12 @@ int idsp_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const flo
  * = sin — the `cossin(p) -> i32[N,2]` function of src/py.rs:10-28. */
 int idsp_cossin_i32(const int32_t *phase, int32_t *out, size_t n, void *stream);
 
+/* `atan2(y, x)` (src/atan2.rs:66-82) elementwise over rows [x, y] — the
+ * `atan2(xy: i32[N,2]) -> i32[N]` function of src/py.rs:30-47 and `Complex::<i32>::arg`
+ * (src/complex.rs:254-256) for `Complex<i32>` = [re, im] rows such as the lock-in output.
+ * Result: i32::MIN = -pi ... i32::MAX = one count below +pi. */
+int idsp_atan2_i32(const int32_t *xy, int32_t *out, size_t n, void *stream);
+
 /* DDS: per lane `Accu<Wrapping<i32>>` (src/accu.rs:34-41, pre-increment) feeding
  * `Complex::<i32>::from_angle` (src/complex.rs:237-240).  State words per lane:
  * { accu.state, accu.step }.  Output element = Complex<i32> = [re, im] adjacent

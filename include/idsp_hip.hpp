@@ -17,6 +17,7 @@
 //   HBF_DEC_CASCADE + HbfDec2..32 / HBF_INT_CASCADE (hbf.rs)    HbfDecCascade / HbfIntCascade
 //   Lockin<[Lowpass<N>; K]> + Accu      (lockin.rs, accu.rs)    Lockin<N, K>
 //   cossin(phase)                       (cossin.rs:14)          cossin(phases, out)
+//   atan2(y, x) / Complex::arg          (atan2.rs:66)           atan2(xy, out)
 //
 // Misuse that is a `debug_assert!`/panic in the reference throws idsp_hip::Error.
 #pragma once
@@ -448,6 +449,13 @@ inline void cossin(const DeviceBuffer<int32_t> &phase, DeviceBuffer<int32_t> &ou
 {
     require(out.len() == 2 * phase.len(), "out.len() != 2 * phase.len()");
     check(idsp_cossin_i32(phase.data(), out.data(), phase.len(), stream));
+}
+
+/// `atan2(xy: i32[N, 2]) -> i32[N]` (src/py.rs:30-47); on `[re, im]` rows = `Complex<i32>::arg` (src/complex.rs:254-256)
+inline void atan2(const DeviceBuffer<int32_t> &xy, DeviceBuffer<int32_t> &out, void *stream = nullptr)
+{
+    require(xy.len() == 2 * out.len(), "xy.len() != 2 * out.len()");
+    check(idsp_atan2_i32(xy.data(), out.data(), out.len(), stream));
 }
 
 /// `Lockin<[Lowpass<N>; K]>` fed by a per-lane `Accu<Wrapping<i32>>` (src/lockin.rs:30-39).

@@ -842,6 +842,68 @@ int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n)
     return IDSP_OK;
 }
 
+/* ------------------------------------------------------------------ atan2 */
+static uint32_t g_atan2_base[16];
+static int32_t g_atan2_slope[16];
+static pthread_once_t g_atan2_once = PTHREAD_ONCE_INIT;
+
+/* build.rs:43-66 */
+static void atan2_init(void)
+{
+    const double Q31 = (double)((int64_t)1 << 31);
+    for (int i = 0; i < 16; i++) {
+        double x0 = 1.0 + (double)i / 16.0, x1 = 1.0 + (double)(i + 1) / 16.0;
+        g_atan2_base[i] = (uint32_t)round(Q31 / x0);
+        g_atan2_slope[i] = (int32_t)round((1.0 / x1 - 1.0 / x0) * Q31);
+    }
+}
+
+/* src/atan2.rs:6-9 */
+static inline uint32_t mul_q31(uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)x * (uint64_t)y) >> 31); }
+
+/* src/atan2.rs:12-29 */
+static uint32_t atan2_divi(uint32_t y, uint32_t x)
+{
+    if (x == 0) return 0;
+    int shift = __builtin_clz(x);
+    y <<= shift;
+    x <<= shift;
+    const int FRAC_BITS = 31 - 4;
+    uint32_t rem = x & ((1u << FRAC_BITS) - 1u);
+    uint32_t idx = (x << 1) >> (1 + FRAC_BITS);
+    uint32_t step = (uint32_t)(((int64_t)g_atan2_slope[idx] * (int64_t)rem) >> FRAC_BITS);
+    uint32_t r0 = g_atan2_base[idx] + step;
+    return mul_q31(y, mul_q31(r0, 0u - mul_q31(x, r0)));
+}
+
+/* src/atan2.rs:32-49: `(r * x2) + a` on Q32<32>: ((r*x2) >> 32) as i32, wrapping add */
+static uint32_t atan2_atani(uint32_t x)
+{
+    static const int32_t ATANI[6] = {0x0517c2cd, -0x06c6496b, 0x0fbdb021, -0x25b32e0a, 0x43b34c81, -0x3bc823dd};
+    int32_t x2 = (int32_t)(((int64_t)x * (int64_t)x) >> 32);
+    int32_t r = 0;
+    for (int i = 5; i >= 0; i--) r = wadd32((int32_t)(((int64_t)r * (int64_t)x2) >> 32), ATANI[i]);
+    return (uint32_t)(((int64_t)r * (int64_t)x) >> 28);
+}
+
+/* src/atan2.rs:66-82 */
+int32_t idsp_ref_atan2(int32_t y, int32_t x)
+{
+    pthread_once(&g_atan2_once, atan2_init);
+    uint32_t k = 0;
+    if (y < 0) { y = y == INT32_MIN ? INT32_MAX : -y; k ^= UINT32_MAX; }
+    if (x < 0) { x = x == INT32_MIN ? INT32_MAX : -x; k ^= UINT32_MAX >> 1; }
+    if (y > x) { int32_t t = y; y = x; x = t; k ^= UINT32_MAX >> 2; }
+    return (int32_t)(atan2_atani(atan2_divi((uint32_t)y, (uint32_t)x)) ^ k);
+}
+
+int idsp_ref_atan2_i32(const int32_t *xy, int32_t *out, size_t n)
+{
+    if (n && (!xy || !out)) return IDSP_EINVAL;
+    for (size_t i = 0; i < n; i++) out[i] = idsp_ref_atan2(xy[2 * i + 1], xy[2 * i]);
+    return IDSP_OK;
+}
+
 /* src/accu.rs:34-41 (state += step; yield state) -> src/complex.rs:237-240. */
 int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout)
 {

@@ -99,6 +99,8 @@ size_t idsp_ref_fir_sym_state_words(const idsp_fir_sym_f32 *cfg);
 int idsp_ref_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const float *x, float *y,
                                  size_t lanes, size_t frames, int layout);
 
+int32_t idsp_ref_atan2(int32_t y, int32_t x);
+int idsp_ref_atan2_i32(const int32_t *xy, int32_t *out, size_t n);
 int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n);
 int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout);
 size_t idsp_ref_lockin_state_words(const idsp_lockin_i32 *cfg);

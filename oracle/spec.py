@@ -482,6 +482,55 @@ def cossin(phase: int) -> Tuple[int, int]:
 
 
 # ----------------------------------------------------------------------------
+# atan2 (src/atan2.rs, build.rs:43-66)
+# ----------------------------------------------------------------------------
+def atan2_table():
+    q31 = float(1 << 31)
+    out = []
+    for i in range(16):
+        x0, x1 = 1.0 + i / 16.0, 1.0 + (i + 1) / 16.0
+        out.append((int(round_half_away(q31 / x0)) & 0xFFFFFFFF, int(round_half_away((1.0 / x1 - 1.0 / x0) * q31))))
+    return out
+
+
+_ATAN2 = atan2_table()
+_ATANI = (0x0517c2cd, -0x06c6496b, 0x0fbdb021, -0x25b32e0a, 0x43b34c81, -0x3bc823dd)
+
+
+def _mul_q31(x: int, y: int) -> int:
+    return u32((x * y) >> 31)
+
+
+def atan2(y: int, x: int) -> int:
+    """src/atan2.rs:66-82 with divi (:12-29) and atani (:32-49)."""
+    k = 0
+    if y < 0:
+        y = I32_MAX if y == I32_MIN else -y
+        k ^= 0xFFFFFFFF
+    if x < 0:
+        x = I32_MAX if x == I32_MIN else -x
+        k ^= 0x7FFFFFFF
+    if y > x:
+        y, x = x, y
+        k ^= 0x3FFFFFFF
+    if x == 0:
+        q = 0
+    else:
+        shift = 32 - x.bit_length()
+        yn, xn = u32(y << shift), u32(x << shift)
+        rem = xn & ((1 << 27) - 1)
+        idx = u32(xn << 1) >> 28
+        base, slope = _ATAN2[idx]
+        r0 = u32(base + u32((slope * rem) >> 27))
+        q = _mul_q31(yn, _mul_q31(r0, u32(-_mul_q31(xn, r0))))
+    x2 = i32((q * q) >> 32)
+    r = 0
+    for a in reversed(_ATANI):
+        r = i32(i32((r * x2) >> 32) + a)
+    return i32(u32((r * q) >> 28) ^ k)
+
+
+# ----------------------------------------------------------------------------
 # Accu, Lowpass, Lockin
 # ----------------------------------------------------------------------------
 class Accu:

@@ -36,6 +36,12 @@ class OracleBackend:
         rc = self.o.fn["cossin_i32"](H._ptr(phases), H._ptr(out), phases.size)
         return rc, out
 
+    def atan2(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        out = np.empty(xy.size // 2, dtype=np.int32)
+        rc = self.o.fn["atan2_i32"](H._ptr(xy), H._ptr(out), out.size)
+        return rc, out
+
     def dds(self, state, lanes, frames, layout):
         out = np.empty(lanes * frames * 2, dtype=np.int32)
         rc = self.o.fn["dds_i32"](H._ptr(state), H._ptr(out), lanes, frames, layout)
@@ -98,6 +104,14 @@ class GpuBackend:
         rc = self.e.fn["cossin_i32"](H._ptr(ps), H._ptr(out), ps.numel(), None)
         torch.cuda.synchronize()
         return rc, out.cpu().numpy().reshape(-1, 2)
+
+    def atan2(self, xy):
+        torch = self.torch
+        xs = self._up(np.ascontiguousarray(xy, dtype=np.int32))
+        out = torch.empty(xs.numel() // 2, dtype=torch.int32, device=self.dev)
+        rc = self.e.fn["atan2_i32"](H._ptr(xs), H._ptr(out), out.numel(), None)
+        torch.cuda.synchronize()
+        return rc, out.cpu().numpy()
 
     def dds(self, state, lanes, frames, layout):
         torch = self.torch

@@ -241,6 +241,44 @@ def case_cossin_spur(be):
     assert int(np.argmax(rest)) in (lo, hi)
 
 
+def case_atan2_zero_axis(be):
+    e = KAT["atan2_zero_axis"]
+    xy = np.array([[c["x"], c["y"]] for c in e["cases"]], np.int32)
+    rc, out = be.atan2(xy)
+    assert rc == 0 and out.tolist() == [c["want"] for c in e["cases"]]
+
+
+def case_atan2_absolute_error(be):
+    """src/atan2.rs:117-153: 323 x 323 grid against f64 atan2."""
+    e = KAT["atan2_absolute_error"]
+    n, scale = e["n"], float(1 << 31)
+    vals = [int(scale * (-1.0 + 2.0 * i / n)) for i in range(n)]
+    assert -(1 << 31) in vals
+    vals += [(1 << 31) - 1, 0]
+    v = np.array(vals, np.int64)
+    xs, ys = np.repeat(v, v.size), np.tile(v, v.size)
+    rc, out = be.atan2(np.stack([xs, ys], 1).astype(np.int32))
+    assert rc == 0
+    want = np.arctan2(ys.astype(np.float64), xs.astype(np.float64))
+    err = np.abs(out.astype(np.float64) * (math.pi / scale) - want)
+    assert err.max() < e["abs_err"]
+    assert math.sqrt(float((err * err).sum())) / v.size < e["rms_err"]
+    assert not (err > e["rel_threshold"]).any()  # rel_err stays 0 < 1e-15
+
+
+def case_atan2_small(be):
+    """src/atan2.rs:155-175: small equal inputs and small vectors near the origin."""
+    e = KAT["atan2_small"]
+    scale = math.pi / float(1 << 31)
+    v = np.arange(*e["equal_range"], dtype=np.int32)
+    rc, out = be.atan2(np.stack([v, v], 1))
+    assert rc == 0 and np.abs(out * scale - math.pi / 4).max() < e["abs_err"]
+    pts = np.array([(x, y) for x in range(*e["near_origin_x"]) for y in range(x + 1)], np.int32)
+    rc, out = be.atan2(pts)
+    want = np.arctan2(pts[:, 1].astype(np.float64), pts[:, 0].astype(np.float64))
+    assert rc == 0 and np.abs(out * scale - want).max() < e["abs_err"]
+
+
 def case_accu(be):
     e = KAT["accu"]
     st = np.array([[e["state"]], [e["step"]]], dtype=np.int64).astype(np.uint32)

@@ -127,6 +127,13 @@ int main()
         EXPECT(o[0] == 2147454703 && o[1] == -1898);
         EXPECT(std::abs(o[2]) < (1 << 17) && o[3] > 2147400000);
     }
+    // src/atan2.rs:177-183 (zero axes are exact), rows are [x, y]
+    {
+        DeviceBuffer<int32_t> xy(std::vector<int32_t>{1, 0, 0, 1, INT32_MAX, 0, 0, INT32_MAX}), out(4);
+        atan2(xy, out);
+        auto o = out.to_host();
+        EXPECT(o[0] == 0 && o[1] == 0x3fffffff && o[2] == 0 && o[3] == 0x3fffffff);
+    }
     // Lockin<[Lowpass<2>; 2]> + Accu: a tone at the LO frequency demodulates to DC (examples/ddc_lockin.rs shape)
     {
         const size_t n = 8192, lanes = 2;

@@ -82,3 +82,5 @@ def test_contract_violations_return_einval_without_a_device():
     # zero lanes / zero frames are valid no-ops that never launch
     assert fn["biquad_i32_df1"](C.cast(q, C.c_void_p), 1, one, one, one, 0, 4, 0, None) == 0
     assert fn["cossin_i32"](None, None, 0, None) == 0
+    assert fn["atan2_i32"](None, None, 0, None) == 0
+    assert fn["atan2_i32"](None, one, 1, None) == _abi.IDSP_EINVAL

@@ -87,6 +87,14 @@ def test_cossin_pyfunction_shape():
     assert abs(out[1, 0].item()) < 1 << 17 and out[1, 1].item() > (1 << 31) - (1 << 16)
 
 
+def test_atan2_pyfunction_shape():
+    """src/py.rs:30-47: i32[N, 2] rows [x, y] -> i32[N]; src/atan2.rs:177-183 values."""
+    out = ia.atan2(dev([[1, 0], [0, 1], [-1, 0], [0, -1]], torch.int32))
+    assert out.tolist() == [0, 0x3FFFFFFF, 0x7FFFFFFF, -0x40000000]
+    with pytest.raises(ValueError):
+        ia.atan2(dev([1, 2, 3], torch.int32))
+
+
 def test_sos_pyfunction_matches_oracle():
     """src/py.rs:49-73 `sos(sos, xy)` (Q29, slice composition) on one stream."""
     import ctypes as C

@@ -377,6 +377,22 @@ def test_cossin_parity_all_octants(bes):
     assert rc == 0 and np.array_equal(co, cg)
 
 
+def test_atan2_parity_all_octants(bes):
+    ob, gb = bes
+    rng = np.random.default_rng(4)
+    edge = np.array([0, 1, -1, 2, 3, I32_MAX, I32_MIN, I32_MIN + 1, 1 << 30, -(1 << 30), (1 << 27) - 1, 1 << 27], np.int64)
+    xy = np.concatenate([
+        rng.integers(I32_MIN, I32_MAX, size=(3000001, 2), dtype=np.int64, endpoint=True),
+        rng.integers(-600, 601, size=(200000, 2)),
+        np.stack([np.repeat(edge, edge.size), np.tile(edge, edge.size)], 1),
+    ]).astype(np.int32)
+    _, ao = ob.atan2(xy)
+    rc, ag = gb.atan2(xy)
+    assert rc == 0 and np.array_equal(ao, ag)
+    rc, e = gb.atan2(np.empty((0, 2), np.int32))
+    assert rc == 0 and e.size == 0
+
+
 @pytest.mark.parametrize("layout", [FM, LM])
 def test_dds_parity(bes, layout):
     ob, gb = bes

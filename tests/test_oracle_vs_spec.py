@@ -5,6 +5,7 @@ must agree bit for bit with the independently written Python spec model
 (reference-shaped state objects, `Major`-style chunked cascades) on seeded
 adversarial inputs.  Also cross-checks the pinned components."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -190,6 +191,30 @@ def test_cossin_exhaustive_sample(o):
     assert o.fn["cossin_i32"](H._ptr(ph), H._ptr(out), ph.size) == 0
     for p, (c, s) in zip(ph.tolist(), out.tolist()):
         assert spec.cossin(p) == (c, s)
+
+
+def test_atan2_all_octants_and_edges(o):
+    rng = np.random.default_rng(10)
+    edge = np.array([0, 1, -1, 2, 3, I32_MAX, I32_MIN, I32_MIN + 1, 1 << 30, -(1 << 30), (1 << 27) - 1, 1 << 27], np.int64)
+    xy = np.concatenate([
+        np.stack([rand_i32(rng, 20000), rand_i32(rng, 20000)], 1),
+        rng.integers(-40, 41, size=(4000, 2)),  # tiny vectors: large clz normalisation shifts
+        np.stack([np.repeat(edge, edge.size), np.tile(edge, edge.size)], 1),
+    ]).astype(np.int32)
+    out = np.empty(xy.shape[0], np.int32)
+    assert o.fn["atan2_i32"](H._ptr(xy), H._ptr(out), out.size) == 0
+    for (x, y), a in zip(xy.tolist(), out.tolist()):
+        assert spec.atan2(y, x) == a, (y, x)
+
+
+def test_atan2_table_matches_generated_header():
+    """build.rs:43-66 recomputed here == the constexpr table the HIP kernel compiles in."""
+    import re
+
+    src = open(os.path.join(os.path.dirname(__file__), "..", "idsp_amd", "csrc", "atan2_table.h")).read()
+    base = [int(v) for v in re.findall(r"(\d+)u", src.split("kAtan2Base")[1].split("}")[0])]
+    slope = [int(v) for v in re.findall(r"-?\d+", src.split("kAtan2Slope[16]")[1].split("}")[0])]
+    assert [(b, s) for b, s in zip(base, slope)] == spec.atan2_table()
 
 
 @pytest.mark.parametrize("order,cascade", [(1, 1), (1, 3), (2, 1), (2, 2), (2, 4)])
