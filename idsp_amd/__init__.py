@@ -9,6 +9,7 @@ The product is the C-ABI shared library ``idsp_amd/lib/libidsp_hip.so``
 """
 from .process import *  # noqa: F401,F403
 from .process import __all__ as _process_all
+from . import coefficients  # noqa: F401  (Filter, pid Builder/Pid, BiquadConfig front-end)
 from .sharding import lane_shard  # noqa: F401
 
-__all__ = list(_process_all) + ["lane_shard"]
+__all__ = list(_process_all) + ["lane_shard", "coefficients"]

@@ -64,6 +64,39 @@ class LockinI32(C.Structure):
     _fields_ = [("order", C.c_int32), ("cascade", C.c_int32), ("k", (C.c_int32 * 2) * LOCKIN_MAX_CASCADE)]
 
 
+class Filter(C.Structure):
+    _fields_ = [("frequency", C.c_double), ("gain", C.c_double), ("shelf", C.c_double), ("shape", C.c_double),
+                ("shape_kind", C.c_int32), ("f32", C.c_int32)]
+
+
+class PidBuilder(C.Structure):
+    _fields_ = [("order", C.c_int32), ("f32", C.c_int32), ("gain", C.c_double * 5), ("limit", C.c_double * 5)]
+
+
+class Units(C.Structure):
+    _fields_ = [("t", C.c_double), ("x", C.c_double), ("y", C.c_double)]
+
+
+class Pid(C.Structure):
+    _fields_ = [("builder", PidBuilder), ("setpoint", C.c_double), ("min", C.c_double), ("max", C.c_double)]
+
+
+class BaConfig(C.Structure):
+    _fields_ = [("ba", C.c_double * 6), ("offset", C.c_double), ("min", C.c_double), ("max", C.c_double),
+                ("f32", C.c_int32)]
+
+
+class FilterConfig(C.Structure):
+    _fields_ = [("typ", C.c_int32), ("shape_kind", C.c_int32), ("frequency", C.c_double), ("gain_db", C.c_double),
+                ("shelf_db", C.c_double), ("shape", C.c_double), ("offset", C.c_double), ("min", C.c_double),
+                ("max", C.c_double), ("f32", C.c_int32)]
+
+
+# idsp_status of the builder validation errors (`iir::Error`, src/iir/error.rs:5-16)
+IDSP_ENONFINITE, IDSP_ENONPOSITIVE, IDSP_EOUTOFRANGE, IDSP_EINVERTED, IDSP_ESIGN = -10, -11, -12, -13, -14
+FILTER_TYPES = ("lowpass", "highpass", "bandpass", "allpass", "notch", "peaking", "lowshelf", "highshelf", "iho")
+SHAPE_Q, SHAPE_BANDWIDTH, SHAPE_SLOPE = 0, 1, 2
+
 _P = C.c_void_p
 _SZ = C.c_size_t
 _I = C.c_int
@@ -72,6 +105,9 @@ _I = C.c_int
 # last void*) is dropped when binding the checker library.
 _STREAM_SIG = [_P, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]  # cfg, n, state, x, y, lanes, frames, layout, stream
 _CFG_SIG = [_P, _P, _P, _P, _SZ, _SZ, _I, _P]          # cfg, state, x, y, lanes, frames, layout, stream
+
+_BYLANE_I32_SIG = [_P, _I, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]  # coef, frac, n, state, x, y, lanes, frames, layout, stream
+_BYLANE_F_SIG = [_P, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]        # coef, n, state, x, y, lanes, frames, layout, stream
 
 PROCESSING = {
     "biquad_i32_df1": _STREAM_SIG,
@@ -91,6 +127,20 @@ PROCESSING = {
     "biquad_f64_df2t": _STREAM_SIG,
     "biquad_f64_df2t_clamp": _STREAM_SIG,
     "cascade_f64_df1": _STREAM_SIG,
+    "biquad_i32_df1_bylane": _BYLANE_I32_SIG,
+    "biquad_i32_df1_clamp_bylane": _BYLANE_I32_SIG,
+    "biquad_i32_dither_bylane": _BYLANE_I32_SIG,
+    "biquad_i32_dither_clamp_bylane": _BYLANE_I32_SIG,
+    "biquad_i32_wide_bylane": _BYLANE_I32_SIG,
+    "biquad_i32_wide_clamp_bylane": _BYLANE_I32_SIG,
+    "biquad_f32_df1_bylane": _BYLANE_F_SIG,
+    "biquad_f32_df1_clamp_bylane": _BYLANE_F_SIG,
+    "biquad_f32_df2t_bylane": _BYLANE_F_SIG,
+    "biquad_f32_df2t_clamp_bylane": _BYLANE_F_SIG,
+    "biquad_f64_df1_bylane": _BYLANE_F_SIG,
+    "biquad_f64_df1_clamp_bylane": _BYLANE_F_SIG,
+    "biquad_f64_df2t_bylane": _BYLANE_F_SIG,
+    "biquad_f64_df2t_clamp_bylane": _BYLANE_F_SIG,
     "hbf_dec_f32": _CFG_SIG,
     "hbf_int_f32": _CFG_SIG,
     "fir_sym_f32_process": _CFG_SIG,
@@ -117,6 +167,24 @@ HELPERS = {
     "fir_sym_state_words": (_SZ, [_P]),
 }
 
+_D = C.c_double
+# host-side coefficient front-end (product only; checked against oracle/spec.py)
+FRONTEND = {
+    "filter_build": (_I, [_P, _I, _I, _P]),
+    "pid_build_i32": (_I, [_P, _D, _I, _I, _P]),
+    "pid_build_f32": (_I, [_P, _D, _I, _P]),
+    "pid_build_f64": (_I, [_P, _D, _I, _P]),
+    "pid_build_clamp_i32": (_I, [_P, _P, _I, _I, _P]),
+    "pid_build_clamp_f32": (_I, [_P, _P, _I, _P]),
+    "pid_build_clamp_f64": (_I, [_P, _P, _I, _P]),
+    "config_ba_build_i32": (_I, [_P, _P, _I, _I, _P]),
+    "config_ba_build_f32": (_I, [_P, _P, _I, _P]),
+    "config_ba_build_f64": (_I, [_P, _P, _I, _P]),
+    "config_filter_build_i32": (_I, [_P, _P, _I, _I, _P]),
+    "config_filter_build_f32": (_I, [_P, _P, _I, _P]),
+    "config_filter_build_f64": (_I, [_P, _P, _I, _P]),
+}
+
 # product-only utilities
 UTILS = {
     "version": (_I, []),
@@ -134,7 +202,7 @@ UTILS = {
 
 def exported_names() -> list:
     """Every symbol include/idsp_hip.h declares (without the ``idsp_`` prefix)."""
-    return sorted(list(PROCESSING) + list(HELPERS) + list(UTILS))
+    return sorted(list(PROCESSING) + list(HELPERS) + list(UTILS) + list(FRONTEND))
 
 
 def bind(lib: C.CDLL, prefix: str, *, with_stream: bool, utils: bool):
@@ -151,7 +219,7 @@ def bind(lib: C.CDLL, prefix: str, *, with_stream: bool, utils: bool):
         fn.argtypes = list(args)
         out[name] = fn
     if utils:
-        for name, (res, args) in UTILS.items():
+        for name, (res, args) in list(UTILS.items()) + list(FRONTEND.items()):
             fn = getattr(lib, prefix + name)
             fn.restype = res
             fn.argtypes = list(args)

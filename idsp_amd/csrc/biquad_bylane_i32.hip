@@ -1,0 +1,22 @@
+// biquad_bylane_i32.hip — C-ABI entry points (include/idsp_hip.h) of the per-lane-coefficient i32 biquads
+// (`ByLane<[Biquad<Q32<F>>; N]>`, dsp-process/src/compose.rs:363-390); device code in biquad_sections.h.
+#include "biquad_sections.h"
+
+using namespace idsp;
+using namespace idsp::bq;
+
+#define IDSP_BYLANE_I32(name, sec)                                                                              \
+    int idsp_biquad_i32_##name##_bylane(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, \
+                                        int32_t *y, size_t lanes, size_t frames, int layout, void *stream)      \
+    {                                                                                                           \
+        return entry_bylane<sec>(coef, frac, n, state, x, y, lanes, frames, layout, stream);                    \
+    }
+
+extern "C" {
+IDSP_BYLANE_I32(df1, Df1I32<false>)
+IDSP_BYLANE_I32(df1_clamp, Df1I32<true>)
+IDSP_BYLANE_I32(dither, DitherI32<false>)
+IDSP_BYLANE_I32(dither_clamp, DitherI32<true>)
+IDSP_BYLANE_I32(wide, WideI32<false>)
+IDSP_BYLANE_I32(wide_clamp, WideI32<true>)
+}  // extern "C"

@@ -71,6 +71,7 @@ __device__ __forceinline__ int64_t sum5(const SecI32 &c, int32_t x0, int32_t x1,
 
 template <bool CLAMP>
 struct Df1I32 {
+    static constexpr bool kClamp = CLAMP;
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 4;  // x0 x1 y0 y1
@@ -90,6 +91,7 @@ struct Df1I32 {
 // src/iir/biquad.rs:511-538 (first-order error feedback)
 template <bool CLAMP>
 struct DitherI32 {
+    static constexpr bool kClamp = CLAMP;
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 5;  // x0 x1 y0 y1 e
@@ -114,6 +116,7 @@ struct DitherI32 {
 // src/iir/biquad.rs:456-480 (64-bit y state)
 template <bool CLAMP>
 struct WideI32 {
+    static constexpr bool kClamp = CLAMP;
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 6;  // x0 x1 y0.lo y0.hi y1.lo y1.hi
@@ -148,6 +151,7 @@ struct WideI32 {
 // src/iir/biquad.rs:366-383 (C = T = A = f32)
 template <bool CLAMP>
 struct Df1F32 {
+    static constexpr bool kClamp = CLAMP;
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 4;
@@ -171,6 +175,7 @@ struct Df1F32 {
 // src/iir/biquad.rs:418-440
 template <bool CLAMP>
 struct Df2tF32 {
+    static constexpr bool kClamp = CLAMP;
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 2;  // s0 s1
@@ -202,6 +207,7 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 
 template <bool CLAMP>
 struct Df1F64 {
+    static constexpr bool kClamp = CLAMP;
     using T = double;
     using Sec = SecF64;
     static constexpr int W = 8;
@@ -224,6 +230,7 @@ struct Df1F64 {
 
 template <bool CLAMP>
 struct Df2tF64 {
+    static constexpr bool kClamp = CLAMP;
     using T = double;
     using Sec = SecF64;
     static constexpr int W = 4;
@@ -343,6 +350,78 @@ struct CascadeDf1 {
     }
 };
 
+// `ByLane<[C; lanes]>` (dsp-process/src/compose.rs:363-390): every lane filters with its
+// own coefficients.  Coefficient planes are lane-contiguous like the state planes:
+// value v of section k of lane l is coef[(k * CV + v) * lanes + l] (an i32/f32/f64),
+// CV = 5 (ba) or 8 (ba, u, min, max); they are read once into registers.
+template <class S, class T>
+__device__ __forceinline__ void unpack_sec(S &c, const T *v, int nv, T lo, T hi)
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) c.ba[i] = v[i];
+    c.u = nv == 8 ? v[5] : T(0);
+    c.mn = nv == 8 ? v[6] : lo;
+    c.mx = nv == 8 ? v[7] : hi;
+}
+__device__ __forceinline__ void unpack_sec(SecI32 &c, const int32_t *v, int nv, int32_t frac)
+{
+    unpack_sec(c, v, nv, INT32_MIN, INT32_MAX);
+    c.frac = frac;
+}
+__device__ __forceinline__ void unpack_sec(SecF32 &c, const float *v, int nv, int32_t)
+{
+    unpack_sec(c, v, nv, -__builtin_inff(), __builtin_inff());
+}
+__device__ __forceinline__ void unpack_sec(SecF64 &c, const double *v, int nv, int32_t)
+{
+    unpack_sec(c, v, nv, -__builtin_inf(), __builtin_inf());
+}
+
+struct ByLaneParams {
+    const void *coef;
+    int32_t frac;
+};
+
+template <class Sec, int N>
+struct ChainByLane {
+    using In = typename Sec::T;
+    using Out = typename Sec::T;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 0;
+    static constexpr int IN_DIV = 1;
+    static constexpr int COST = N * Sec::COST;
+    static constexpr int CV = Sec::kClamp ? 8 : 5;
+    using Params = ByLaneParams;
+    uint32_t s[N][Sec::W];
+    typename Sec::Sec c[N];
+
+    __device__ __forceinline__ void load(const Params &p, const uint32_t *st, size_t lanes, size_t lane)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+#pragma unroll
+            for (int w = 0; w < Sec::W; w++) s[k][w] = st[size_t(k * Sec::W + w) * lanes + lane];
+            In cv[CV];
+#pragma unroll
+            for (int v = 0; v < CV; v++) cv[v] = static_cast<const In *>(p.coef)[size_t(k * CV + v) * lanes + lane];
+            unpack_sec(c[k], cv, CV, p.frac);
+        }
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int w = 0; w < Sec::W; w++) st[size_t(k * Sec::W + w) * lanes + lane] = s[k][w];
+    }
+    __device__ __forceinline__ Out step(const Params &, In x)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) x = Sec::step(c[k], s[k], x);
+        return x;
+    }
+};
+
 // ------------------------------------------------------------ host dispatch
 template <class Sec, int N, class CfgFill>
 int run_chain_n(CfgFill fill, size_t first, void *state, const typename Sec::T *x, typename Sec::T *y,
@@ -384,6 +463,52 @@ int run_chain(CfgFill fill, size_t n, void *state, const typename Sec::T *x, typ
     return IDSP_OK;
 }
 
+inline int check_frac(int frac, size_t k)
+{
+    // `const { assert!(F >= 0 && F < 32) }` biquad.rs:448-450,513-515
+    if (frac < 0 || frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, frac);
+    return IDSP_OK;
+}
+
+constexpr int kMaxChainByLane = 2;  // coefficient registers come on top of the state
+
+// n per-lane sections in passes of <= kMaxChainByLane (stage-major like run_chain)
+template <class Sec>
+int run_chain_bylane(const void *coef, int frac, size_t n, void *state, const typename Sec::T *x, typename Sec::T *y,
+                     size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    using T = typename Sec::T;
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+    if (n == 0) {
+        if (x != y) IDSP_HIP_TRY(hipMemcpyAsync(y, x, lanes * frames * sizeof(T), hipMemcpyDeviceToDevice, s));
+        return IDSP_OK;
+    }
+    constexpr int CV = ChainByLane<Sec, 1>::CV;
+    size_t done = 0;
+    const T *src = x;
+    while (done < n) {
+        const size_t m = n - done < size_t(kMaxChainByLane) ? n - done : size_t(kMaxChainByLane);
+        ByLaneParams prm{static_cast<const T *>(coef) + done * CV * lanes, frac};
+        uint32_t *st = static_cast<uint32_t *>(state) + done * Sec::W * lanes;
+        const int rc = m == 1 ? launch_stream<ChainByLane<Sec, 1>>(prm, st, src, y, lanes, frames, layout, s)
+                              : launch_stream<ChainByLane<Sec, 2>>(prm, st, src, y, lanes, frames, layout, s);
+        if (rc) return rc;
+        done += m;
+        src = y;
+    }
+    return IDSP_OK;
+}
+
+template <class Sec>
+int entry_bylane(const void *coef, int frac, size_t n, void *state, const typename Sec::T *x, typename Sec::T *y,
+                 size_t lanes, size_t frames, int layout, void *stream)
+{
+    int rc = check_stream_args(coef, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (std::is_same<typename Sec::T, int32_t>::value && (rc = check_frac(frac, 0))) return rc;
+    return run_chain_bylane<Sec>(coef, frac, n, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
 template <class T, int N, class CfgFill>
 int run_cascade_n(CfgFill fill, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout, hipStream_t s)
 {
@@ -408,13 +533,6 @@ int run_cascade(CfgFill fill, size_t n, void *state, const T *x, T *y, size_t la
         case 7: return run_cascade_n<T, 7>(fill, state, x, y, lanes, frames, layout, s);
         default: return run_cascade_n<T, 8>(fill, state, x, y, lanes, frames, layout, s);
     }
-}
-
-inline int check_frac(int frac, size_t k)
-{
-    // `const { assert!(F >= 0 && F < 32) }` biquad.rs:448-450,513-515
-    if (frac < 0 || frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, frac);
-    return IDSP_OK;
 }
 
 struct FillI32 {

@@ -12,6 +12,7 @@ own:
     Cascade<[Biquad; N]>           (iir/biquad.rs:324)  Cascade([...])
     DirectForm1 / DirectForm2Transposed / DirectForm1Wide / DirectForm1Dither
     Split::new(cfg, state).lanes::<N>()  (split.rs:272) Split(cfg, DirectForm1).lanes(N)
+    Split::new(ByLane([c0, c1, ..]), states) (compose.rs:363) ByLane([c0, c1, ..], DirectForm1)
     Process::block(x, y) over &[[T; N]]  (process.rs:44) .block(x, y)      FrameMajor [frames, lanes]
     Inplace::inplace(xy)                 (process.rs:61) .inplace(xy)
     ViewProcess::process_view(View<LaneMajor>, ViewMut<LaneMajor>) (view.rs:245)
@@ -40,7 +41,7 @@ from ._lib import IdspError, call, load
 __all__ = [
     "FrameMajor", "LaneMajor", "View", "ViewMut", "Biquad", "BiquadClamp", "Cascade",
     "DirectForm1", "DirectForm2Transposed", "DirectForm1Wide", "DirectForm1Dither", "DirectForm",
-    "Split", "Lanes", "HbfDecCascade", "HbfIntCascade", "FirSym", "HBF_TAPS", "HBF_TAPS_98",
+    "Split", "Lanes", "ByLane", "HbfDecCascade", "HbfIntCascade", "FirSym", "HBF_TAPS", "HBF_TAPS_98",
     "Lowpass", "Lockin", "Accu", "Dds", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
 ]
 
@@ -386,6 +387,60 @@ class Lanes(_LaneOp):
         call(self._name, C.cast(self._cfg, C.c_void_p) if self._cfg is not None else None, self._n,
              C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
              self.n_lanes, frames, layout, _stream_ptr(x))
+
+
+class ByLane(_LaneOp):
+    """`Split<ByLane<[C; N]>, [S; N]>` (dsp-process/src/compose.rs:363-390): lane i is
+    filtered by configuration i with state i.  `configs[i]` is a Biquad, a BiquadClamp or
+    a list of either (serial slice, compose.rs:43-77); all lanes share one type, section
+    count and (for `Q32<F>`) one F.  The coefficients live on the GPU as lane-contiguous
+    planes (`self.coef`, [sections, 5 or 8, lanes]) and may be rewritten between calls
+    with `set_lane`."""
+
+    def __init__(self, configs: Sequence, state_kind: _StateKind, device="cuda"):
+        rows = [list(c) if isinstance(c, (list, tuple)) else [c] for c in configs]
+        if not rows or not rows[0]:
+            raise ValueError("ByLane needs at least one lane and one section")
+        first = rows[0][0]
+        self._clamp = isinstance(first, BiquadClamp)
+        self._n = len(rows[0])
+        self._frac = (first.coeff.frac if self._clamp else first.frac)
+        self._f64 = first.f64
+        name, _, dt = _biquad_entry(rows[0], state_kind)  # validates the (config, state) pairing
+        self._name = name + "_bylane"
+        self.dtype_in = self.dtype_out = dt
+        super().__init__(len(rows), state_kind.words * self._n * (2 if dt == torch.float64 else 1), device)
+        self.coef = torch.zeros((self._n, 8 if self._clamp else 5, self.n_lanes), dtype=dt, device="cpu")
+        for i, r in enumerate(rows):
+            self._fill(i, r)
+        self.coef = self.coef.to(self.device)
+
+    def _fill(self, lane: int, row):
+        if len(row) != self._n:
+            raise ValueError("every lane needs the same number of sections")
+        for k, s in enumerate(row):
+            c = s.coeff if self._clamp else s
+            if isinstance(s, BiquadClamp) != self._clamp or c.frac != self._frac or c.f64 != self._f64:
+                raise ValueError("all lanes of a ByLane must share one configuration type")
+            vals = list(c.ba) + ([s.u, s.min, s.max] if self._clamp else [])
+            self.coef[k, :, lane] = torch.tensor(vals, dtype=self.coef.dtype)
+
+    def set_lane(self, lane: int, config):
+        """Replace the configuration of one lane (its state is kept, like assigning `by_lane.0[i]`)."""
+        row = list(config) if isinstance(config, (list, tuple)) else [config]
+        host = torch.zeros((self._n, self.coef.shape[1], 1), dtype=self.coef.dtype)
+        dev, self.coef = self.coef, host
+        try:
+            self._fill(0, row)
+        finally:
+            host, self.coef = self.coef, dev
+        self.coef[:, :, lane] = host[:, :, 0].to(self.device)
+
+    def _run(self, x, y, frames, layout):
+        args = (C.c_void_p(self.coef.data_ptr()),) + ((self._frac,) if self._frac is not None else ()) + (
+            self._n, C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+            self.n_lanes, frames, layout, _stream_ptr(x))
+        call(self._name, *args)
 
 
 # --------------------------------------------------------------------------

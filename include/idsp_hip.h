@@ -57,7 +57,14 @@ typedef enum idsp_status {
     IDSP_OK = 0,
     IDSP_EINVAL = -1,  /* bad shape / parameter (reference: debug_assert / const assert) */
     IDSP_EHIP = -2,    /* HIP runtime error, text in idsp_last_error() */
-    IDSP_ENODEV = -3   /* no usable gfx950 device */
+    IDSP_ENODEV = -3,  /* no usable gfx950 device */
+    /* builder parameter validation, `iir::Error` (src/iir/error.rs:5-16); idsp_last_error()
+     * holds the reference's Display text, e.g. "parameter `frequency` is out of range" */
+    IDSP_ENONFINITE = -10,   /* Error::NonFinite     */
+    IDSP_ENONPOSITIVE = -11, /* Error::NonPositive   */
+    IDSP_EOUTOFRANGE = -12,  /* Error::OutOfRange    */
+    IDSP_EINVERTED = -13,    /* Error::InvertedRange */
+    IDSP_ESIGN = -14         /* Error::SignMismatch  */
 } idsp_status;
 
 typedef enum idsp_layout {
@@ -241,6 +248,158 @@ int idsp_biquad_f64_df2t_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void 
 int idsp_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state,
                          const double *x, double *y, size_t lanes, size_t frames,
                          int layout, void *stream);
+
+/*
+ * Per-lane coefficients: `ByLane<[C; N]>` (dsp-process/src/compose.rs:363-390,
+ * `process_view` :375-389: lane i is filtered by configuration i with state i)
+ * for C = a slice of `n` Biquad/BiquadClamp sections (compose.rs:43-77).
+ *
+ * `coef` is a device array of lane-contiguous planes like the state: value v
+ * of section k of lane l is coef[(k * CV + v) * lanes + l], with CV = 5
+ * (`Biquad::ba`, biquad.rs:116) for the plain entries and CV = 8 (ba, u, min,
+ * max; biquad.rs:121-157) for the `_clamp` entries.  The i32 variants share
+ * one `frac` (the const generic F of `Q32<F>`) across lanes and sections.
+ * State layout, x/y layout, in-place rule and status codes are those of the
+ * shared-coefficient entries above.
+ */
+int idsp_biquad_i32_df1_bylane(const int32_t *coef, int frac, size_t n, void *state,
+        const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_df1_clamp_bylane(const int32_t *coef, int frac, size_t n, void *state,
+        const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_dither_bylane(const int32_t *coef, int frac, size_t n, void *state,
+        const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_dither_clamp_bylane(const int32_t *coef, int frac, size_t n, void *state,
+        const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_wide_bylane(const int32_t *coef, int frac, size_t n, void *state,
+        const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_wide_clamp_bylane(const int32_t *coef, int frac, size_t n, void *state,
+        const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df1_bylane(const float *coef, size_t n, void *state,
+        const float *x, float *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df1_clamp_bylane(const float *coef, size_t n, void *state,
+        const float *x, float *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df2t_bylane(const float *coef, size_t n, void *state,
+        const float *x, float *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df2t_clamp_bylane(const float *coef, size_t n, void *state,
+        const float *x, float *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df1_bylane(const double *coef, size_t n, void *state,
+        const double *x, double *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df1_clamp_bylane(const double *coef, size_t n, void *state,
+        const double *x, double *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df2t_bylane(const double *coef, size_t n, void *state,
+        const double *x, double *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df2t_clamp_bylane(const double *coef, size_t n, void *state,
+        const double *x, double *y, size_t lanes, size_t frames, int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* coefficient front-end (host side, no device work)                        */
+/* ------------------------------------------------------------------------ */
+/*
+ * `iir::coefficients::Filter<T>`, `iir::pid::{Builder, Pid, Units}` and
+ * `iir::config::BiquadConfig::{build, try_build}`: pure host functions that
+ * produce the idsp_biquad_* records above (or rows of the per-lane coefficient
+ * planes).  Parameters travel as f64; `f32 != 0` selects T = f32, i.e. every
+ * field is first rounded to f32 and all arithmetic is carried out in f32 like
+ * the reference's generic code instantiated with T = f32.  `validate != 0`
+ * runs the reference's `validate()` first (the `try_build*` methods) and
+ * returns IDSP_ENONFINITE .. IDSP_ESIGN; `validate == 0` is the unchecked
+ * `build*` which, like the reference, may produce NaN/inf coefficients.
+ * The `_i32` outputs are C = `Q32<frac>`, Y = i32; `_f32`: C = Y = f32;
+ * `_f64`: C = Y = f64.
+ */
+
+/* `coefficients::Type` (src/iir/coefficients.rs:43-66) */
+typedef enum idsp_filter_type {
+    IDSP_LOWPASS = 0, IDSP_HIGHPASS, IDSP_BANDPASS, IDSP_ALLPASS, IDSP_NOTCH,
+    IDSP_PEAKING, IDSP_LOWSHELF, IDSP_HIGHSHELF, IDSP_IHO
+} idsp_filter_type;
+
+/* `coefficients::Shape` (src/iir/coefficients.rs:6-16) */
+typedef enum idsp_shape_kind { IDSP_SHAPE_Q = 0, IDSP_SHAPE_BANDWIDTH = 1, IDSP_SHAPE_SLOPE = 2 } idsp_shape_kind;
+
+/* `coefficients::Filter<T>` (src/iir/coefficients.rs:27-40); Default (:88-97) is
+ * frequency 0, gain 1, shelf 1, Shape::Q(1/sqrt 2). */
+typedef struct idsp_filter {
+    double frequency; /* angular critical frequency w0, pi = Nyquist */
+    double gain;      /* linear passband gain */
+    double shelf;     /* linear shelf gain (peaking / shelves / iho) */
+    double shape;     /* Q, bandwidth in octaves, or shelf slope */
+    int32_t shape_kind;
+    int32_t f32;
+} idsp_filter;
+
+/* `Filter::build(typ)` / `try_build(typ)` (coefficients.rs:483-501): cookbook
+ * `[[b0,b1,b2],[a0,a1,a2]]` flattened to ba[6] = the `sos` row format of
+ * idsp_biquad_*_from_sos.  With f32 set the six values are exact f32 values. */
+int idsp_filter_build(const idsp_filter *f, int type, int validate, double ba[6]);
+
+/* `pid::Order` (src/iir/pid.rs:14-24) and `pid::Action` (:61-75) index values */
+#define IDSP_PID_ORDER_P 2
+#define IDSP_PID_ORDER_I 1
+#define IDSP_PID_ORDER_I2 0
+
+/* `pid::Builder<T>` (src/iir/pid.rs:40-45); gain/limit index = Action: I2, I, P, D, D2.
+ * Default (:47-55): order I, gains 0, limits +inf. */
+typedef struct idsp_pid_builder {
+    int32_t order;
+    int32_t f32;
+    double gain[5];
+    double limit[5];
+} idsp_pid_builder;
+
+/* `Build<[C; 5]> for Builder<T>` (src/iir/pid.rs:256-313) with context `period`;
+ * validate = `Builder::validate` (:195-222).  ba = [b0, b1, b2, a1, a2]. */
+int idsp_pid_build_i32(const idsp_pid_builder *b, double period, int validate, int frac, int32_t ba[5]);
+int idsp_pid_build_f32(const idsp_pid_builder *b, double period, int validate, float ba[5]);
+int idsp_pid_build_f64(const idsp_pid_builder *b, double period, int validate, double ba[5]);
+
+/* `pid::Units<T>` (src/iir/pid.rs:350-369), Default 1, 1, 1 */
+typedef struct idsp_units {
+    double t, x, y;
+} idsp_units;
+
+/* `pid::Pid<T>` (src/iir/pid.rs:384-417); Default: builder default, setpoint 0, min -inf, max +inf */
+typedef struct idsp_pid {
+    idsp_pid_builder builder;
+    double setpoint, min, max;
+} idsp_pid;
+
+/* `Build<BiquadClamp<C, Y>> for Pid<T>` (src/iir/pid.rs:533-567) = `BiquadConfig::Pid`
+ * (config.rs:371,408); validate = `Pid::validate` (pid.rs:497-518). */
+int idsp_pid_build_clamp_i32(const idsp_pid *p, const idsp_units *units, int validate, int frac,
+                             idsp_biquad_clamp_i32 *out);
+int idsp_pid_build_clamp_f32(const idsp_pid *p, const idsp_units *units, int validate, idsp_biquad_clamp_f32 *out);
+int idsp_pid_build_clamp_f64(const idsp_pid *p, const idsp_units *units, int validate, idsp_biquad_clamp_f64 *out);
+
+/* `config::BaConfig<T>` (src/iir/config.rs:19-31): SI-unit `[[b],[a]]`, offset, limits */
+typedef struct idsp_ba_config {
+    double ba[6];
+    double offset, min, max;
+    int32_t f32;
+} idsp_ba_config;
+
+/* `BiquadConfig::Ba(..).build(units)` (config.rs:359-367) / `.try_build` (:389-407) */
+int idsp_config_ba_build_i32(const idsp_ba_config *c, const idsp_units *units, int validate, int frac,
+                             idsp_biquad_clamp_i32 *out);
+int idsp_config_ba_build_f32(const idsp_ba_config *c, const idsp_units *units, int validate, idsp_biquad_clamp_f32 *out);
+int idsp_config_ba_build_f64(const idsp_ba_config *c, const idsp_units *units, int validate, idsp_biquad_clamp_f64 *out);
+
+/* `config::FilterConfig<T>` (src/iir/config.rs:46-67): frequency relative to 1/units.t, gains in dB */
+typedef struct idsp_filter_config {
+    int32_t typ; /* idsp_filter_type */
+    int32_t shape_kind;
+    double frequency, gain_db, shelf_db, shape;
+    double offset, min, max;
+    int32_t f32;
+} idsp_filter_config;
+
+/* `BiquadConfig::Filter(..).build(units)` (config.rs:372-385) / `.try_build` (:409-427) */
+int idsp_config_filter_build_i32(const idsp_filter_config *c, const idsp_units *units, int validate, int frac,
+                                 idsp_biquad_clamp_i32 *out);
+int idsp_config_filter_build_f32(const idsp_filter_config *c, const idsp_units *units, int validate,
+                                 idsp_biquad_clamp_f32 *out);
+int idsp_config_filter_build_f64(const idsp_filter_config *c, const idsp_units *units, int validate,
+                                 idsp_biquad_clamp_f64 *out);
 
 /* ------------------------------------------------------------------------ */
 /* hbf — symmetric FIR and half-band decimator / interpolator cascades      */

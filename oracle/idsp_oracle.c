@@ -390,6 +390,54 @@ LANE_DRIVER(idsp_ref_biquad_f64_df1_clamp, idsp_biquad_clamp_f64, double, 8, 1, 
 LANE_DRIVER(idsp_ref_biquad_f64_df2t, idsp_biquad_f64, double, 4, 1, df2t_f64(c->ba, s, x0))
 LANE_DRIVER(idsp_ref_biquad_f64_df2t_clamp, idsp_biquad_clamp_f64, double, 4, 1, df2t_clamp_f64(c, s, x0))
 
+/*
+ * `ByLane<[C; N]>::process_view` (dsp-process/src/compose.rs:375-389): lane i is
+ * filtered by configuration i with state i.  Coefficient planes:
+ * coef[(k * CV + v) * lanes + l], CV = 5 (ba) or 8 (ba, u, min, max).
+ */
+#define FILL_PLAIN(c, k, l) do { for (int v = 0; v < 5; v++) (c).ba[v] = coef[((k) * 5 + v) * lanes + (l)]; } while (0)
+#define FILL_CLAMP(c, k, l) do { for (int v = 0; v < 5; v++) (c).ba[v] = coef[((k) * 8 + v) * lanes + (l)]; \
+        (c).u = coef[((k) * 8 + 5) * lanes + (l)]; (c).min = coef[((k) * 8 + 6) * lanes + (l)];             \
+        (c).max = coef[((k) * 8 + 7) * lanes + (l)]; } while (0)
+#define BYLANE_BODY(BASE, CFG_T, FILL, SETFRAC)                                                    \
+    {                                                                                              \
+        int rc = check_common(coef, n, state, x, y, lanes, frames, layout);                        \
+        if (rc) return rc;                                                                         \
+        CFG_T cfg[IDSP_MAX_SECTIONS];                                                              \
+        for (size_t l = 0; l < lanes; l++) {                                                       \
+            for (size_t k = 0; k < n; k++) { FILL(cfg[k], k, l); SETFRAC; }                        \
+            rc = BASE##_range(cfg, n, state, x, y, lanes, frames, layout, l, l + 1);               \
+            if (rc) return rc;                                                                     \
+        }                                                                                          \
+        return IDSP_OK;                                                                            \
+    }
+#define BYLANE_I32(NAME, CFG_T, FILL)                                                              \
+    int idsp_ref_biquad_i32_##NAME##_bylane(const int32_t *coef, int frac, size_t n, void *state,  \
+            const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout)                 \
+    {                                                                                              \
+        if (frac < 0 || frac > 31) return IDSP_EINVAL;                                             \
+        BYLANE_BODY(idsp_ref_biquad_i32_##NAME, CFG_T, FILL, cfg[k].frac = frac)                   \
+    }
+#define BYLANE_F(T, TN, NAME, CFG_T, FILL)                                                         \
+    int idsp_ref_biquad_##TN##_##NAME##_bylane(const T *coef, size_t n, void *state, const T *x,   \
+            T *y, size_t lanes, size_t frames, int layout)                                         \
+    BYLANE_BODY(idsp_ref_biquad_##TN##_##NAME, CFG_T, FILL, (void)0)
+
+BYLANE_I32(df1, idsp_biquad_i32, FILL_PLAIN)
+BYLANE_I32(df1_clamp, idsp_biquad_clamp_i32, FILL_CLAMP)
+BYLANE_I32(dither, idsp_biquad_i32, FILL_PLAIN)
+BYLANE_I32(dither_clamp, idsp_biquad_clamp_i32, FILL_CLAMP)
+BYLANE_I32(wide, idsp_biquad_i32, FILL_PLAIN)
+BYLANE_I32(wide_clamp, idsp_biquad_clamp_i32, FILL_CLAMP)
+BYLANE_F(float, f32, df1, idsp_biquad_f32, FILL_PLAIN)
+BYLANE_F(float, f32, df1_clamp, idsp_biquad_clamp_f32, FILL_CLAMP)
+BYLANE_F(float, f32, df2t, idsp_biquad_f32, FILL_PLAIN)
+BYLANE_F(float, f32, df2t_clamp, idsp_biquad_clamp_f32, FILL_CLAMP)
+BYLANE_F(double, f64, df1, idsp_biquad_f64, FILL_PLAIN)
+BYLANE_F(double, f64, df1_clamp, idsp_biquad_clamp_f64, FILL_CLAMP)
+BYLANE_F(double, f64, df2t, idsp_biquad_f64, FILL_PLAIN)
+BYLANE_F(double, f64, df2t_clamp, idsp_biquad_clamp_f64, FILL_CLAMP)
+
 /* `Cascade<[Biquad<C>; N]>` x `DirectForm<T, N>` (src/iir/biquad.rs:339-364):
  * sample-major fold over sections; section k's input history is the output
  * history of section k-1 (x for k = 0).  Words: x0,x1,(y0,y1) x n. */

@@ -81,6 +81,21 @@ int idsp_ref_biquad_f64_df2t(const idsp_biquad_f64 *cfg, size_t n, void *state,
                              const double *x, double *y, size_t lanes, size_t frames, int layout);
 int idsp_ref_biquad_f64_df2t_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state,
                                    const double *x, double *y, size_t lanes, size_t frames, int layout);
+/* ByLane<[C; N]> (dsp-process/src/compose.rs:363-390) */
+int idsp_ref_biquad_i32_df1_bylane(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_df1_clamp_bylane(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_dither_bylane(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_dither_clamp_bylane(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_wide_bylane(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_i32_wide_clamp_bylane(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f32_df1_bylane(const float *coef, size_t n, void *state, const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f32_df1_clamp_bylane(const float *coef, size_t n, void *state, const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f32_df2t_bylane(const float *coef, size_t n, void *state, const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f32_df2t_clamp_bylane(const float *coef, size_t n, void *state, const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f64_df1_bylane(const double *coef, size_t n, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f64_df1_clamp_bylane(const double *coef, size_t n, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f64_df2t_bylane(const double *coef, size_t n, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_biquad_f64_df2t_clamp_bylane(const double *coef, size_t n, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
 int idsp_ref_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state,
                              const double *x, double *y, size_t lanes, size_t frames, int layout);
 

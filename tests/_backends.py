@@ -24,6 +24,14 @@ class OracleBackend:
         rc = self.o.stream(op, cfg, n, state, x, y, lanes, frames, layout)
         return rc, y
 
+    def bylane(self, op, coef, frac, n, state, x, lanes, frames, layout, inplace=False):
+        """`op` without the `_bylane` suffix; coef = [n, CV, lanes] planes; frac None for floats."""
+        x = np.ascontiguousarray(x)
+        coef = np.ascontiguousarray(coef)
+        y = x if inplace else np.empty_like(x)
+        args = (H._ptr(coef),) + (() if frac is None else (frac,)) + (n, H._ptr(state), H._ptr(x), H._ptr(y), lanes, frames, layout)
+        return self.o.fn[op + "_bylane"](*args), y
+
     def cfgcall(self, op, cfg, state, x, y_shape, y_dtype, lanes, frames, layout):
         x = np.ascontiguousarray(x) if x is not None else None
         y = np.empty(y_shape, dtype=y_dtype)
@@ -83,6 +91,20 @@ class GpuBackend:
         torch.cuda.synchronize()
         if ss is not None:
             state[...] = self._down(ss, np.uint32).reshape(state.shape)
+        return rc, self._down(ys, x.dtype).reshape(np.shape(x))
+
+    def bylane(self, op, coef, frac, n, state, x, lanes, frames, layout, inplace=False):
+        torch = self.torch
+        xs, cs, ss = self._up(x), self._up(coef), self._up(state)
+        ys = xs if inplace else torch.empty_like(xs)
+        if not inplace:
+            ys.fill_(-77 if xs.dtype == torch.int32 else float("nan"))
+        args = (H._ptr(cs),) + (() if frac is None else (frac,)) + (n, H._ptr(ss), H._ptr(xs), H._ptr(ys), lanes, frames, layout, None)
+        rc = self.e.fn[op + "_bylane"](*args)
+        torch.cuda.synchronize()
+        if ss is not None:
+            state[...] = self._down(ss, np.uint32).reshape(state.shape)
+        assert np.array_equal(self._down(cs, coef.dtype).reshape(coef.shape), coef)  # coefficients are read-only
         return rc, self._down(ys, x.dtype).reshape(np.shape(x))
 
     def cfgcall(self, op, cfg, state, x, y_shape, y_dtype, lanes, frames, layout):

@@ -152,3 +152,40 @@ def test_f64_biquad_and_fir_through_the_mirror():
     yi = torch.empty_like(xi)
     ia.FirSym("EvenSymmetric", [0.25, 0.5]).lanes(1).block(xi, yi)
     assert yi.flatten().tolist()[:5] == [0.25, 0.5, 0.5, 0.25, 0.0]  # taps mirror around the window centre
+
+
+def test_by_lane_filter_bank():
+    """`Split::new(ByLane([c0, c1, ..]), states)` (dsp-process/src/compose.rs:363-390): a bank of
+    different lowpasses, one per lane, equals each filter run alone; `set_lane` swaps one in place."""
+    from idsp_amd import coefficients as co
+
+    f0s = [0.01, 0.05, 0.1, 0.2, 0.3]
+    bank = [co.Filter().critical_frequency(f0).build_biquad(co.Type.Lowpass, frac=30) for f0 in f0s]
+    x = torch.randint(-(1 << 20), 1 << 20, (300, len(bank)), dtype=torch.int32, device="cuda")
+    y = torch.empty_like(x)
+    bl = ia.ByLane(bank, ia.DirectForm1)
+    bl.block(x, y)
+    for i, b in enumerate(bank):
+        yi = torch.empty((300, 1), dtype=torch.int32, device="cuda")
+        ia.Split(b, ia.DirectForm1).lanes(1).block(x[:, i:i + 1].contiguous(), yi)
+        assert torch.equal(y[:, i], yi[:, 0])
+    bl.reset()
+    bl.set_lane(2, bank[0])
+    bl.block(x, y)
+    y0 = torch.empty((300, 1), dtype=torch.int32, device="cuda")
+    ia.Split(bank[0], ia.DirectForm1).lanes(1).block(x[:, 2:3].contiguous(), y0)
+    assert torch.equal(y[:, 2], y0[:, 0])
+    # a PID bank with clamps: per-lane BiquadClamp<f32> on DirectForm2Transposed, lane-major views
+    pids = [co.Pid().kp(1.0 + k).ki(10.0 * k).output_limits(-0.5, 0.5).build(co.Units(t=1e-3)) for k in range(4)]
+    pl = ia.ByLane(pids, ia.DirectForm2Transposed)
+    xs = torch.randn(4 * 64, device="cuda")
+    ys = torch.empty_like(xs)
+    pl.process_view(ia.View(xs, ia.LaneMajor, 4), ia.ViewMut(ys, ia.LaneMajor, 4))
+    assert ys.abs().max().item() <= 0.5
+    for k, c in enumerate(pids):
+        one = torch.empty(64, device="cuda")
+        ia.Split(c, ia.DirectForm2Transposed).lanes(1).process_view(
+            ia.View(xs[64 * k:64 * (k + 1)].contiguous(), ia.LaneMajor, 1), ia.ViewMut(one, ia.LaneMajor, 1))
+        assert torch.equal(ys[64 * k:64 * (k + 1)], one)
+    with pytest.raises(ValueError):
+        ia.ByLane([bank[0], pids[0]], ia.DirectForm1)
