@@ -53,6 +53,11 @@ build/test_host: tests/cpp/test_host.cpp include/idsp_hip.hpp include/idsp_hip.h
 	@mkdir -p build
 	g++ -std=c++17 -O1 -Wall -Iinclude tests/cpp/test_host.cpp -Lidsp_amd/lib -lidsp_hip -Wl,-rpath,'$$ORIGIN/../idsp_amd/lib' -o $@
 
+# coefficient front-end test program: host code only, runs without a GPU
+build/test_coeff: tests/cpp/test_coeff.cpp include/idsp_hip.hpp include/idsp_hip.h $(LIB)
+	@mkdir -p build
+	g++ -std=c++17 -O1 -Wall -Iinclude tests/cpp/test_coeff.cpp -Lidsp_amd/lib -lidsp_hip -Wl,-rpath,'$$ORIGIN/../idsp_amd/lib' -o $@
+
 clean:
 	rm -f $(HIP_OBJS) $(LIB) $(ORACLE) $(ORACLE_NAT)
 

@@ -16,6 +16,8 @@
 //   ViewProcess::process_view(View<LaneMajor>)  (view.rs:245)   .process_view(View, ViewMut)
 //   HBF_DEC_CASCADE + HbfDec2..32 / HBF_INT_CASCADE (hbf.rs)    HbfDecCascade / HbfIntCascade
 //   Lockin<[Lowpass<N>; K]> + Accu      (lockin.rs, accu.rs)    Lockin<N, K>
+//   ByLane<[C; N]>                      (compose.rs:363)        ByLane<Cfg, S>(configs)
+//   coefficients::Filter, pid::Builder, Pid, Units (iir/coefficients.rs, iir/pid.rs)  Filter, pid::Builder, Pid, Units
 //   cossin(phase)                       (cossin.rs:14)          cossin(phases, out)
 //   atan2(y, x) / Complex::arg          (atan2.rs:66)           atan2(xy, out)
 //
@@ -378,6 +380,304 @@ template <class Cfg, class S>
 SplitT<Cfg, S> Split(const std::vector<Cfg> &sections, S)
 {
     return SplitT<Cfg, S>{sections};
+}
+
+namespace detail {
+using ByLaneI32 = int (*)(const int32_t *, int, size_t, void *, const int32_t *, int32_t *, size_t, size_t, int, void *);
+using ByLaneF32 = int (*)(const float *, size_t, void *, const float *, float *, size_t, size_t, int, void *);
+using ByLaneF64 = int (*)(const double *, size_t, void *, const double *, double *, size_t, size_t, int, void *);
+template <class Cfg, class S>
+struct EntryByLane;
+template <int F> struct EntryByLane<Biquad<Q32<F>>, DirectForm1> { static constexpr ByLaneI32 fn = idsp_biquad_i32_df1_bylane; };
+template <int F> struct EntryByLane<Biquad<Q32<F>>, DirectForm1Dither> { static constexpr ByLaneI32 fn = idsp_biquad_i32_dither_bylane; };
+template <int F> struct EntryByLane<Biquad<Q32<F>>, DirectForm1Wide> { static constexpr ByLaneI32 fn = idsp_biquad_i32_wide_bylane; };
+template <int F> struct EntryByLane<BiquadClamp<Q32<F>>, DirectForm1> { static constexpr ByLaneI32 fn = idsp_biquad_i32_df1_clamp_bylane; };
+template <int F> struct EntryByLane<BiquadClamp<Q32<F>>, DirectForm1Dither> { static constexpr ByLaneI32 fn = idsp_biquad_i32_dither_clamp_bylane; };
+template <int F> struct EntryByLane<BiquadClamp<Q32<F>>, DirectForm1Wide> { static constexpr ByLaneI32 fn = idsp_biquad_i32_wide_clamp_bylane; };
+template <> struct EntryByLane<Biquad<float>, DirectForm1> { static constexpr ByLaneF32 fn = idsp_biquad_f32_df1_bylane; };
+template <> struct EntryByLane<Biquad<float>, DirectForm2Transposed> { static constexpr ByLaneF32 fn = idsp_biquad_f32_df2t_bylane; };
+template <> struct EntryByLane<BiquadClamp<float>, DirectForm1> { static constexpr ByLaneF32 fn = idsp_biquad_f32_df1_clamp_bylane; };
+template <> struct EntryByLane<BiquadClamp<float>, DirectForm2Transposed> { static constexpr ByLaneF32 fn = idsp_biquad_f32_df2t_clamp_bylane; };
+template <> struct EntryByLane<Biquad<double>, DirectForm1> { static constexpr ByLaneF64 fn = idsp_biquad_f64_df1_bylane; };
+template <> struct EntryByLane<Biquad<double>, DirectForm2Transposed> { static constexpr ByLaneF64 fn = idsp_biquad_f64_df2t_bylane; };
+template <> struct EntryByLane<BiquadClamp<double>, DirectForm1> { static constexpr ByLaneF64 fn = idsp_biquad_f64_df1_clamp_bylane; };
+template <> struct EntryByLane<BiquadClamp<double>, DirectForm2Transposed> { static constexpr ByLaneF64 fn = idsp_biquad_f64_df2t_clamp_bylane; };
+
+template <class C> struct FracOf { static constexpr int value = -1; };
+template <int F> struct FracOf<Biquad<Q32<F>>> { static constexpr int value = F; };
+template <int F> struct FracOf<BiquadClamp<Q32<F>>> { static constexpr int value = F; };
+// one lane's section as the 5 (ba) or 8 (ba, u, min, max) plane values
+template <class C> std::vector<typename Biquad<C>::Sample> plane_values(const Biquad<C> &b)
+{
+    return {b.ba.begin(), b.ba.end()};
+}
+template <class C> std::vector<typename Biquad<C>::Sample> plane_values(const BiquadClamp<C> &c)
+{
+    std::vector<typename Biquad<C>::Sample> v(c.coeff.ba.begin(), c.coeff.ba.end());
+    v.push_back(c.u), v.push_back(c.min), v.push_back(c.max);
+    return v;
+}
+}  // namespace detail
+
+/// `Split<ByLane<[C; lanes]>, [S; lanes]>` (dsp-process/src/compose.rs:363-390): lane i is filtered by
+/// configuration i with state i.  `configs[i]` is the serial slice of sections of lane i; every lane
+/// has the same number of sections.  The coefficients are kept on the GPU as lane-contiguous planes.
+template <class Cfg, class S>
+class ByLane {
+public:
+    using Sample = typename Cfg::Sample;
+    explicit ByLane(const std::vector<std::vector<Cfg>> &configs, void *stream = nullptr)
+        : lanes_(configs.size()), sections_(configs.empty() ? 0 : configs[0].size()), stream_(stream),
+          state_(size_t(S::words) * (sizeof(Sample) / 4) * (sections_ ? sections_ : 1) * lanes_)
+    {
+        require(lanes_ && sections_, "ByLane needs at least one lane and one section");
+        const size_t cv = detail::plane_values(configs[0][0]).size();
+        std::vector<Sample> host(sections_ * cv * lanes_);
+        for (size_t l = 0; l < lanes_; l++) {
+            require(configs[l].size() == sections_, "every lane needs the same number of sections");
+            for (size_t k = 0; k < sections_; k++) {
+                const auto v = detail::plane_values(configs[l][k]);
+                for (size_t i = 0; i < cv; i++) host[(k * cv + i) * lanes_ + l] = v[i];
+            }
+        }
+        coef_ = DeviceBuffer<Sample>(host);
+    }
+    /// one section per lane
+    explicit ByLane(const std::vector<Cfg> &configs, void *stream = nullptr) : ByLane(wrap(configs), stream) {}
+    size_t lanes() const { return lanes_; }
+    DeviceBuffer<uint32_t> &state() { return state_; }
+    DeviceBuffer<Sample> &coefficients() { return coef_; }
+
+    /// `Process::block` over `&[[X; N]]` — FrameMajor (compose.rs:363-372 per frame)
+    void block(const DeviceBuffer<Sample> &x, DeviceBuffer<Sample> &y)
+    {
+        require(x.len() == y.len(), "x.len() != y.len()");
+        require(x.len() % lanes_ == 0, "slice is not a whole number of frames");
+        run(x.data(), y.data(), x.len() / lanes_, IDSP_FRAME_MAJOR);
+    }
+    void inplace(DeviceBuffer<Sample> &xy)
+    {
+        require(xy.len() % lanes_ == 0, "slice is not a whole number of frames");
+        run(xy.data(), xy.data(), xy.len() / lanes_, IDSP_FRAME_MAJOR);
+    }
+    /// `SplitViewProcess::process_view` (compose.rs:375-389)
+    template <class Layout>
+    void process_view(View<Sample, Layout> x, ViewMut<Sample, Layout> y)
+    {
+        require(x.frames == y.frames, "x.frames() != y.frames()");  // compose.rs:386
+        require(x.lanes == lanes_ && y.lanes == lanes_, "view lane count != ByLane lane count");
+        run(x.flat, y.flat, x.frames, Layout::value);
+    }
+
+private:
+    static std::vector<std::vector<Cfg>> wrap(const std::vector<Cfg> &c)
+    {
+        std::vector<std::vector<Cfg>> r;
+        for (const auto &v : c) r.push_back({v});
+        return r;
+    }
+    void run(const Sample *x, Sample *y, size_t frames, int layout)
+    {
+        if constexpr (detail::FracOf<Cfg>::value >= 0)
+            check(detail::EntryByLane<Cfg, S>::fn(coef_.data(), detail::FracOf<Cfg>::value, sections_, state_.data(), x, y,
+                                                  lanes_, frames, layout, stream_));
+        else
+            check(detail::EntryByLane<Cfg, S>::fn(coef_.data(), sections_, state_.data(), x, y, lanes_, frames, layout, stream_));
+    }
+    size_t lanes_, sections_;
+    void *stream_;
+    DeviceBuffer<uint32_t> state_;
+    DeviceBuffer<Sample> coef_;
+};
+
+// ------------------------------------------------------- coefficient front-end
+namespace detail {
+template <class C> struct OutOf;
+template <int F> struct OutOf<Q32<F>> {
+    using Rec = idsp_biquad_clamp_i32;
+    static int pid(const idsp_pid_builder *b, double t, int v, int32_t *ba) { return idsp_pid_build_i32(b, t, v, F, ba); }
+    static int pid_clamp(const idsp_pid *p, const idsp_units *u, int v, Rec *o) { return idsp_pid_build_clamp_i32(p, u, v, F, o); }
+    static int ba(const idsp_ba_config *c, const idsp_units *u, int v, Rec *o) { return idsp_config_ba_build_i32(c, u, v, F, o); }
+    static int filter(const idsp_filter_config *c, const idsp_units *u, int v, Rec *o) { return idsp_config_filter_build_i32(c, u, v, F, o); }
+};
+template <> struct OutOf<float> {
+    using Rec = idsp_biquad_clamp_f32;
+    static int pid(const idsp_pid_builder *b, double t, int v, float *ba) { return idsp_pid_build_f32(b, t, v, ba); }
+    static int pid_clamp(const idsp_pid *p, const idsp_units *u, int v, Rec *o) { return idsp_pid_build_clamp_f32(p, u, v, o); }
+    static int ba(const idsp_ba_config *c, const idsp_units *u, int v, Rec *o) { return idsp_config_ba_build_f32(c, u, v, o); }
+    static int filter(const idsp_filter_config *c, const idsp_units *u, int v, Rec *o) { return idsp_config_filter_build_f32(c, u, v, o); }
+};
+template <> struct OutOf<double> {
+    using Rec = idsp_biquad_clamp_f64;
+    static int pid(const idsp_pid_builder *b, double t, int v, double *ba) { return idsp_pid_build_f64(b, t, v, ba); }
+    static int pid_clamp(const idsp_pid *p, const idsp_units *u, int v, Rec *o) { return idsp_pid_build_clamp_f64(p, u, v, o); }
+    static int ba(const idsp_ba_config *c, const idsp_units *u, int v, Rec *o) { return idsp_config_ba_build_f64(c, u, v, o); }
+    static int filter(const idsp_filter_config *c, const idsp_units *u, int v, Rec *o) { return idsp_config_filter_build_f64(c, u, v, o); }
+};
+template <class C, class Rec>
+BiquadClamp<C> clamp_from(const Rec &r)
+{
+    BiquadClamp<C> c;
+    for (int i = 0; i < 5; i++) c.coeff.ba[i] = r.ba[i];
+    c.u = r.u, c.min = r.min, c.max = r.max;
+    return c;
+}
+}  // namespace detail
+
+/// `pid::Units<T>` (src/iir/pid.rs:350-375)
+struct Units : idsp_units {
+    Units(double t_ = 1.0, double x_ = 1.0, double y_ = 1.0) : idsp_units{t_, x_, y_} {}
+};
+
+/// `coefficients::Filter<T>` (src/iir/coefficients.rs:27-40) with T = f64 (f32 = true: T = f32);
+/// setters as in the reference (:110-238).  `build*` is unchecked, `try_build*` validates and throws.
+class Filter {
+public:
+    explicit Filter(bool f32 = false) : f_{0.0, 1.0, 1.0, f32 ? double(1.0f / std::sqrt(2.0f)) : 1.0 / std::sqrt(2.0), IDSP_SHAPE_Q, f32} {}
+    Filter &frequency(double critical, double sample) { return critical_frequency(t(t(critical) / t(sample))); }
+    Filter &critical_frequency(double f0) { return angular_critical_frequency(t(t(6.283185307179586476925286766559) * t(f0))); }
+    Filter &angular_critical_frequency(double w0) { f_.frequency = t(w0); return *this; }
+    Filter &gain(double k) { f_.gain = t(k); return *this; }
+    Filter &gain_db(double k_db) { return gain(pow10(k_db)); }
+    Filter &shelf(double a) { f_.shelf = t(a); return *this; }
+    Filter &shelf_db(double a_db) { return shelf(pow10(a_db)); }
+    Filter &inverse_q(double qi) { return q(t(1.0 / t(qi))); }
+    Filter &q(double v) { return set_shape(IDSP_SHAPE_Q, v); }
+    Filter &bandwidth(double bw) { return set_shape(IDSP_SHAPE_BANDWIDTH, bw); }
+    Filter &shelf_slope(double s) { return set_shape(IDSP_SHAPE_SLOPE, s); }
+    Filter &set_shape(idsp_shape_kind kind, double v) { f_.shape_kind = kind, f_.shape = t(v); return *this; }
+    /// `Filter::build(typ)` (:483-495) -> [b0, b1, b2, a0, a1, a2]
+    std::array<double, 6> build(idsp_filter_type typ) const { return go(typ, 0); }
+    /// `Filter::try_build(typ)` (:498-501)
+    std::array<double, 6> try_build(idsp_filter_type typ) const { return go(typ, 1); }
+    void validate() const { go(IDSP_LOWPASS, 1); }
+    std::array<double, 6> lowpass() const { return build(IDSP_LOWPASS); }
+    std::array<double, 6> highpass() const { return build(IDSP_HIGHPASS); }
+    std::array<double, 6> bandpass() const { return build(IDSP_BANDPASS); }
+    std::array<double, 6> allpass() const { return build(IDSP_ALLPASS); }
+    std::array<double, 6> notch() const { return build(IDSP_NOTCH); }
+    std::array<double, 6> peaking() const { return build(IDSP_PEAKING); }
+    std::array<double, 6> lowshelf() const { return build(IDSP_LOWSHELF); }
+    std::array<double, 6> highshelf() const { return build(IDSP_HIGHSHELF); }
+    std::array<double, 6> iho() const { return build(IDSP_IHO); }
+    /// `build_biquad::<C>` / `try_build_biquad::<C>` (:504-517): `From<[[T; 3]; 2]>` evaluated in T
+    template <class C> Biquad<C> build_biquad(idsp_filter_type typ) const { return to_biquad<C>(build(typ)); }
+    template <class C> Biquad<C> try_build_biquad(idsp_filter_type typ) const { return to_biquad<C>(try_build(typ)); }
+    template <class C> BiquadClamp<C> build_clamped(idsp_filter_type typ) const { return BiquadClamp<C>(build_biquad<C>(typ)); }
+
+private:
+    double t(double v) const { return f_.f32 ? double(float(v)) : v; }
+    double pow10(double db) const { return f_.f32 ? double(std::pow(10.0f, float(db) / 20.0f)) : std::pow(10.0, db / 20.0); }
+    std::array<double, 6> go(idsp_filter_type typ, int validate) const
+    {
+        std::array<double, 6> ba{};
+        check(idsp_filter_build(&f_, typ, validate, ba.data()));
+        return ba;
+    }
+    template <class C>
+    Biquad<C> to_biquad(const std::array<double, 6> &ba) const
+    {
+        idsp_ba_config c{};
+        for (int i = 0; i < 6; i++) c.ba[i] = ba[i];
+        c.min = -std::numeric_limits<double>::infinity(), c.max = std::numeric_limits<double>::infinity(), c.f32 = f_.f32;
+        const Units one;
+        typename detail::OutOf<C>::Rec r;
+        check(detail::OutOf<C>::ba(&c, &one, 0, &r));
+        return detail::clamp_from<C>(r).coeff;
+    }
+    idsp_filter f_;
+};
+
+namespace pid {
+enum Action { I2 = 0, I = 1, P = 2, D = 3, D2 = 4 };                  // src/iir/pid.rs:61-75
+enum Order { OrderP = 2, OrderI = 1, OrderI2 = 0 };                  // src/iir/pid.rs:14-24
+
+/// `pid::Builder<T>` (src/iir/pid.rs:40-55)
+class Builder {
+public:
+    explicit Builder(bool f32 = false)
+    {
+        b_.order = OrderI, b_.f32 = f32;
+        for (int i = 0; i < 5; i++) b_.gain[i] = 0.0, b_.limit[i] = std::numeric_limits<double>::infinity();
+    }
+    Builder &order(Order o) { b_.order = o; return *this; }
+    Builder &gain(Action a, double g) { b_.gain[a] = g; return *this; }
+    Builder &limit(Action a, double l) { b_.limit[a] = l; return *this; }
+    Builder &kp(double g) { return gain(P, g); }
+    Builder &ki(double g) { return gain(I, g); }
+    Builder &ki2(double g) { return gain(I2, g); }
+    Builder &kd(double g) { return gain(D, g); }
+    Builder &kd2(double g) { return gain(D2, g); }
+    Builder &limit_i(double l) { return limit(I, l); }
+    Builder &limit_i2(double l) { return limit(I2, l); }
+    Builder &limit_d(double l) { return limit(D, l); }
+    Builder &limit_d2(double l) { return limit(D2, l); }
+    /// `Build<Biquad<C>>::build(&period)` (pid.rs:256-328) / `try_build` (:225-232)
+    template <class C> Biquad<C> build(double period) const { return go<C>(period, 0); }
+    template <class C> Biquad<C> try_build(double period) const { return go<C>(period, 1); }
+    const idsp_pid_builder &abi() const { return b_; }
+
+private:
+    template <class C>
+    Biquad<C> go(double period, int validate) const
+    {
+        Biquad<C> out;
+        check(detail::OutOf<C>::pid(&b_, period, validate, out.ba.data()));
+        return out;
+    }
+    idsp_pid_builder b_{};
+};
+}  // namespace pid
+
+/// `pid::Pid<T>` (src/iir/pid.rs:384-431) == `config::PidConfig<T>`
+class Pid {
+public:
+    explicit Pid(bool f32 = false) : b_(f32) {}
+    Pid &order(pid::Order o) { b_.order(o); return *this; }
+    Pid &kp(double g) { b_.kp(g); return *this; }
+    Pid &ki(double g) { b_.ki(g); return *this; }
+    Pid &ki2(double g) { b_.ki2(g); return *this; }
+    Pid &kd(double g) { b_.kd(g); return *this; }
+    Pid &kd2(double g) { b_.kd2(g); return *this; }
+    Pid &limit_i(double l) { b_.limit_i(l); return *this; }
+    Pid &limit_i2(double l) { b_.limit_i2(l); return *this; }
+    Pid &limit_d(double l) { b_.limit_d(l); return *this; }
+    Pid &limit_d2(double l) { b_.limit_d2(l); return *this; }
+    Pid &setpoint(double s) { setpoint_ = s; return *this; }
+    Pid &output_limits(double mn, double mx) { min_ = mn, max_ = mx; return *this; }
+    /// `Build<BiquadClamp<C, Y>> for Pid<T>` (pid.rs:533-567) / `try_build` (:521-528)
+    template <class C> BiquadClamp<C> build(const Units &u) const { return go<C>(u, 0); }
+    template <class C> BiquadClamp<C> try_build(const Units &u) const { return go<C>(u, 1); }
+
+private:
+    template <class C>
+    BiquadClamp<C> go(const Units &u, int validate) const
+    {
+        const idsp_pid p{b_.abi(), setpoint_, min_, max_};
+        typename detail::OutOf<C>::Rec r;
+        check(detail::OutOf<C>::pid_clamp(&p, &u, validate, &r));
+        return detail::clamp_from<C>(r);
+    }
+    pid::Builder b_;
+    double setpoint_ = 0.0, min_ = -std::numeric_limits<double>::infinity(), max_ = std::numeric_limits<double>::infinity();
+};
+
+/// `BiquadConfig::Ba(BaConfig)` and `BiquadConfig::Filter(FilterConfig)` arms of
+/// `BiquadConfig::{build, try_build}` (src/iir/config.rs:355-430); the Pid arm is `Pid` above,
+/// the Raw arm is the `BiquadClamp` itself.
+template <class C>
+BiquadClamp<C> build_config(const idsp_ba_config &c, const Units &u, bool validate = false)
+{
+    typename detail::OutOf<C>::Rec r;
+    check(detail::OutOf<C>::ba(&c, &u, validate, &r));
+    return detail::clamp_from<C>(r);
+}
+template <class C>
+BiquadClamp<C> build_config(const idsp_filter_config &c, const Units &u, bool validate = false)
+{
+    typename detail::OutOf<C>::Rec r;
+    check(detail::OutOf<C>::filter(&c, &u, validate, &r));
+    return detail::clamp_from<C>(r);
 }
 
 /// Same-rate linear-phase FIR `type_fir!` (src/hbf.rs:70-138): OddSymmetric / EvenSymmetric /

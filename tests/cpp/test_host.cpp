@@ -170,6 +170,25 @@ int main()
         fir.process_view(View<float, LaneMajor>::from_flat(xi, 1), ViewMut<float, LaneMajor>::from_flat(yi, 1));
         EXPECT((yi.to_host() == std::vector<float>{0.25f, 0.5f, 0.5f, 0.25f, 0.0f, 0.0f}));
     }
+    // `ByLane<[Biquad<Q32<30>>; 3]>` (dsp-process/src/compose.rs:363-390): lane i == filter i run alone
+    {
+        std::vector<Biquad<Q32<30>>> bank;
+        for (double f0 : {0.02, 0.1, 0.3}) bank.push_back(Filter().critical_frequency(f0).build_biquad<Q32<30>>(IDSP_LOWPASS));
+        std::vector<int32_t> xs(3 * 50);
+        for (size_t i = 0; i < xs.size(); i++) xs[i] = int32_t((i * 2654435761u) >> 8) - (1 << 23);
+        DeviceBuffer<int32_t> x(xs), y(xs.size());
+        ByLane<Biquad<Q32<30>>, DirectForm1> bl(bank);
+        bl.block(x, y);
+        auto yh = y.to_host();
+        for (size_t l = 0; l < 3; l++) {
+            std::vector<int32_t> xl(50);
+            for (size_t f = 0; f < 50; f++) xl[f] = xs[f * 3 + l];
+            DeviceBuffer<int32_t> xd(xl), yd(50);
+            Split(bank[l], DirectForm1{}).lanes(1).block(xd, yd);
+            auto one = yd.to_host();
+            for (size_t f = 0; f < 50; f++) EXPECT(one[f] == yh[f * 3 + l]);
+        }
+    }
     // contract violations are reported as errors, never aborts
     {
         bool threw = false;

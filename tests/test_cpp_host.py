@@ -19,6 +19,14 @@ def test_cpp_host_layer_compiles_and_links():
     assert os.path.exists(exe)
 
 
+def test_cpp_coefficient_front_end_reference_tests():
+    """Filter / pid::Builder / Pid / build_config of idsp_hip.hpp: host code, no GPU needed."""
+    subprocess.run(["make", "-s", "build/test_coeff"], cwd=ROOT, check=True)
+    r = subprocess.run([os.path.join(ROOT, "build", "test_coeff")], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all coefficient front-end tests passed" in r.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_host_layer_reference_tests(gpu):
     exe = _build()

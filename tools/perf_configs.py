@@ -153,6 +153,39 @@ def dds(lanes, frames, layout, iters, tag):
     report(f"{tag}:dds {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample", 8 * lanes * frames, med, mn)
 
 
+def biquad_bylane(op, dtype, words, cv, lanes, frames, layout, n_sections, iters, tag):
+    """`ByLane<[Biquad; lanes]>`: a bank of lowpasses with per-lane corner frequencies (coefficient planes in HBM)."""
+    f0 = torch.rand(n_sections, 1, lanes, dtype=torch.float64) * 0.2 + 0.005
+    w0 = 2 * math.pi * f0
+    alpha = 0.5 * torch.sin(w0) * math.sqrt(2.0)
+    b = 0.5 * (1 - torch.cos(w0))
+    a0 = 1 + alpha
+    ba = torch.cat([b / a0, 2 * b / a0, b / a0, 2 * torch.cos(w0) / a0, -(1 - alpha) / a0], 1)
+    if dtype == torch.int32:
+        coef = torch.clamp(torch.round(ba * float(1 << 30)), -(1 << 31), (1 << 31) - 1).to(torch.int32)
+        extra = torch.tensor([3, -(1 << 30), 1 << 30], dtype=torch.int32)
+        x = torch.randint(-(1 << 24), 1 << 24, (lanes * frames,), dtype=torch.int32, device=dev)
+    else:
+        coef = ba.to(dtype)
+        extra = torch.tensor([0.01, -10.0, 10.0], dtype=dtype)
+        x = torch.randn(lanes * frames, dtype=dtype, device=dev)
+    if cv == 8:
+        coef = torch.cat([coef, extra.view(1, 3, 1).expand(n_sections, 3, lanes)], 1)
+    coef = coef.contiguous().to(dev)
+    y = torch.empty_like(x)
+    st = torch.zeros((words * n_sections, lanes), dtype=torch.int32, device=dev)
+    pre = (p(coef), 30) if dtype == torch.int32 else (p(coef),)
+
+    def run():
+        call(op + "_bylane", *pre, n_sections, p(st), p(x), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    esz = x.element_size()
+    passes = (n_sections + 1) // 2
+    report(f"{tag}:{op}_bylane x{n_sections} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample",
+           2 * esz * lanes * frames * passes + coef.numel() * esz, med, mn)
+
+
 def cossin(n, iters, tag):
     ph = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device=dev).to(torch.int32)
     out = torch.empty(2 * n, dtype=torch.int32, device=dev)
@@ -195,6 +228,15 @@ def main():
         biquad("biquad_i32_df1", torch.int32, 4, 65536, 4096, FM, 4, it, "C2v")
         biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, 4, it, "C2v")
         biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, 8, it, "C2v")
+    if want("bylane"):
+        for layout in (FM, LM):
+            biquad_bylane("biquad_i32_df1", torch.int32, 4, 5, 65536, 4096, layout, 1, it, "C2b")
+        biquad_bylane("biquad_i32_df1_clamp", torch.int32, 4, 8, 65536, 4096, FM, 1, it, "C2b")
+        biquad_bylane("biquad_i32_df1", torch.int32, 4, 5, 65536, 4096, FM, 2, it, "C2b")
+        biquad_bylane("biquad_i32_wide_clamp", torch.int32, 6, 8, 65536, 4096, FM, 1, it, "C2b")
+        biquad_bylane("biquad_f32_df2t", torch.float32, 2, 5, 65536, 4096, FM, 1, it, "C2b")
+        biquad_bylane("biquad_f32_df1_clamp", torch.float32, 4, 8, 65536, 4096, FM, 1, it, "C2b")
+        biquad_bylane("biquad_f32_df2t", torch.float32, 2, 5, 1 << 20, 4096, FM, 1, max(3, it // 3), "C5b")
     if want("f32"):
         for op, w in (("biquad_f32_df1", 4), ("biquad_f32_df2t", 2), ("biquad_f32_df1_clamp", 4), ("biquad_f32_df2t_clamp", 2)):
             for layout in (FM, LM):
