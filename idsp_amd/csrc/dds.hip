@@ -22,7 +22,16 @@ __device__ const uint32_t d_cossin_table[1 << kCossinDepth] = {
 #undef T8
 };
 
-constexpr size_t kSplitMaxLanes = 40960;  // split only while it fills SIMDs that would otherwise have no wave (measured: no gain beyond)
+// Largest lane count that still runs the I and Q arms on two threads (IDSP_SPLIT_MAX_LANES overrides).
+inline size_t split_max_lanes()
+{
+    static const size_t v = [] {
+        const char *e = getenv("IDSP_SPLIT_MAX_LANES");
+        return e ? size_t(strtoull(e, nullptr, 10)) : size_t(40960);
+    }();
+    return v;
+}
+#define kSplitMaxLanes split_max_lanes()
 
 struct Cplx {
     int32_t re, im;
@@ -122,6 +131,9 @@ struct LpBank {
         return x;
     }
 };
+
+// value of the other thread of an adjacent-thread pair (v_mov_b32 quad_perm:[1,0,3,2])
+__device__ __forceinline__ int32_t pair_swap(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
 
 // ------------------------------------------------------------- processors
 template <int N, int K>
@@ -253,6 +265,22 @@ struct LockinSplitProc {
         const Cplx lo = cossin_dev(int32_t(acc), lut);
         return q ? lo.im : lo.re;
     }
+    // The two threads of a lane evaluate the LO of alternate frames (thread q: frames 2j + q) and
+    // swap the component the partner needs with one DPP move: 16 instead of 32 cossin
+    // instructions per frame and thread on a VALU-bound kernel.
+    __device__ __forceinline__ void pre_batch(const Params &, Pre (&out)[BATCH])
+    {
+#pragma unroll
+        for (int j = 0; j < BATCH / 2; j++) {
+            const uint32_t ph = acc + inc * uint32_t(2 * j + 1) + (q ? inc : 0u);
+            const Cplx lo = cossin_dev(int32_t(ph), lut);
+            const int32_t mine = q ? lo.im : lo.re, other = q ? lo.re : lo.im;
+            const int32_t recv = pair_swap(other);
+            out[2 * j] = q ? recv : mine;
+            out[2 * j + 1] = q ? mine : recv;
+        }
+        acc += inc * uint32_t(BATCH);
+    }
     __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo) { return b.step(p, __mulhi(lo, x)); }
 };
 
@@ -288,6 +316,19 @@ struct DdsSplitProc {
         acc += inc;
         const Cplx c = cossin_dev(int32_t(acc), lut);
         return q ? c.im : c.re;
+    }
+    __device__ __forceinline__ void pre_batch(const Params &, Pre (&out)[BATCH])
+    {
+#pragma unroll
+        for (int j = 0; j < BATCH / 2; j++) {
+            const uint32_t ph = acc + inc * uint32_t(2 * j + 1) + (q ? inc : 0u);
+            const Cplx c = cossin_dev(int32_t(ph), lut);
+            const int32_t mine = q ? c.im : c.re, other = q ? c.re : c.im;
+            const int32_t recv = pair_swap(other);
+            out[2 * j] = q ? recv : mine;
+            out[2 * j + 1] = q ? mine : recv;
+        }
+        acc += inc * uint32_t(BATCH);
     }
     __device__ __forceinline__ Out step(const Params &, In, const Pre &v) { return v; }
 };

@@ -56,6 +56,24 @@ struct BatchOf<P, std::void_t<decltype(P::BATCH)>> {
     static constexpr int value = P::BATCH;
 };
 
+// BATCH pre-stage values: processors may provide pre_batch(prm, Pre (&)[BATCH]) (e.g. to share
+// the work between the IN_DIV threads of a lane); the default evaluates pre() BATCH times.
+template <class P, class = void>
+struct HasPreBatch : std::false_type {};
+template <class P>
+struct HasPreBatch<P, std::void_t<decltype(&P::pre_batch)>> : std::true_type {};
+
+template <class P, int B>
+__device__ __forceinline__ void pre_all(P &p, const typename P::Params &prm, typename P::Pre (&pre)[B])
+{
+    if constexpr (HasPreBatch<P>::value) {
+        p.pre_batch(prm, pre);
+    } else {
+#pragma unroll
+        for (int b = 0; b < B; b++) pre[b] = p.pre(prm);
+    }
+}
+
 // one sample through processors with or without a state-independent pre-stage
 template <class P>
 __device__ __forceinline__ typename P::Out step1(P &p, const typename P::Params &prm, typename P::In v)
@@ -164,8 +182,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
             for (int u0 = 0; u0 < U; u0 += B) {
                 if constexpr (B > 1) {
                     typename P::Pre pre[B];
-#pragma unroll
-                    for (int b = 0; b < B; b++) pre[b] = p.pre(prm);
+                    pre_all<P, B>(p, prm, pre);
 #pragma unroll
                     for (int b = 0; b < B; b++) {
                         const int u = u0 + b;
@@ -203,8 +220,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
         if constexpr (B > 1) {
             for (; f + B <= frames; f += B) {
                 typename P::Pre pre[B];
-#pragma unroll
-                for (int b = 0; b < B; b++) pre[b] = p.pre(prm);
+                pre_all<P, B>(p, prm, pre);
 #pragma unroll
                 for (int b = 0; b < B; b++) nt_store<kNT>(yp + size_t(b) * lanes, p.step(prm, In{}, pre[b]));
                 yp += size_t(B) * lanes;
