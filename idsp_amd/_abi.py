@@ -64,6 +64,10 @@ class LockinI32(C.Structure):
     _fields_ = [("order", C.c_int32), ("cascade", C.c_int32), ("k", (C.c_int32 * 2) * LOCKIN_MAX_CASCADE)]
 
 
+class Cic(C.Structure):
+    _fields_ = [("order", C.c_int32), ("comb_delay", C.c_int32), ("rate", C.c_uint32)]
+
+
 class Filter(C.Structure):
     _fields_ = [("frequency", C.c_double), ("gain", C.c_double), ("shelf", C.c_double), ("shape", C.c_double),
                 ("shape_kind", C.c_int32), ("f32", C.c_int32)]
@@ -144,6 +148,10 @@ PROCESSING = {
     "hbf_dec_f32": _CFG_SIG,
     "hbf_int_f32": _CFG_SIG,
     "fir_sym_f32_process": _CFG_SIG,
+    "cic_dec_i32": _CFG_SIG,
+    "cic_dec_i64": _CFG_SIG,
+    "cic_int_i32": _CFG_SIG,
+    "cic_int_i64": _CFG_SIG,
     "cossin_i32": [_P, _P, _SZ, _P],
     "atan2_i32": [_P, _P, _SZ, _P],
     "dds_i32": [_P, _P, _SZ, _SZ, _I, _P],
@@ -165,6 +173,10 @@ HELPERS = {
     "hbf_int_state_words": (_SZ, [_P]),
     "lockin_state_words": (_SZ, [_P]),
     "fir_sym_state_words": (_SZ, [_P]),
+    "cic_gain": (C.c_int64, [_P]),
+    "cic_gain_log2": (_I, [_P]),
+    "cic_response_length": (_SZ, [_P]),
+    "cic_state_words": (_SZ, [_P, _I]),
 }
 
 _D = C.c_double

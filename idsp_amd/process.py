@@ -19,6 +19,7 @@ own:
                                                          .process_view(View(...), ViewMut(...))
     HBF_DEC_CASCADE / HbfDec16 ...       (hbf.rs:363-421) HbfDecCascade(stages).lanes(N)
     Lockin<[Lowpass<N>; K]>, Accu        (lockin.rs, accu.rs) Lockin([...]).lanes(N, step=...)
+    Split::stateful(Cic::new(rate)).decimate() (cic.rs:338) Cic(N, rate).decimate().lanes(n)
     cossin(phase)                        (cossin.rs:14)  cossin(phases)
     atan2(y, x) / Complex::arg           (atan2.rs:66)   atan2(xy)
 
@@ -41,7 +42,7 @@ from ._lib import IdspError, call, load
 __all__ = [
     "FrameMajor", "LaneMajor", "View", "ViewMut", "Biquad", "BiquadClamp", "Cascade",
     "DirectForm1", "DirectForm2Transposed", "DirectForm1Wide", "DirectForm1Dither", "DirectForm",
-    "Split", "Lanes", "ByLane", "HbfDecCascade", "HbfIntCascade", "FirSym", "HBF_TAPS", "HBF_TAPS_98",
+    "Split", "Lanes", "ByLane", "HbfDecCascade", "HbfIntCascade", "FirSym", "Cic", "HBF_TAPS", "HBF_TAPS_98",
     "Lowpass", "Lockin", "Accu", "Dds", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
 ]
 
@@ -521,6 +522,69 @@ class FirSym(_LaneOp):
 
     def _run(self, x, y, frames, layout):
         call("fir_sym_f32_process", C.byref(self.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
+             C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
+
+
+class Cic:
+    """`Cic<T, N, M>::new(rate)` (src/cic.rs:13-47) with T = i64 (default) or i32.  `.decimate()` /
+    `.interpolate()` give the chunked processors of src/cic.rs:338-346, `.lanes(n)` puts n of them on the GPU."""
+
+    def __init__(self, order: int, rate: int, comb_delay: int = 1, dtype=torch.int64):
+        load()
+        if dtype not in (torch.int32, torch.int64):
+            raise ValueError("Cic<T>: T is i32 or i64")
+        self.cfg = _abi.Cic(int(order), int(comb_delay), int(rate))
+        self.dtype = dtype
+        if call("cic_state_words", C.byref(self.cfg), 64) == 0:
+            raise ValueError("Cic: order 1..6, comb delay 1..4 (src/cic.rs:36: must be non-zero)")
+
+    def order(self) -> int:  # cic.rs:57-59
+        return self.cfg.order
+
+    def comb_delay(self) -> int:  # cic.rs:62-64
+        return self.cfg.comb_delay
+
+    def rate(self) -> int:  # cic.rs:69-71
+        return self.cfg.rate
+
+    def gain(self) -> int:
+        """`Cic::gain()` (cic.rs:103-105) in T (wrapping)"""
+        g = call("cic_gain", C.byref(self.cfg))
+        return g if self.dtype == torch.int64 else ((g + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)
+
+    def gain_log2(self) -> int:  # cic.rs:111-113
+        return call("cic_gain_log2", C.byref(self.cfg))
+
+    def response_length(self) -> int:  # cic.rs:116-118
+        return call("cic_response_length", C.byref(self.cfg))
+
+    def decimate(self) -> "_CicLanes":
+        """`Split::stateful(cic).decimate()`: `Process<[T; R], T>`, R = rate + 1"""
+        return _CicLanes(self, True)
+
+    def interpolate(self) -> "_CicLanes":
+        """`Split::stateful(cic).interpolate()`: `Process<T, [T; R]>`"""
+        return _CicLanes(self, False)
+
+
+class _CicLanes(_LaneOp):
+    def __init__(self, cic: Cic, dec: bool):
+        self.cic, self._dec = cic, dec
+        self.dtype_in = self.dtype_out = cic.dtype
+        r = cic.cfg.rate + 1
+        self.in_width, self.out_width = (r, 1) if dec else (1, r)
+        self._name = ("cic_dec_" if dec else "cic_int_") + ("i64" if cic.dtype == torch.int64 else "i32")
+
+    def lanes(self, n: int, device="cuda") -> "_CicLanes":
+        words = call("cic_state_words", C.byref(self.cic.cfg), 64 if self.cic.dtype == torch.int64 else 32)
+        _LaneOp.__init__(self, n, words, device)
+        return self
+
+    def inplace(self, xy):
+        raise ValueError("a rate changer has no in-place form")
+
+    def _run(self, x, y, frames, layout):
+        call(self._name, C.byref(self.cic.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
              C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
 
 

@@ -292,6 +292,49 @@ int idsp_biquad_f64_df2t_clamp_bylane(const double *coef, size_t n, void *state,
         const double *x, double *y, size_t lanes, size_t frames, int layout, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Cic — cascaded integrator-comb rate changer (src/cic.rs)                 */
+/* ------------------------------------------------------------------------ */
+
+#define IDSP_CIC_MAX_ORDER 6
+#define IDSP_CIC_MAX_DELAY 4
+
+/* `Cic<T, N, M>::new(rate)` (src/cic.rs:13-28,39-47): order N (1..6), comb delay M
+ * (1..4), rate = fast/slow - 1.  T = i32 or i64 is chosen by the entry point. */
+typedef struct idsp_cic {
+    int32_t order;
+    int32_t comb_delay;
+    uint32_t rate;
+} idsp_cic;
+
+/* `Cic::gain()` as i64 (wrapping), `gain_log2()`, `response_length()` (src/cic.rs:103-118);
+ * gain_log2 / response_length return a negative idsp_status / 0 for an invalid cfg. */
+int64_t idsp_cic_gain(const idsp_cic *cfg);
+int idsp_cic_gain_log2(const idsp_cic *cfg);
+size_t idsp_cic_response_length(const idsp_cic *cfg);
+/* 32-bit state words per lane for T of `bits` (32 or 64) width; 0 for an invalid cfg.
+ * Values in order: zoh, combs[N][M] (row n = comb n, oldest first), integrators[N];
+ * a 64-bit value is two words, low first; planes are lane-contiguous like every state.
+ * `index` is not part of the record: the chunked entries below start and end every call
+ * at index == 0 (`tick()`), the only phase `Decimator` / `Interpolator` accept. */
+size_t idsp_cic_state_words(const idsp_cic *cfg, int bits);
+
+/* `Split::stateful(Cic::<T, N, M>::new(R - 1)).decimate()` (src/cic.rs:338-341; `Process<T, Option<T>>`
+ * :186-207 under `Decimator`, dsp-process/src/adapters.rs:158-167): x holds `frames` chunks `[T; R]`
+ * per lane (R = rate + 1; FRAME_MAJOR x[(f*lanes + l)*R + r], LANE_MAJOR x[(l*frames + f)*R + r]),
+ * y one sample per chunk.  Integrators and combs wrap (cic.rs:191,199). */
+int idsp_cic_dec_i32(const idsp_cic *cfg, void *state, const int32_t *x, int32_t *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+int idsp_cic_dec_i64(const idsp_cic *cfg, void *state, const int64_t *x, int64_t *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+/* `...interpolate()` (src/cic.rs:343-346; `Process<Option<T>, T>` :160-182 under `Interpolator`,
+ * adapters.rs:27-35): one input sample per frame, y holds chunks `[T; R]`.  Release-mode
+ * (wrapping) arithmetic; the reference's debug build would panic on overflow (cic.rs:177). */
+int idsp_cic_int_i32(const idsp_cic *cfg, void *state, const int32_t *x, int32_t *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+int idsp_cic_int_i64(const idsp_cic *cfg, void *state, const int64_t *x, int64_t *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* coefficient front-end (host side, no device work)                        */
 /* ------------------------------------------------------------------------ */
 /*

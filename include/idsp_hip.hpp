@@ -18,6 +18,7 @@
 //   Lockin<[Lowpass<N>; K]> + Accu      (lockin.rs, accu.rs)    Lockin<N, K>
 //   ByLane<[C; N]>                      (compose.rs:363)        ByLane<Cfg, S>(configs)
 //   coefficients::Filter, pid::Builder, Pid, Units (iir/coefficients.rs, iir/pid.rs)  Filter, pid::Builder, Pid, Units
+//   Split::stateful(Cic::new(rate)).decimate()/.interpolate() (cic.rs:338-346)  CicDecimator<T> / CicInterpolator<T>
 //   cossin(phase)                       (cossin.rs:14)          cossin(phases, out)
 //   atan2(y, x) / Complex::arg          (atan2.rs:66)           atan2(xy, out)
 //
@@ -31,6 +32,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -742,6 +744,45 @@ private:
 };
 using HbfDecCascade = HbfCascade<true>;
 using HbfIntCascade = HbfCascade<false>;
+
+/// `Cic<T, N, M>::new(rate)` (src/cic.rs:13-47), T = int32_t or int64_t, chunked as
+/// `Split::stateful(cic).decimate()` / `.interpolate()` (src/cic.rs:338-346) over `lanes` lanes.
+template <class T, bool DEC>
+class CicLanes {
+    static_assert(std::is_same<T, int32_t>::value || std::is_same<T, int64_t>::value, "Cic<T>: T is i32 or i64");
+
+public:
+    CicLanes(int order, uint32_t rate, size_t lanes, int comb_delay = 1, void *stream = nullptr)
+        : cfg_{order, comb_delay, rate}, lanes_(lanes), stream_(stream)
+    {
+        const size_t words = idsp_cic_state_words(&cfg_, int(sizeof(T) * 8));
+        require(words > 0, "Cic: order 1..6, comb delay 1..4");
+        state_ = DeviceBuffer<uint32_t>(words * lanes);
+    }
+    int64_t gain() const { return std::is_same<T, int64_t>::value ? idsp_cic_gain(&cfg_) : int64_t(int32_t(idsp_cic_gain(&cfg_))); }
+    int gain_log2() const { return idsp_cic_gain_log2(&cfg_); }                 // cic.rs:111-113
+    size_t response_length() const { return idsp_cic_response_length(&cfg_); }  // cic.rs:116-118
+    size_t chunk() const { return size_t(cfg_.rate) + 1; }                      // R
+    DeviceBuffer<uint32_t> &state() { return state_; }
+    /// x: chunks `[T; R]` (decimator) or samples (interpolator); y the other
+    template <class Layout>
+    void process_view(View<T, Layout> x, ViewMut<T, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        if constexpr (std::is_same<T, int64_t>::value)
+            check((DEC ? idsp_cic_dec_i64 : idsp_cic_int_i64)(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+        else
+            check((DEC ? idsp_cic_dec_i32 : idsp_cic_int_i32)(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
+
+private:
+    idsp_cic cfg_;
+    size_t lanes_;
+    void *stream_;
+    DeviceBuffer<uint32_t> state_;
+};
+template <class T> using CicDecimator = CicLanes<T, true>;
+template <class T> using CicInterpolator = CicLanes<T, false>;
 
 // ------------------------------------------------------------ DDS / lock-in
 /// `cossin(p: i32[N]) -> i32[N, 2]` (src/py.rs:10-28)

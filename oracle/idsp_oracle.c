@@ -890,6 +890,112 @@ int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n)
     return IDSP_OK;
 }
 
+/* -------------------------------------------------------------------- Cic */
+/* `Cic<T, N, M>` (src/cic.rs); per-lane state values: zoh, combs[N][M], integrators[N]. */
+static int cic_ok(const idsp_cic *c)
+{
+    return c && c->order >= 1 && c->order <= IDSP_CIC_MAX_ORDER && c->comb_delay >= 1 && c->comb_delay <= IDSP_CIC_MAX_DELAY;
+}
+int64_t idsp_ref_cic_gain(const idsp_cic *c)
+{
+    if (!cic_ok(c)) return 0;
+    uint64_t b = (uint64_t)c->comb_delay * ((uint64_t)c->rate + 1), g = 1; /* cic.rs:103-105 */
+    for (int i = 0; i < c->order; i++) g *= b;
+    return (int64_t)g;
+}
+int idsp_ref_cic_gain_log2(const idsp_cic *c)
+{
+    if (!cic_ok(c)) return IDSP_EINVAL;
+    uint32_t v = (uint32_t)c->comb_delay * c->rate + (uint32_t)(c->comb_delay - 1); /* cic.rs:111-113 */
+    return (v ? 32 - __builtin_clz(v) : 0) * c->order;
+}
+size_t idsp_ref_cic_response_length(const idsp_cic *c) { return cic_ok(c) ? (size_t)c->rate * (size_t)c->order : 0; }
+size_t idsp_ref_cic_state_words(const idsp_cic *c, int bits)
+{
+    if (!cic_ok(c) || (bits != 32 && bits != 64)) return 0;
+    return (size_t)(1 + c->order * c->comb_delay + c->order) * (size_t)(bits / 32);
+}
+
+#define CIC_IMPL(SUF, T, UT, VW)                                                                        \
+    static T cic_ld_##SUF(const uint32_t *st, size_t lanes, size_t l, int v)                             \
+    {                                                                                                   \
+        UT u = 0;                                                                                       \
+        for (int w = 0; w < VW; w++) u |= (UT)st[(size_t)(v * VW + w) * lanes + l] << (32 * w);         \
+        return (T)u;                                                                                    \
+    }                                                                                                   \
+    static void cic_st_##SUF(uint32_t *st, size_t lanes, size_t l, int v, T x)                           \
+    {                                                                                                   \
+        for (int w = 0; w < VW; w++) st[(size_t)(v * VW + w) * lanes + l] = (uint32_t)((UT)x >> (32 * w)); \
+    }                                                                                                   \
+    /* cic.rs:166-171 / 197-203 */                                                                      \
+    static T cic_combs_##SUF(T *comb, int n_, int m, T x)                                                \
+    {                                                                                                   \
+        for (int n = 0; n < n_; n++) {                                                                  \
+            T *c = comb + n * m;                                                                        \
+            T y = (T)((UT)x - (UT)c[0]);                                                                \
+            memmove(c, c + 1, (size_t)(m - 1) * sizeof(T));                                             \
+            c[m - 1] = x;                                                                               \
+            x = y;                                                                                      \
+        }                                                                                               \
+        return x;                                                                                       \
+    }                                                                                                   \
+    static T cic_integ_##SUF(T *integ, int n_, T x)                                                      \
+    {                                                                                                   \
+        for (int n = 0; n < n_; n++) { integ[n] = (T)((UT)integ[n] + (UT)x); x = integ[n]; }            \
+        return x;                                                                                       \
+    }                                                                                                   \
+    static int cic_run_##SUF(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes,           \
+                             size_t frames, int layout, int dec)                                        \
+    {                                                                                                   \
+        if (!cic_ok(cfg)) return IDSP_EINVAL;                                                           \
+        int rc = check_common(cfg, 1, state, x, y, lanes, frames, layout);                              \
+        if (rc) return rc;                                                                              \
+        uint32_t *st = (uint32_t *)state;                                                               \
+        const int N = cfg->order, M = cfg->comb_delay;                                                  \
+        const size_t R = (size_t)cfg->rate + 1;                                                         \
+        for (size_t l = 0; l < lanes; l++) {                                                            \
+            T zoh = cic_ld_##SUF(st, lanes, l, 0), comb[IDSP_CIC_MAX_ORDER * IDSP_CIC_MAX_DELAY],       \
+              integ[IDSP_CIC_MAX_ORDER];                                                                \
+            for (int i = 0; i < N * M; i++) comb[i] = cic_ld_##SUF(st, lanes, l, 1 + i);                \
+            for (int i = 0; i < N; i++) integ[i] = cic_ld_##SUF(st, lanes, l, 1 + N * M + i);           \
+            uint32_t index = 0;                                                                         \
+            for (size_t f = 0; f < frames; f++) {                                                       \
+                size_t lo = idx_of(f, l, lanes, frames, layout);                                        \
+                if (dec) { /* Process<T, Option<T>>, cic.rs:186-207 */                                  \
+                    int ticks = 0;                                                                      \
+                    for (size_t r = 0; r < R; r++) {                                                    \
+                        T v = cic_integ_##SUF(integ, N, x[lo * R + r]);                                 \
+                        if (index > 0) { index--; continue; }                                           \
+                        index = cfg->rate;                                                              \
+                        zoh = cic_combs_##SUF(comb, N, M, v);                                           \
+                        y[lo] = zoh;                                                                    \
+                        ticks++;                                                                        \
+                    }                                                                                   \
+                    if (ticks != 1) return IDSP_EINVAL; /* Decimator: exactly one tick per chunk */     \
+                } else { /* Process<Option<T>, T>, cic.rs:160-182 */                                    \
+                    for (size_t r = 0; r < R; r++) {                                                    \
+                        if (r == 0) { index = cfg->rate; zoh = cic_combs_##SUF(comb, N, M, x[lo]); }    \
+                        else index--;                                                                   \
+                        y[lo * R + r] = cic_integ_##SUF(integ, N, zoh);                                 \
+                    }                                                                                   \
+                }                                                                                       \
+            }                                                                                           \
+            cic_st_##SUF(st, lanes, l, 0, zoh);                                                         \
+            for (int i = 0; i < N * M; i++) cic_st_##SUF(st, lanes, l, 1 + i, comb[i]);                 \
+            for (int i = 0; i < N; i++) cic_st_##SUF(st, lanes, l, 1 + N * M + i, integ[i]);            \
+        }                                                                                               \
+        return IDSP_OK;                                                                                 \
+    }                                                                                                   \
+    int idsp_ref_cic_dec_##SUF(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes,         \
+                               size_t frames, int layout)                                               \
+    { return cic_run_##SUF(cfg, state, x, y, lanes, frames, layout, 1); }                               \
+    int idsp_ref_cic_int_##SUF(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes,         \
+                               size_t frames, int layout)                                               \
+    { return cic_run_##SUF(cfg, state, x, y, lanes, frames, layout, 0); }
+
+CIC_IMPL(i32, int32_t, uint32_t, 1)
+CIC_IMPL(i64, int64_t, uint64_t, 2)
+
 /* ------------------------------------------------------------------ atan2 */
 static uint32_t g_atan2_base[16];
 static int32_t g_atan2_slope[16];

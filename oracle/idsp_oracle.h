@@ -114,6 +114,15 @@ size_t idsp_ref_fir_sym_state_words(const idsp_fir_sym_f32 *cfg);
 int idsp_ref_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const float *x, float *y,
                                  size_t lanes, size_t frames, int layout);
 
+/* Cic (src/cic.rs) */
+int64_t idsp_ref_cic_gain(const idsp_cic *cfg);
+int idsp_ref_cic_gain_log2(const idsp_cic *cfg);
+size_t idsp_ref_cic_response_length(const idsp_cic *cfg);
+size_t idsp_ref_cic_state_words(const idsp_cic *cfg, int bits);
+int idsp_ref_cic_dec_i32(const idsp_cic *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_cic_dec_i64(const idsp_cic *cfg, void *state, const int64_t *x, int64_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_cic_int_i32(const idsp_cic *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_cic_int_i64(const idsp_cic *cfg, void *state, const int64_t *x, int64_t *y, size_t lanes, size_t frames, int layout);
 int32_t idsp_ref_atan2(int32_t y, int32_t x);
 int idsp_ref_atan2_i32(const int32_t *xy, int32_t *out, size_t n);
 int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n);

@@ -531,6 +531,118 @@ def atan2(y: int, x: int) -> int:
 
 
 # ----------------------------------------------------------------------------
+# Cic (src/cic.rs) and the modular composition its tests compare it with
+# ----------------------------------------------------------------------------
+class Cic:
+    """`Cic<T, N, M>` (src/cic.rs:13-28) with T = i32 or i64 (`bits`), release (wrapping) arithmetic."""
+
+    def __init__(self, order: int, comb_delay: int, rate: int, bits: int = 64):
+        assert comb_delay > 0, "Comb delay must be non-zero"  # cic.rs:36
+        self.n, self.m, self.rate, self.bits = order, comb_delay, rate, bits
+        self.index, self.zoh = 0, 0
+        self.combs = [[0] * comb_delay for _ in range(order)]
+        self.integrators = [0] * order
+
+    def _w(self, v):
+        return wrap(v, self.bits)
+
+    def tick(self):  # cic.rs:88-90
+        return self.index == 0
+
+    def gain(self):  # cic.rs:103-105
+        return self._w((self.m * (self.rate + 1)) ** self.n)
+
+    def gain_log2(self):  # cic.rs:111-113
+        return (self.m * self.rate + self.m - 1).bit_length() * self.n
+
+    def response_length(self):  # cic.rs:116-118
+        return self.rate * self.n
+
+    def _combs(self, x):  # cic.rs:166-171 / :197-203
+        for c in self.combs:
+            y = self._w(x - c[0])
+            c[:] = c[1:] + [x]
+            x = y
+        return x
+
+    def interpolate(self, x):
+        """`Process<Option<T>, T>` (cic.rs:160-182); x = None or a sample"""
+        if x is not None:
+            assert self.index == 0
+            self.index = self.rate
+            self.zoh = self._combs(x)
+        else:
+            self.index -= 1
+        v = self.zoh
+        for i in range(self.n):
+            self.integrators[i] = self._w(self.integrators[i] + v)
+            v = self.integrators[i]
+        return v
+
+    def decimate(self, x):
+        """`Process<T, Option<T>>` (cic.rs:186-207)"""
+        for i in range(self.n):
+            self.integrators[i] = self._w(self.integrators[i] + x)
+            x = self.integrators[i]
+        if self.index > 0:
+            self.index -= 1
+            return None
+        self.index = self.rate
+        self.zoh = self._combs(x)
+        return self.zoh
+
+
+def cic_modular_decimator(order: int, r: int, m: int, chunks, bits: int = 64):
+    """src/cic.rs:313-320: `Integrator` x N (dsp-process/src/basic.rs:457-466) -> `Downsample(R - 1)`
+    (adapters.rs:71-83) -> `Comb<[T; M]>` x N (basic.rs:475-486) under `Decimator` (adapters.rs:158-167)."""
+    ints, ds, combs = [0] * order, 0, [[0] * m for _ in range(order)]
+    out = []
+    for chunk in chunks:
+        assert len(chunk) == r
+        y = None
+        for x in chunk:
+            for i in range(order):
+                ints[i] = wrap(ints[i] + x, bits)
+                x = ints[i]
+            if ds > 0:
+                ds -= 1
+                continue
+            ds = r - 1
+            for c in combs:
+                v = wrap(x - c[m - 1], bits)
+                c[:] = [x] + c[:m - 1]
+                x = v
+            assert y is None  # exactly one tick per chunk
+            y = x
+        out.append(y)
+    return out
+
+
+def cic_modular_interpolator(order: int, r: int, m: int, xs, bits: int = 64):
+    """src/cic.rs:330-336: `Comb` x N (mapped over Option) -> `Hold` (adapters.rs:109-118) -> `Integrator` x N
+    under `Interpolator` (adapters.rs:27-35)."""
+    combs, hold, ints = [[0] * m for _ in range(order)], 0, [0] * order
+    out = []
+    for x in xs:
+        row = []
+        for k in range(r):
+            if k == 0:
+                v = x
+                for c in combs:
+                    w = wrap(v - c[m - 1], bits)
+                    c[:] = [v] + c[:m - 1]
+                    v = w
+                hold = v
+            v = hold
+            for i in range(order):
+                ints[i] = wrap(ints[i] + v, bits)
+                v = ints[i]
+            row.append(v)
+        out.append(row)
+    return out
+
+
+# ----------------------------------------------------------------------------
 # Accu, Lowpass, Lockin
 # ----------------------------------------------------------------------------
 class Accu:

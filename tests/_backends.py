@@ -110,9 +110,9 @@ class GpuBackend:
     def cfgcall(self, op, cfg, state, x, y_shape, y_dtype, lanes, frames, layout):
         torch = self.torch
         xs = self._up(x)
-        tdt = torch.float32 if y_dtype == np.float32 else torch.int32
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int64): torch.int64}.get(np.dtype(y_dtype), torch.int32)
         ys = torch.empty(int(np.prod(y_shape)), dtype=tdt, device=self.dev)
-        ys.fill_(float("nan") if tdt == torch.float32 else -77)
+        ys.fill_(float("nan") if tdt == torch.float32 else -77)  # poison: every element must be written
         ss = self._up(state)
         rc = self.e.cfgcall(op, cfg, ss, xs, ys, lanes, frames, layout)
         torch.cuda.synchronize()

@@ -279,6 +279,82 @@ def case_atan2_small(be):
     assert rc == 0 and np.abs(out * scale - want).max() < e["abs_err"]
 
 
+def _cic(be, kind, cfg, x, lanes, frames, layout, state=None, dtype=np.int64):
+    """kind 'dec' / 'int'; returns (y, state)."""
+    R = cfg.rate + 1
+    bits = 64 if dtype == np.int64 else 32
+    words = be.helper("cic_state_words", C.byref(cfg), bits)
+    st = np.zeros((words, lanes), np.uint32) if state is None else state
+    suffix = "i64" if dtype == np.int64 else "i32"
+    n_out = lanes * frames * (1 if kind == "dec" else R)
+    rc, y = be.cfgcall(f"cic_{kind}_{suffix}", cfg, st, np.asarray(x, dtype), (n_out,), dtype, lanes, frames, layout)
+    assert rc == 0
+    return y, st
+
+
+def case_cic_identity_and_unit_rate(be):
+    """src/cic.rs:223-240,286-306"""
+    e = KAT["cic"]["identity"]
+    cfg = _abi.Cic(e["order"], e["comb_delay"], e["rate"])
+    rng = np.random.default_rng(12)
+    x = rng.integers(-(1 << 62), 1 << 62, size=200, dtype=np.int64)
+    y, st = _cic(be, "dec", cfg, x, 1, 200, LM)
+    assert np.array_equal(y, x)
+    assert int(st[0, 0]) | (int(st[1, 0]) << 32) == int(x[-1]) & 0xFFFFFFFFFFFFFFFF  # get_decimate() == zoh
+    y, _ = _cic(be, "int", cfg, x >> 3, 1, 200, LM)
+    assert np.array_equal(y, x >> 3)
+    u = KAT["cic"]["unit_rate"]
+    cfg = _abi.Cic(u["order"], u["comb_delay"], u["rate"])
+    assert be.helper("cic_gain_log2", C.byref(cfg)) == u["gain_log2"] and be.helper("cic_gain", C.byref(cfg)) == u["gain"]
+    x = np.concatenate([rng.integers(-(1 << 31), 1 << 31, size=5), np.zeros(100, np.int64)]).astype(np.int64)
+    y, st = _cic(be, "dec", cfg, x, 1, x.size, LM)
+    assert np.all(y[5 + u["order"] * u["comb_delay"]:] == 0)  # FIR of length N * (M - 1) + 1 <= 9 flushed
+
+
+def case_cic_step_response(be):
+    """src/cic.rs:242-262 with the chunked interpolator: one Some(x) per tick, R outputs per input."""
+    e = KAT["cic"]["step"]
+    for rate in e["rates"]:
+        cfg = _abi.Cic(e["order"], e["comb_delay"], rate)
+        shift = be.helper("cic_gain_log2", C.byref(cfg))
+        gain = be.helper("cic_gain", C.byref(cfg))
+        assert shift < 32 and gain <= 1 << shift
+        resp = be.helper("cic_response_length", C.byref(cfg))
+        assert resp == rate * e["order"]
+        R = rate + 1
+        chunks = -(-2 * resp // R) + 1
+        st, y_last = None, 0
+        for xv in e["x"]:
+            y, st = _cic(be, "int", cfg, np.full(chunks, xv, np.int64), 1, chunks, LM, state=st)
+            want = xv * gain
+            for i, v in enumerate(y.tolist()):
+                if i < resp:
+                    if want > y_last:
+                        assert y_last <= v < want
+                    elif want < y_last:
+                        assert want <= v - 1 < y_last
+                    else:
+                        assert v == want
+                else:
+                    assert v == want
+            y_last = int(y[-1])
+
+
+def case_cic_modular_composition(be):
+    """src/cic.rs:348-383: Cic == Integrator^N -> Downsample -> Comb^N (and the interpolating dual)."""
+    from oracle import spec
+
+    xd = [v * 3 - 7 for v in range(-31, 65)]
+    xi = [v * v - 3 * v + 2 for v in range(-12, 20)]
+    for n, r, m in KAT["cic"]["modular"]["cases"]:
+        cfg = _abi.Cic(n, m, r - 1)
+        frames = len(xd) // r
+        y, _ = _cic(be, "dec", cfg, xd[:frames * r], 1, frames, LM)
+        assert y.tolist() == spec.cic_modular_decimator(n, r, m, [xd[i * r:(i + 1) * r] for i in range(frames)])
+        y, _ = _cic(be, "int", cfg, xi, 1, len(xi), LM)
+        assert y.reshape(len(xi), r).tolist() == spec.cic_modular_interpolator(n, r, m, xi)
+
+
 def case_accu(be):
     e = KAT["accu"]
     st = np.array([[e["state"]], [e["step"]]], dtype=np.int64).astype(np.uint32)

@@ -189,6 +189,22 @@ int main()
             for (size_t f = 0; f < 50; f++) EXPECT(one[f] == yh[f * 3 + l]);
         }
     }
+    // src/cic.rs:223-240 (rate 0 is the identity) and :286-306 (Cic<i64, 3, 3>: gain_log2 6, gain 27)
+    {
+        CicDecimator<int64_t> id(3, 0, 1);
+        DeviceBuffer<int64_t> x(std::vector<int64_t>{5, -7, 1ll << 40, -(1ll << 50)}), y(4);
+        id.process_view(View<int64_t, LaneMajor>::from_flat(x, 1), ViewMut<int64_t, LaneMajor>::from_flat(y, 1));
+        EXPECT(y.to_host() == x.to_host());
+        CicDecimator<int64_t> unit(3, 0, 1, 3);
+        EXPECT(unit.gain_log2() == 6 && unit.gain() == 27);
+        // a settled rate-4 cubic interpolator holds x * gain (cic.rs:242-262): R = 4, N = 3 -> gain 64
+        CicInterpolator<int32_t> up(3, 3, 1);
+        DeviceBuffer<int32_t> xi(std::vector<int32_t>(8, 10)), yi(32);
+        up.process_view(View<int32_t, LaneMajor>::from_flat(xi, 1), ViewMut<int32_t, LaneMajor>::from_flat(yi, 1, 4));
+        EXPECT(up.gain() == 64 && up.response_length() == 9);
+        auto o = yi.to_host();
+        for (size_t i = up.response_length(); i < o.size(); i++) EXPECT(o[i] == 640);
+    }
     // contract violations are reported as errors, never aborts
     {
         bool threw = false;

@@ -189,3 +189,28 @@ def test_by_lane_filter_bank():
         assert torch.equal(ys[64 * k:64 * (k + 1)], one)
     with pytest.raises(ValueError):
         ia.ByLane([bank[0], pids[0]], ia.DirectForm1)
+
+
+def test_cic_reference_properties():
+    """src/cic.rs:223-240 (rate 0 identity), :286-306 (unit rate), :242-262 (step response)."""
+    id_ = ia.Cic(3, 0).decimate().lanes(2)
+    x = torch.tensor([[5, -7], [1 << 40, -(1 << 50)], [3, 4]], dtype=torch.int64, device="cuda")
+    y = torch.zeros(3, 2, dtype=torch.int64, device="cuda")
+    id_.block(x.reshape(3, 2, 1), y)
+    assert torch.equal(x, y)
+    unit = ia.Cic(3, 0, comb_delay=3)
+    assert unit.gain_log2() == 6 and unit.gain() == 27 and unit.order() == 3 and unit.comb_delay() == 3
+    up = ia.Cic(3, 3, dtype=torch.int32)
+    assert up.gain() == 64 and up.response_length() == 9
+    p = up.interpolate().lanes(1)
+    xs = torch.full((8,), 10, dtype=torch.int32, device="cuda")
+    ys = torch.zeros(32, dtype=torch.int32, device="cuda")
+    p.process_view(ia.View(xs, ia.LaneMajor, 1), ia.ViewMut(ys, ia.LaneMajor, 1, width=4))
+    assert ys[9:].tolist() == [640] * 23 and ys[:9].tolist() == sorted(ys[:9].tolist())
+    # decimating what was interpolated returns gain^2-scaled samples once settled
+    d = ia.Cic(3, 3, dtype=torch.int32).decimate().lanes(1)
+    yd = torch.zeros(8, dtype=torch.int32, device="cuda")
+    d.process_view(ia.View(ys, ia.LaneMajor, 1, width=4), ia.ViewMut(yd, ia.LaneMajor, 1))
+    assert yd[-1].item() == 10 * 64 * 64
+    with pytest.raises(ValueError):
+        ia.Cic(0, 3)

@@ -186,6 +186,24 @@ def biquad_bylane(op, dtype, words, cv, lanes, frames, layout, n_sections, iters
            2 * esz * lanes * frames * passes + coef.numel() * esz, med, mn)
 
 
+def cic(kind, dtype, order, rate, lanes, frames, layout, iters, tag):
+    cfg = _abi.Cic(order, 1, rate)
+    R = rate + 1
+    hi = torch.randint(-(1 << 20), 1 << 20, (lanes * frames * R,), dtype=dtype, device=dev)
+    lo = torch.randint(-(1 << 20), 1 << 20, (lanes * frames,), dtype=dtype, device=dev)
+    esz = hi.element_size()
+    st = torch.zeros((call("cic_state_words", C.byref(cfg), esz * 8), lanes), dtype=torch.int32, device=dev)
+    x, y = (hi, lo) if kind == "dec" else (lo, hi)
+    name = f"cic_{kind}_{'i64' if esz == 8 else 'i32'}"
+
+    def run():
+        call(name, C.byref(cfg), p(st), p(x), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:{name} N={order} R={R} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames * R, "sample",
+           (R + 1) * esz * lanes * frames, med, mn)
+
+
 def cossin(n, iters, tag):
     ph = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device=dev).to(torch.int32)
     out = torch.empty(2 * n, dtype=torch.int32, device=dev)
@@ -254,6 +272,13 @@ def main():
         for s in (1, 2, 3, 5):
             hbf("dec", s, 16384, 65536 >> s, LM, it, "hbf")
             hbf("int", s, 16384, 65536 >> s, LM, it, "hbf")
+    if want("cic"):
+        for layout in (FM, LM):
+            cic("dec", torch.int32, 3, 15, 16384, 4096, layout, it, "cic")
+            cic("int", torch.int32, 3, 15, 16384, 4096, layout, it, "cic")
+        cic("dec", torch.int64, 3, 15, 16384, 2048, FM, it, "cic")
+        cic("dec", torch.int32, 3, 63, 16384, 1024, FM, it, "cic")
+        cic("dec", torch.int32, 3, 15, 65536, 1024, FM, it, "cic")
     if want("c4"):
         for layout in (FM, LM):
             lockin(2, 2, 32768, 4096, layout, it, "C4")
