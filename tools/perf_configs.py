@@ -215,6 +215,17 @@ def cossin(n, iters, tag):
     report(f"{tag}:cossin {n}", n, "phase", 12 * n, med, mn)
 
 
+def atan2(n, iters, tag):
+    xy = torch.randint(-(1 << 31), (1 << 31) - 1, (2 * n,), dtype=torch.int64, device=dev).to(torch.int32)
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+
+    def run():
+        call("atan2_i32", p(xy), p(out), n, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:atan2 {n}", n, "angle", 12 * n, med, mn)
+
+
 def copy_ref(nbytes, iters):
     a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
     b = torch.empty_like(a)
@@ -287,6 +298,7 @@ def main():
         dds(32768, 4096, FM, it, "dds")
         dds(65536, 4096, FM, it, "dds")
         cossin(1 << 27, it, "cossin")
+        atan2(1 << 27, it, "atan2")
 
 
 if __name__ == "__main__":
