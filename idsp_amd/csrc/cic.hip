@@ -10,7 +10,9 @@
 namespace idsp {
 namespace {
 
-constexpr int kBlock = 256;
+// one wave per workgroup: at 16384 lanes that is 256 workgroups = every CU gets one (256-thread
+// blocks would fill only 64 CUs, and a CU's L1 moves ~10 B/cycle: 1.3 TB/s measured that way)
+constexpr int kBlock = 64;
 
 template <class T>
 struct Vec16 {
@@ -102,9 +104,17 @@ struct CicRegs {
     }
 };
 
+// Chunk widths with a dedicated instantiation: VPC 16-byte vectors per chunk `[T; R]` (VPC = 0: any
+// other width, scalar loop).  At 16384 lanes there are only 256 waves on the chip, so every wave has to
+// keep tens of KiB in flight by itself (tools/ubench_pattern.hip: 2.0 / 3.9 / 5.0 TB/s with 1 / 4 / 16
+// chunk rows in flight per thread at 256 waves): the chunk stream runs through a register ring of
+// kRingVecs vectors.  Plain loads — a 128-byte line is shared by two lanes and touched by up to four
+// instructions, and nontemporal loads re-fetched it every time (measured: 4x traffic).
+constexpr int kRingVecs = 64;
+
 // Decimator: per chunk, sample 0 integrates, ticks (index 0 -> rate) and runs the combs; samples
 // 1..R-1 only integrate (src/cic.rs:186-207 driven by adapters.rs:158-167).
-template <class T, int N>
+template <class T, int N, int VPC>
 __global__ __launch_bounds__(kBlock) void cic_dec_kernel(const idsp_cic cfg, uint32_t *st, const T *x, T *y, const size_t lanes,
                                                           const size_t frames, const int layout)
 {
@@ -119,38 +129,71 @@ __global__ __launch_bounds__(kBlock) void cic_dec_kernel(const idsp_cic cfg, uin
     const size_t hstride = fm ? lanes * R : R;
     T *lp = y + (fm ? lane : lane * frames);
     const size_t lstride = fm ? lanes : 1;
-    using V = Vec16<T>;
-    const bool vec = R % V::n == 0 && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    for (size_t f = 0; f < frames; f++) {
-        const T *row = hp + f * hstride;
-        T out;
-        if (vec) {
-            const typename V::type *vr = reinterpret_cast<const typename V::type *>(row);
-            typename V::type v = vr[0];
-            out = c.integrate(v[0]);
+    if constexpr (VPC > 0) {
+        using V = Vec16<T>;
+        using VT = typename V::type;
+        constexpr int U = kRingVecs / VPC > 2 ? kRingVecs / VPC : 2;
+        VT ring[U][VPC];
+        auto fetch = [&](int u, size_t f) {
+            const VT *vr = reinterpret_cast<const VT *>(hp + f * hstride);
+#pragma unroll
+            for (int i = 0; i < VPC; i++) ring[u][i] = vr[i];
+        };
+        // integrates the chunk in ring slot u; the combs take the integrator output of sample 0 and touch
+        // only comb state, so they run after the whole chunk without changing any value
+        auto frame = [&](int u, size_t f) {
+            T out{};
+#pragma unroll
+            for (int i = 0; i < VPC; i++)
+#pragma unroll
+                for (int k = 0; k < V::n; k++) {
+                    const T v = c.integrate(ring[u][i][k]);
+                    if (i == 0 && k == 0) out = v;
+                }
             c.zoh = c.combs(out, m);
+            lp[f * lstride] = c.zoh;
+        };
 #pragma unroll
-            for (int k = 1; k < V::n; k++) c.integrate(v[k]);
-            const size_t nv = R / V::n;
-#pragma unroll 4
-            for (size_t i = 1; i < nv; i++) {
-                v = vr[i];
+        for (int u = 0; u < U; u++)
+            if (size_t(u) < frames) fetch(u, size_t(u));
+        size_t f = 0;
+        for (; f + 2 * U <= frames; f += U) {  // every refill of this trip is in range
 #pragma unroll
-                for (int k = 0; k < V::n; k++) c.integrate(v[k]);
+            for (int u = 0; u < U; u++) {
+                frame(u, f + u);
+                fetch(u, f + u + U);
             }
-        } else {
-            out = c.integrate(row[0]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (f + u < frames) {
+                frame(u, f + u);
+                if (f + u + U < frames) fetch(u, f + u + U);
+            }
+        }
+        f += U;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (f + u < frames) frame(u, f + u);
+    } else {
+        for (size_t f = 0; f < frames; f++) {
+            const T *row = hp + f * hstride;
+            const T out = c.integrate(row[0]);
             c.zoh = c.combs(out, m);
             for (size_t r = 1; r < R; r++) c.integrate(row[r]);
+            lp[f * lstride] = c.zoh;
         }
-        lp[f * lstride] = c.zoh;
     }
     c.store(st, lanes, lane, m);
 }
 
 // Interpolator: per input sample the combs run once (index = rate), then R integrator passes over
-// the held comb output emit the chunk (src/cic.rs:160-182 driven by adapters.rs:27-35).
-template <class T, int N>
+// the held comb output emit the chunk (src/cic.rs:160-182 driven by adapters.rs:27-35).  The
+// low-rate inputs are read kInAhead frames ahead so that waiting for one does not drain the chunk
+// stores issued since (vmcnt is in-order).
+constexpr int kInAhead = 32;
+
+template <class T, int N, int VPC>
 __global__ __launch_bounds__(kBlock) void cic_int_kernel(const idsp_cic cfg, uint32_t *st, const T *x, T *y, const size_t lanes,
                                                           const size_t frames, const int layout)
 {
@@ -165,16 +208,14 @@ __global__ __launch_bounds__(kBlock) void cic_int_kernel(const idsp_cic cfg, uin
     const size_t hstride = fm ? lanes * R : R;
     const T *lp = x + (fm ? lane : lane * frames);
     const size_t lstride = fm ? lanes : 1;
-    using V = Vec16<T>;
-    const bool vec = R % V::n == 0 && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
-    for (size_t f = 0; f < frames; f++) {
-        c.zoh = c.combs(lp[f * lstride], m);
+    auto chunk = [&](size_t f, T xin) {
+        c.zoh = c.combs(xin, m);
         T *row = hp + f * hstride;
-        if (vec) {
+        if constexpr (VPC > 0) {
+            using V = Vec16<T>;
             typename V::type *vr = reinterpret_cast<typename V::type *>(row);
-            const size_t nv = R / V::n;
-#pragma unroll 4
-            for (size_t i = 0; i < nv; i++) {
+#pragma unroll
+            for (int i = 0; i < VPC; i++) {
                 typename V::type v;
 #pragma unroll
                 for (int k = 0; k < V::n; k++) v[k] = c.integrate(c.zoh);
@@ -183,7 +224,32 @@ __global__ __launch_bounds__(kBlock) void cic_int_kernel(const idsp_cic cfg, uin
         } else {
             for (size_t r = 0; r < R; r++) row[r] = c.integrate(c.zoh);
         }
+    };
+    T ring[kInAhead];
+#pragma unroll
+    for (int u = 0; u < kInAhead; u++)
+        if (size_t(u) < frames) ring[u] = lp[size_t(u) * lstride];
+    size_t f = 0;
+    for (; f + 2 * kInAhead <= frames; f += kInAhead) {
+#pragma unroll
+        for (int u = 0; u < kInAhead; u++) {
+            const T xin = ring[u];
+            ring[u] = lp[(f + u + kInAhead) * lstride];
+            chunk(f + u, xin);
+        }
     }
+#pragma unroll
+    for (int u = 0; u < kInAhead; u++) {
+        if (f + u < frames) {
+            const T xin = ring[u];
+            if (f + u + kInAhead < frames) ring[u] = lp[(f + u + kInAhead) * lstride];
+            chunk(f + u, xin);
+        }
+    }
+    f += kInAhead;
+#pragma unroll
+    for (int u = 0; u < kInAhead; u++)
+        if (f + u < frames) chunk(f + u, ring[u]);
     c.store(st, lanes, lane, m);
 }
 
@@ -206,12 +272,31 @@ int run(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes, size_t
     const dim3 grid(unsigned((lanes + kBlock - 1) / kBlock)), block(kBlock);
     uint32_t *st = static_cast<uint32_t *>(state);
     hipStream_t s = as_stream(stream);
-#define IDSP_CIC_CASE(NN)                                                                                       \
-    case NN:                                                                                                    \
-        if (DEC)                                                                                                \
-            hipLaunchKernelGGL((cic_dec_kernel<T, NN>), grid, block, 0, s, *cfg, st, x, y, lanes, frames, layout); \
-        else                                                                                                    \
-            hipLaunchKernelGGL((cic_int_kernel<T, NN>), grid, block, 0, s, *cfg, st, x, y, lanes, frames, layout); \
+    // vectors per chunk when the chunk is a whole number of 16-byte vectors and the rows are aligned
+    using V = Vec16<T>;
+    const size_t R = size_t(cfg->rate) + 1;
+    int vpc = 0;
+    if (R % V::n == 0 && reinterpret_cast<uintptr_t>(DEC ? static_cast<const void *>(x) : static_cast<const void *>(y)) % 16 == 0) {
+        const size_t v = R / V::n;
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) vpc = int(v);
+    }
+#define IDSP_CIC_LAUNCH(NN, VV)                                                                                       \
+    do {                                                                                                              \
+        if (DEC)                                                                                                      \
+            hipLaunchKernelGGL((cic_dec_kernel<T, NN, VV>), grid, block, 0, s, *cfg, st, x, y, lanes, frames, layout); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((cic_int_kernel<T, NN, VV>), grid, block, 0, s, *cfg, st, x, y, lanes, frames, layout); \
+    } while (0)
+#define IDSP_CIC_CASE(NN)                            \
+    case NN:                                         \
+        switch (vpc) {                               \
+            case 1: IDSP_CIC_LAUNCH(NN, 1); break;   \
+            case 2: IDSP_CIC_LAUNCH(NN, 2); break;   \
+            case 4: IDSP_CIC_LAUNCH(NN, 4); break;   \
+            case 8: IDSP_CIC_LAUNCH(NN, 8); break;   \
+            case 16: IDSP_CIC_LAUNCH(NN, 16); break; \
+            default: IDSP_CIC_LAUNCH(NN, 0); break;  \
+        }                                            \
         break;
     switch (cfg->order) {
         IDSP_CIC_CASE(1)
@@ -222,6 +307,7 @@ int run(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes, size_t
         IDSP_CIC_CASE(6)
     }
 #undef IDSP_CIC_CASE
+#undef IDSP_CIC_LAUNCH
     return launch_status();
 }
 

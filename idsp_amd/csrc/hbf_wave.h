@@ -185,6 +185,17 @@ __device__ __forceinline__ void dec_chunk(float *lds, int nin, float *yg, size_t
 }
 
 // LM: x[(lane*frames + f)*R + k], y[lane*frames + f];  FM: x[(f*lanes + lane)*R + k], y[f*lanes + lane]
+// FRAME_MAJOR: lanes l and l+1 share 128-byte lines (a lane owns R*4 <= 64 bytes per frame).  Workgroups
+// are dealt to the 8 XCDs round-robin, and every XCD has its own L2, so with lane = blockIdx the two
+// halves of a line are fetched by two different L2s (PMC: 2.0x FETCH_SIZE, 10x WRITE_SIZE at C3).
+// Give each XCD one contiguous eighth of the lanes instead: neighbours then meet in the same L2, a few
+// dispatch rounds apart.  grid = 8 * ceil(lanes / 8); workgroups past the end exit.
+__device__ __forceinline__ size_t xcd_lane(size_t lanes)
+{
+    const size_t per = (lanes + 7) / 8;
+    return (blockIdx.x % 8) * per + blockIdx.x / 8;
+}
+
 template <class C, bool LM>
 __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x, float *y, const size_t lanes,
                                                    const size_t frames)
@@ -193,7 +204,8 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
     constexpr int S = C::stages, R = C::rate;
     static_assert(LM || R >= 4, "FRAME_MAJOR wave kernel needs 16-byte frame pieces");
     const int lid = threadIdx.x;
-    const size_t lane = blockIdx.x;
+    const size_t lane = LM ? size_t(blockIdx.x) : xcd_lane(lanes);
+    if (lane >= lanes) return;
 
     // history <- state words (per stage: even[M-1] then odd[2M-1], oldest first)
     static_for<0, S>([&](auto s) {
@@ -347,7 +359,8 @@ __global__ __launch_bounds__(kW) void hbf_int_wave(uint32_t *st, const float *x,
     constexpr int S = C::stages, R = C::rate;
     static_assert(R >= 4 || LM, "FRAME_MAJOR wave kernel needs 16-byte frame pieces");
     const int lid = threadIdx.x;
-    const size_t lane = blockIdx.x;
+    const size_t lane = LM ? size_t(blockIdx.x) : xcd_lane(lanes);
+    if (lane >= lanes) return;
 
     static_for<0, S>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
@@ -395,7 +408,7 @@ template <int TS, int S, bool DEC>
 int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm, hipStream_t stream)
 {
     using C = Casc<TS, S, DEC>;
-    const dim3 grid{unsigned(lanes)}, block{unsigned(kW)};
+    const dim3 grid{unsigned(lm ? lanes : 8 * ((lanes + 7) / 8))}, block{unsigned(kW)};
     if (lm) {
         if constexpr (DEC)
             hipLaunchKernelGGL((hbf_dec_wave<C, true>), grid, block, 0, stream, st, x, y, lanes, frames);

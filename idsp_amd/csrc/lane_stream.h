@@ -142,11 +142,12 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
     using In = typename P::In;
     using Out = typename P::Out;
     __shared__ uint32_t ptab[P::LDS_WORDS ? P::LDS_WORDS : 1];
+    // launched with 256-thread workgroups when that still gives every CU one, else with single waves
     if constexpr (P::LDS_WORDS > 0) {
-        P::fill_shared(ptab, threadIdx.x, kFmBlock);
+        P::fill_shared(ptab, threadIdx.x, int(blockDim.x));
         __syncthreads();
     }
-    const size_t lane = size_t(blockIdx.x) * kFmBlock + threadIdx.x;
+    const size_t lane = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (lane >= lanes) return;
 
     P p;
@@ -471,6 +472,15 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 // --------------------------------------------------------------------- launch
 // Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
 // latency, so go deep; with many resident waves keep the register budget low.
+// smallest launch (in waves) that takes the 256-thread LDS-DMA kernel (IDSP_LDS_MIN_WAVES overrides):
+// measured equal to the single-wave register kernel at 16384 lanes, 15-20 % ahead at 32768-49152,
+// slightly behind at 8192
+inline size_t lds_min_waves()
+{
+    static const size_t v = getenv("IDSP_LDS_MIN_WAVES") ? size_t(atoll(getenv("IDSP_LDS_MIN_WAVES"))) : size_t(256);
+    return v;
+}
+
 template <class P>
 int launch_stream(const typename P::Params &prm, void *state, const typename P::In *x,
                   typename P::Out *y, size_t lanes, size_t frames, int layout, hipStream_t s)
@@ -486,7 +496,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             // cheap per-sample arithmetic (the extra LDS hop and the two barriers per tile cost issue
             // slots), <= 2 waves per SIMD, whole 256-lane blocks, 16-byte aligned rows: LDS-DMA path
             static const int lds_cost_max = getenv("IDSP_LDS_COST") ? atoi(getenv("IDSP_LDS_COST")) : 120;
-            if (P::COST <= lds_cost_max && waves <= 2048 && lanes % kFmBlock == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+            if (P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= 2048 && lanes % kFmBlock == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                 reinterpret_cast<uintptr_t>(y) % 16 == 0 && !getenv("IDSP_NO_LDS_PATH")) {
                 constexpr size_t ow = sizeof(typename P::Out) / 4;
                 constexpr size_t bytes = (size_t(kLdsNB) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
@@ -502,11 +512,14 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 return launch_status();
             }
         }
-        const unsigned grid = unsigned((lanes + kFmBlock - 1) / kFmBlock);
+        // A CU's L1 moves ~10 B/cycle, so a launch must reach all 256 CUs: below 1024 waves (= 256
+        // workgroups of 4) use one wave per workgroup (16384 lanes in 256-thread blocks would run on 64 CUs).
+        const unsigned block = waves < 1024 ? unsigned(kWave) : unsigned(kFmBlock);
+        const unsigned grid = unsigned((lanes + block - 1) / block);
         if (waves <= 2048)
-            hipLaunchKernelGGL((stream_frame_major<P, 24>), dim3(grid), dim3(kFmBlock), 0, s, prm, st, x, y, lanes, frames);
+            hipLaunchKernelGGL((stream_frame_major<P, 24>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
         else
-            hipLaunchKernelGGL((stream_frame_major<P, 8>), dim3(grid), dim3(kFmBlock), 0, s, prm, st, x, y, lanes, frames);
+            hipLaunchKernelGGL((stream_frame_major<P, 8>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
     }
     return launch_status();
 }
