@@ -475,7 +475,7 @@ int idsp_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int lay
     if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return fail(IDSP_EINVAL, "bad layout %d", layout);
     if (lanes && (!state || (frames && !out))) return fail(IDSP_EINVAL, "state or out is NULL");
     if (lanes == 0) return IDSP_OK;
-    if (layout == IDSP_FRAME_MAJOR && lanes <= kSplitMaxLanes) {
+    if (lanes <= kSplitMaxLanes) {
         DdsSplitProc::Params ps{0};
         return launch_stream<DdsSplitProc>(ps, state, static_cast<const int32_t *>(nullptr), out, 2 * lanes, frames, layout,
                                            as_stream(stream));
@@ -498,8 +498,8 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
     if (rc) return rc;
     if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
     if (lanes == 0) return IDSP_OK;
-    // fewer than one wave per SIMD even after doubling: put the I and Q arms on separate threads
-    if (layout == IDSP_FRAME_MAJOR && lanes <= kSplitMaxLanes)
+    // too few lanes to give every SIMD a wave: put the I and Q arms on separate threads (both layouts)
+    if (lanes <= kSplitMaxLanes)
         return dispatch_nk<LockinSplitProc, int32_t>(cfg, state, x, y, 2 * lanes, frames, layout, as_stream(stream));
     return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, as_stream(stream));
 }

@@ -391,42 +391,48 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 {
     using In = typename P::In;
     using Out = typename P::Out;
-    constexpr int IW = sizeof(In) / 4, OW = sizeof(Out) / 4;  // words per input / output sample
-    static_assert((IW == 1 || IW == 2) && (OW == 1 || OW == 2), "samples are one or two 32-bit words");
-    constexpr int MW = IW > OW ? IW : OW;
-    constexpr int TS = kWave / MW;            // samples per tile and lane (widest row = 64 words)
-    constexpr int RWI = TS * IW, RWO = TS * OW;  // words per tile row
-    constexpr int RPI = kWave / RWI;          // tile rows covered by one load instruction
+    // D = IN_DIV threads ("virtual lanes") share one lane: they read the same input sample and each
+    // writes its own OW words of the lane's D*OW-word output sample; `lanes` counts virtual lanes.
+    constexpr int D = P::IN_DIV;
+    constexpr int IW = sizeof(In) / 4, OW = sizeof(Out) / 4, OWR = OW * D;  // words per input / output sample
+    static_assert((IW == 1 || IW == 2) && (OWR == 1 || OWR == 2) && (D == 1 || D == 2), "samples are one or two 32-bit words");
+    constexpr int MW = IW > OWR ? IW : OWR;
+    constexpr int TS = kWave / MW;             // samples per tile and lane (widest row = 64 words)
+    constexpr int RWI = TS * IW, RWO = TS * OWR;  // words per tile row
+    constexpr int ROWS = kWave / D;            // lanes per wave
+    constexpr int RPI = kWave / RWI;           // tile rows covered by one load instruction
+    constexpr int NLD = ROWS / RPI;            // load instructions per tile
     constexpr bool kAlias = P::HAS_IN && RWI == RWO;
 
-    __shared__ uint32_t tin[P::HAS_IN ? kWave : 1][RWI + 1];
-    __shared__ uint32_t tout_[kAlias ? 1 : kWave][RWO + 1];
+    __shared__ uint32_t tin[P::HAS_IN ? ROWS : 1][RWI + 1];
+    __shared__ uint32_t tout_[kAlias ? 1 : ROWS][RWO + 1];
     uint32_t(*tout)[RWO + 1] = kAlias ? reinterpret_cast<uint32_t(*)[RWO + 1]>(tin) : tout_;
 
     const int lid = threadIdx.x;
-    const size_t lane0 = size_t(blockIdx.x) * kWave;
-    const size_t lane = lane0 + lid;
-    const bool active = lane < lanes;
-    const size_t nrows = lanes - lane0 < size_t(kWave) ? lanes - lane0 : size_t(kWave);
+    const size_t vlane = size_t(blockIdx.x) * kWave + lid;  // virtual lane of this thread
+    const bool active = vlane < lanes;
+    const size_t lane0 = size_t(blockIdx.x) * ROWS, rlanes = lanes / D;  // first lane of the wave, lane count
+    const size_t nrows = rlanes - lane0 < size_t(ROWS) ? rlanes - lane0 : size_t(ROWS);
+    const int trow = lid / D, tsub = lid % D;
 
     __shared__ uint32_t ptab[P::LDS_WORDS ? P::LDS_WORDS : 1];
     if constexpr (P::LDS_WORDS > 0) P::fill_shared(ptab, lid, kWave);  // published by the first tile sync
 
     P p;
     if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
-    if (active) p.load(prm, st, lanes, lane);
+    if (active) p.load(prm, st, lanes, vlane);
 
     const uint32_t *xw = reinterpret_cast<const uint32_t *>(x);
     uint32_t *yw = reinterpret_cast<uint32_t *>(y);
     // word (row r, col c) handled by this thread in load instruction i: r = i*RPI + lrow, c = lcol
     const int lrow = lid / RWI, lcol = lid % RWI;
 
-    uint32_t stage[RWI];
+    uint32_t stage[NLD];
     auto fetch = [&](size_t t0) {
         if constexpr (P::HAS_IN) {
             const size_t nw = (frames - t0 < size_t(TS) ? frames - t0 : size_t(TS)) * IW;
 #pragma unroll
-            for (int i = 0; i < RWI; i++) {
+            for (int i = 0; i < NLD; i++) {
                 const size_t r = size_t(i) * RPI + lrow;
                 stage[i] = (r < nrows && size_t(lcol) < nw) ? xw[((lane0 + r) * frames + t0) * IW + lcol] : 0u;
             }
@@ -435,9 +441,9 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 
     auto one = [&](size_t j) {
         In v{};
-        if constexpr (P::HAS_IN) v = words_to<In>(&tin[lid][j * IW]);
+        if constexpr (P::HAS_IN) v = words_to<In>(&tin[trow][j * IW]);
         const Out o = step1(p, prm, v);
-        to_words<Out>(o, &tout[lid][j * OW]);
+        to_words<Out>(o, &tout[trow][j * OWR + tsub * OW]);
     };
 
     fetch(0);
@@ -445,28 +451,43 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
         const size_t ncols = frames - t0 < size_t(TS) ? frames - t0 : size_t(TS);
         if constexpr (P::HAS_IN) {
 #pragma unroll
-            for (int i = 0; i < RWI; i++) tin[i * RPI + lrow][lcol] = stage[i];
+            for (int i = 0; i < NLD; i++) tin[i * RPI + lrow][lcol] = stage[i];
         }
         lds_wave_sync();
         if (t0 + TS < frames) fetch(t0 + TS);  // next tile in flight during the arithmetic
 
         if (active) {
             if (ncols == size_t(TS)) {
+                constexpr int B = BatchOf<P>::value;
+                if constexpr (B > 1 && TS % B == 0) {
 #pragma unroll
-                for (int j = 0; j < TS; j++) one(size_t(j));
+                    for (int j0 = 0; j0 < TS; j0 += B) {
+                        typename P::Pre pre[B];
+                        pre_all<P, B>(p, prm, pre);
+#pragma unroll
+                        for (int b = 0; b < B; b++) {
+                            In v{};
+                            if constexpr (P::HAS_IN) v = words_to<In>(&tin[trow][(j0 + b) * IW]);
+                            to_words<Out>(p.step(prm, v, pre[b]), &tout[trow][(j0 + b) * OWR + tsub * OW]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TS; j++) one(size_t(j));
+                }
             } else {
                 for (size_t j = 0; j < ncols; j++) one(j);
             }
         }
         lds_wave_sync();
         // row-contiguous stores: one instruction = up to 64 consecutive words of one lane
-        const size_t nw = ncols * OW;
+        const size_t nw = ncols * OWR;
         for (size_t r = 0; r < nrows; r++) {
-            if (size_t(lid) < nw) yw[((lane0 + r) * frames + t0) * OW + lid] = tout[r][lid];
+            if (size_t(lid) < nw) yw[((lane0 + r) * frames + t0) * OWR + lid] = tout[r][lid];
         }
         lds_wave_sync();
     }
-    if (active) p.store(prm, st, lanes, lane);
+    if (active) p.store(prm, st, lanes, vlane);
 }
 
 // --------------------------------------------------------------------- launch
