@@ -475,3 +475,29 @@ def test_concurrent_streams_distinct_states(bes):
     for (y, so), yg, sg in zip(want, yd, sd):
         assert np.array_equal(yg.cpu().numpy(), y)
         assert np.array_equal(sg.cpu().numpy().view(np.uint32), so)
+
+
+def test_cossin_atan2_unaligned_buffers_take_the_scalar_path(bes):
+    """The vector kernels need 16-byte aligned buffers; a 4-byte offset view must give the same values."""
+    import torch
+
+    ob, gb = bes
+    e = H.engine()
+    rng = np.random.default_rng(77)
+    n = 100003
+    p = rng.integers(I32_MIN, I32_MAX, size=n, dtype=np.int64, endpoint=True).astype(np.int32)
+    _, want = ob.cossin(p)
+    buf = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    buf[1:] = torch.from_numpy(p).cuda()
+    out = torch.zeros(2 * n + 1, dtype=torch.int32, device="cuda")
+    assert e.fn["cossin_i32"](C.c_void_p(buf.data_ptr() + 4), C.c_void_p(out.data_ptr() + 4), n, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out[1:].cpu().numpy().reshape(-1, 2), want)
+    xy = rng.integers(I32_MIN, I32_MAX, size=(n, 2), dtype=np.int64, endpoint=True).astype(np.int32)
+    _, want = ob.atan2(xy)
+    buf = torch.zeros(2 * n + 1, dtype=torch.int32, device="cuda")
+    buf[1:] = torch.from_numpy(xy.reshape(-1)).cuda()
+    out = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    assert e.fn["atan2_i32"](C.c_void_p(buf.data_ptr() + 4), C.c_void_p(out.data_ptr() + 4), n, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out[1:].cpu().numpy(), want)
