@@ -186,3 +186,99 @@ def test_c5_f32_df2t_one_million_lanes(eng):
         assert torch.equal(ysh.view(torch.int32), whole[lo:hi].view(torch.int32))
         assert torch.equal(sts, stw[:, lo:hi])
     assert torch.equal(whole.t().contiguous().view(torch.int32), y[:fr].view(torch.int32))
+
+
+def test_bylane_bank_65536_lanes(eng):
+    """`ByLane` at the C2 shape (65536 different Q30 lowpasses x 4096 samples): replicated coefficients
+    reproduce the shared-coefficient launch bit for bit over the whole tensor; a bank of distinct filters
+    is checked against the oracle on a lane subset; LANE_MAJOR == transposed FRAME_MAJOR."""
+    lanes, frames = 65536, 4096
+    o = H.oracle()
+    cfg = lowpass_i32()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(12)
+    x = torch.randint(-(1 << 24), 1 << 24, (frames, lanes), dtype=torch.int32, device=DEV, generator=g)
+    base = torch.tensor(list(cfg[0].ba), dtype=torch.int32, device=DEV)
+    coef = base.view(1, 5, 1).expand(1, 5, lanes).contiguous()
+    y_sh, y_bl = torch.empty_like(x), torch.empty_like(x)
+    st_sh = torch.zeros((4, lanes), dtype=torch.int32, device=DEV)
+    st_bl = torch.zeros_like(st_sh)
+    assert eng.stream("biquad_i32_df1", cfg, 1, st_sh, x, y_sh, lanes, frames, FM) == 0
+    assert eng.fn["biquad_i32_df1_bylane"](p(coef), 30, 1, p(st_bl), p(x), p(y_bl), lanes, frames, FM, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y_sh, y_bl) and torch.equal(st_sh, st_bl)
+    # distinct filters per lane: f0 spread over 3 decades, quantised on the host like `Biquad::from`
+    f0 = torch.logspace(-4, -1, lanes, dtype=torch.float64)
+    w0 = 2 * math.pi * f0
+    alpha = 0.5 * torch.sin(w0) * math.sqrt(2.0)
+    b = 0.5 * (1 - torch.cos(w0))
+    a0 = 1 + alpha
+    ba = torch.stack([b / a0, 2 * b / a0, b / a0, 2 * torch.cos(w0) / a0, -(1 - alpha) / a0], 0)
+    q = torch.clamp(torch.round(ba * float(1 << 30)), -(1 << 31), (1 << 31) - 1).to(torch.int32)
+    coef = q.view(1, 5, lanes).contiguous().to(DEV)
+    st = torch.zeros((4, lanes), dtype=torch.int32, device=DEV)
+    y = torch.empty_like(x)
+    assert eng.fn["biquad_i32_df1_bylane"](p(coef), 30, 1, p(st), p(x), p(y), lanes, frames, FM, None) == 0
+    torch.cuda.synchronize()
+    sub = np.r_[0:64, 30000:30064, 65472:65536]
+    xs = np.ascontiguousarray(x[:, sub].cpu().numpy())
+    cs = np.ascontiguousarray(coef[:, :, sub].cpu().numpy())
+    ys = np.empty_like(xs)
+    ss = np.zeros((4, sub.size), np.uint32)
+    assert o.fn["biquad_i32_df1_bylane"](H._ptr(cs), 30, 1, H._ptr(ss), H._ptr(xs), H._ptr(ys), sub.size, frames, FM) == 0
+    assert np.array_equal(y[:, sub].cpu().numpy(), ys)
+    assert np.array_equal(st[:, sub].cpu().numpy().view(np.uint32), ss)
+    # LANE_MAJOR == transposed FRAME_MAJOR
+    xt = x.t().contiguous()
+    yt = torch.empty_like(xt)
+    st2 = torch.zeros_like(st)
+    assert eng.fn["biquad_i32_df1_bylane"](p(coef), 30, 1, p(st2), p(xt), p(yt), lanes, frames, LM, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(yt.t(), y) and torch.equal(st, st2)
+
+
+def test_cic_decimator_into_hbf_16384_lanes(eng):
+    """`Cic` /16 in front of the half-band chain at 16384 lanes: parity on a lane subset, chunked ==
+    whole, LANE_MAJOR == FRAME_MAJOR, and interpolate -> decimate returns gain^2 * x once settled."""
+    lanes, frames, R = 16384, 1024, 16
+    o = H.oracle()
+    cfg = _abi.Cic(3, 1, R - 1)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(13)
+    x = torch.randint(-(1 << 15), 1 << 15, (frames, lanes, R), dtype=torch.int32, device=DEV, generator=g)
+    words = eng.fn["cic_state_words"](C.byref(cfg), 32)
+    st = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)
+    y = torch.empty((frames, lanes), dtype=torch.int32, device=DEV)
+    assert eng.cfgcall("cic_dec_i32", cfg, st, x, y, lanes, frames, FM) == 0
+    torch.cuda.synchronize()
+    sub = np.r_[0:32, 9000:9032, 16352:16384]
+    xs = np.ascontiguousarray(x[:, sub].cpu().numpy())
+    ys = np.empty((frames, sub.size), np.int32)
+    ss = np.zeros((words, sub.size), np.uint32)
+    assert o.cfgcall("cic_dec_i32", cfg, ss, xs, ys, sub.size, frames, FM) == 0
+    assert np.array_equal(y[:, sub].cpu().numpy(), ys)
+    assert np.array_equal(st[:, sub].cpu().numpy().view(np.uint32), ss)
+    # chunked == whole
+    st2 = torch.zeros_like(st)
+    y2 = torch.empty_like(y)
+    for a, b in ((0, 300), (300, 301), (301, frames)):
+        assert eng.cfgcall("cic_dec_i32", cfg, st2, x[a:b], y2[a:b], lanes, b - a, FM) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(st, st2)
+    # LANE_MAJOR
+    xl = x.permute(1, 0, 2).contiguous()
+    yl = torch.empty((lanes, frames), dtype=torch.int32, device=DEV)
+    st3 = torch.zeros_like(st)
+    assert eng.cfgcall("cic_dec_i32", cfg, st3, xl, yl, lanes, frames, LM) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(yl.t(), y) and torch.equal(st, st3)
+    # x -> interpolate x16 -> decimate /16: DC gain = gain()^2 = R^6 once both impulse responses have passed
+    dc = torch.randint(-100, 100, (1, lanes), dtype=torch.int64, device=DEV).expand(64, lanes).contiguous()
+    sti = torch.zeros((eng.fn["cic_state_words"](C.byref(cfg), 64), lanes), dtype=torch.int32, device=DEV)
+    std = torch.zeros_like(sti)
+    up = torch.empty((64, lanes, R), dtype=torch.int64, device=DEV)
+    down = torch.empty((64, lanes), dtype=torch.int64, device=DEV)
+    assert eng.cfgcall("cic_int_i64", cfg, sti, dc, up, lanes, 64, FM) == 0
+    assert eng.cfgcall("cic_dec_i64", cfg, std, up, down, lanes, 64, FM) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(down[-1], dc[0] * (R ** 6))
