@@ -64,6 +64,13 @@ class LockinI32(C.Structure):
     _fields_ = [("order", C.c_int32), ("cascade", C.c_int32), ("k", (C.c_int32 * 2) * LOCKIN_MAX_CASCADE)]
 
 
+WDF_MAX_ORDER = 8
+
+
+class Wdf(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_uint32), ("a", C.c_int32 * WDF_MAX_ORDER)]
+
+
 class Cic(C.Structure):
     _fields_ = [("order", C.c_int32), ("comb_delay", C.c_int32), ("rate", C.c_uint32)]
 
@@ -148,6 +155,10 @@ PROCESSING = {
     "hbf_dec_f32": _CFG_SIG,
     "hbf_int_f32": _CFG_SIG,
     "fir_sym_f32_process": _CFG_SIG,
+    "normal_i32_df1": _STREAM_SIG,
+    "normal_f32_df1": _STREAM_SIG,
+    "normal_f64_df1": _STREAM_SIG,
+    "wdf_i32": _STREAM_SIG,
     "cic_dec_i32": _CFG_SIG,
     "cic_dec_i64": _CFG_SIG,
     "cic_int_i32": _CFG_SIG,
@@ -173,6 +184,9 @@ HELPERS = {
     "hbf_int_state_words": (_SZ, [_P]),
     "lockin_state_words": (_SZ, [_P]),
     "fir_sym_state_words": (_SZ, [_P]),
+    "normal_from_sos": (_I, [_P, _P]),
+    "wdf_quantize": (_I, [_I, C.c_uint32, _P, _P]),
+    "wdf_state_words": (_SZ, [_P, _SZ]),
     "cic_gain": (C.c_int64, [_P]),
     "cic_gain_log2": (_I, [_P]),
     "cic_response_length": (_SZ, [_P]),

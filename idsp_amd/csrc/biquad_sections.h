@@ -247,6 +247,77 @@ struct Df2tF64 {
     }
 };
 
+// ------------------------------------------------------------ normal form
+// `Normal<C>` x `DirectForm1<T>` (src/iir/normal.rs:37-58); ba = [b0, b1, b2, p.re, p.im], state words
+// {x0, x1, y0, y1}: y1' = (b0 x0 + b1 x1 + b2 x2 + re y1 + (-im) y0).as_(), y0' = (im y1 + re y0).as_().
+struct NormalI32 {
+    using T = int32_t;
+    using Sec = SecI32;
+    static constexpr bool kClamp = false;
+    static constexpr int W = 4;
+    static constexpr int COST = 70;
+    static __device__ __forceinline__ int32_t step(const SecI32 &c, uint32_t (&s)[W], int32_t x0)
+    {
+        const int32_t y0o = int32_t(s[2]), y1o = int32_t(s[3]);
+        int64_t acc = mulw(c.ba[0], x0);
+        acc = wadd(acc, mulw(c.ba[1], int32_t(s[0])));
+        acc = wadd(acc, mulw(c.ba[2], int32_t(s[1])));
+        acc = wadd(acc, mulw(c.ba[3], y1o));
+        acc = wadd(acc, mulw(int32_t(0u - uint32_t(c.ba[4])), y0o));  // `-self.p.im()` wraps like Neg on Q
+        const int32_t y1 = shr_lo(acc, c.frac);
+        const int32_t y0 = shr_lo(wadd(mulw(c.ba[4], y1o), mulw(c.ba[3], y0o)), c.frac);
+        s[1] = s[0];
+        s[0] = uint32_t(x0);
+        s[2] = uint32_t(y0);
+        s[3] = uint32_t(y1);
+        return y0;
+    }
+};
+struct NormalF32 {
+    using T = float;
+    using Sec = SecF32;
+    static constexpr bool kClamp = false;
+    static constexpr int W = 4;
+    static constexpr int COST = 30;
+    static __device__ __forceinline__ float step(const SecF32 &c, uint32_t (&s)[W], float x0)
+    {
+        const float y0o = __uint_as_float(s[2]), y1o = __uint_as_float(s[3]);
+        float acc = c.ba[0] * x0;
+        acc = acc + c.ba[1] * __uint_as_float(s[0]);
+        acc = acc + c.ba[2] * __uint_as_float(s[1]);
+        acc = acc + c.ba[3] * y1o;
+        acc = acc + (-c.ba[4]) * y0o;
+        const float y0 = c.ba[4] * y1o + c.ba[3] * y0o;
+        s[1] = s[0];
+        s[0] = __float_as_uint(x0);
+        s[2] = __float_as_uint(y0);
+        s[3] = __float_as_uint(acc);
+        return y0;
+    }
+};
+struct NormalF64 {
+    using T = double;
+    using Sec = SecF64;
+    static constexpr bool kClamp = false;
+    static constexpr int W = 8;
+    static constexpr int COST = 70;
+    static __device__ __forceinline__ double step(const SecF64 &c, uint32_t (&s)[W], double x0)
+    {
+        const double y0o = ldd(s, 2), y1o = ldd(s, 3);
+        double acc = c.ba[0] * x0;
+        acc = acc + c.ba[1] * ldd(s, 0);
+        acc = acc + c.ba[2] * ldd(s, 1);
+        acc = acc + c.ba[3] * y1o;
+        acc = acc + (-c.ba[4]) * y0o;
+        const double y0 = c.ba[4] * y1o + c.ba[3] * y0o;
+        s[2] = s[0], s[3] = s[1];
+        std_(s, 0, x0);
+        std_(s, 2, y0);
+        std_(s, 3, acc);
+        return y0;
+    }
+};
+
 // ------------------------------------------------------------ processors
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
 template <class Sec, int N>

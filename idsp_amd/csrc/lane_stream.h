@@ -261,7 +261,7 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))  // uniform by construction; pin it to an SGPR
                  : "memory");
 }
 template <int N>

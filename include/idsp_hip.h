@@ -292,6 +292,45 @@ int idsp_biquad_f64_df2t_clamp_bylane(const double *coef, size_t n, void *state,
         const double *x, double *y, size_t lanes, size_t frames, int layout, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* iir::normal::Normal and iir::wdf::Wdf lanes                               */
+/* ------------------------------------------------------------------------ */
+
+/* `Normal<C>` x `DirectForm1<T>` (src/iir/normal.rs:28-58), the Rader-Gold / Chamberlin normal form:
+ *   y1' = (b0*x0 + b1*x1 + b2*x2 + re*y1 + (-im)*y0).as_();  y0' = (im*y1 + re*y0).as_();  returns y0'
+ * with state words {x0, x1, y0, y1} (y0 = in-phase, y1 = quadrature component, normal.rs:24-25).
+ * The configuration reuses the biquad records: ba = [b0, b1, b2, p.re, p.im] (and frac for Q32<F>);
+ * n sections run in series like the biquad entries. */
+int idsp_normal_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y,
+                        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_normal_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y,
+                        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_normal_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, double *y,
+                        size_t lanes, size_t frames, int layout, void *stream);
+/* `From<&[[f64; 3]; 2]> for Normal<C>` (src/iir/normal.rs:62-76): sos = [b0,b1,b2,a0,a1,a2] ->
+ * out = [b0/a0, b1/a0, b2/a0, p.re, p.im]; IDSP_EINVAL when the poles are real (`assert!(pq >= 0.0)`). */
+int idsp_normal_from_sos(const double sos[6], double out[5]);
+
+/* `Wdf<N, M>` (src/iir/wdf.rs:103-171): N two-port adaptors, adaptor i of type nibble i of M
+ * (`Tpa`, wdf.rs:14-32: 0xA A, 0xB B, 0xE B1, 0x1 X, 0xC C, 0xF C1, 0xD D, anything else Z), with
+ * coefficients a[i] as raw `Q32<32>` bits.  State = `WdfState<N>::z` (N words per section). */
+#define IDSP_WDF_MAX_ORDER 8
+typedef struct idsp_wdf {
+    int32_t n;   /* N: 1..8 */
+    uint32_t m;  /* M: one nibble per adaptor, adaptor 0 in the low nibble */
+    int32_t a[IDSP_WDF_MAX_ORDER];
+} idsp_wdf;
+/* `Wdf::<N, M>::quantize(&g)` (src/iir/wdf.rs:126-137, `Tpa::quantize` :50-62): fills out->a from the
+ * allpass poles g[0..n) for the architecture nibbles m; IDSP_EOUTOFRANGE when a pole does not fit its
+ * adaptor type (the reference returns None). */
+int idsp_wdf_quantize(int n, uint32_t m, const double *g, idsp_wdf *out);
+/* Per-lane state words of a chain of n_sections sections (sum of their n). */
+size_t idsp_wdf_state_words(const idsp_wdf *cfg, size_t n_sections);
+/* Serial chain of n_sections `Wdf` sections (array / tuple composition, dsp-process/src/compose.rs:43-113),
+ * `SplitProcess<i32, i32, WdfState<N>>` (wdf.rs:153-169); in place allowed. */
+int idsp_wdf_i32(const idsp_wdf *cfg, size_t n_sections, void *state, const int32_t *x, int32_t *y,
+                 size_t lanes, size_t frames, int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Cic — cascaded integrator-comb rate changer (src/cic.rs)                 */
 /* ------------------------------------------------------------------------ */
 

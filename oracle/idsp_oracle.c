@@ -22,6 +22,7 @@
 
 static inline int64_t wadd64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 static inline int32_t wadd32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int32_t wsub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 static inline int64_t wshl64(int64_t a, int s) { return (int64_t)((uint64_t)a << s); }
 static inline int64_t mul_wide(int32_t c, int32_t v) { return (int64_t)c * (int64_t)v; }
 static inline int32_t trunc32(int64_t a) { return (int32_t)(uint32_t)(uint64_t)a; }
@@ -887,6 +888,151 @@ int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n)
 {
     if (n && (!phase || !out)) return IDSP_EINVAL;
     for (size_t i = 0; i < n; i++) idsp_ref_cossin(phase[i], &out[2 * i], &out[2 * i + 1]);
+    return IDSP_OK;
+}
+
+/* ----------------------------------------------------------- Normal, Wdf */
+/* `Normal<C>` x `DirectForm1<T>` (src/iir/normal.rs:37-58); ba = [b0, b1, b2, p.re, p.im] */
+static inline int32_t normal_i32(const int32_t ba[5], int frac, uint32_t *s, int32_t x0)
+{
+    int32_t x1 = (int32_t)s[0], x2 = (int32_t)s[1], y0o = (int32_t)s[2], y1o = (int32_t)s[3];
+    int32_t nim = (int32_t)(0u - (uint32_t)ba[4]);
+    int64_t acc = (int64_t)ba[0] * x0;
+    acc = wadd64(acc, (int64_t)ba[1] * x1);
+    acc = wadd64(acc, (int64_t)ba[2] * x2);
+    acc = wadd64(acc, (int64_t)ba[3] * y1o);
+    acc = wadd64(acc, (int64_t)nim * y0o);
+    int32_t y1 = (int32_t)(acc >> frac);
+    int32_t y0 = (int32_t)(wadd64((int64_t)ba[4] * y1o, (int64_t)ba[3] * y0o) >> frac);
+    s[1] = (uint32_t)x1; s[0] = (uint32_t)x0; s[2] = (uint32_t)y0; s[3] = (uint32_t)y1;
+    return y0;
+}
+static inline float normal_f32(const float ba[5], uint32_t *s, float x0)
+{
+    float x1 = f32_from_bits(s[0]), x2 = f32_from_bits(s[1]), y0o = f32_from_bits(s[2]), y1o = f32_from_bits(s[3]);
+    float acc = ba[0] * x0;
+    acc = acc + ba[1] * x1;
+    acc = acc + ba[2] * x2;
+    acc = acc + ba[3] * y1o;
+    acc = acc + (-ba[4]) * y0o;
+    float y0 = ba[4] * y1o + ba[3] * y0o;
+    s[1] = s[0]; s[0] = f32_to_bits(x0); s[2] = f32_to_bits(y0); s[3] = f32_to_bits(acc);
+    return y0;
+}
+static inline double normal_f64(const double ba[5], uint32_t *s, double x0)
+{
+    double x1 = f64_from_words(s, 0), x2 = f64_from_words(s, 1), y0o = f64_from_words(s, 2), y1o = f64_from_words(s, 3);
+    double acc = ba[0] * x0;
+    acc = acc + ba[1] * x1;
+    acc = acc + ba[2] * x2;
+    acc = acc + ba[3] * y1o;
+    acc = acc + (-ba[4]) * y0o;
+    double y0 = ba[4] * y1o + ba[3] * y0o;
+    f64_to_words(s, 1, x1); f64_to_words(s, 0, x0); f64_to_words(s, 2, y0); f64_to_words(s, 3, acc);
+    return y0;
+}
+LANE_DRIVER(idsp_ref_normal_i32_df1, idsp_biquad_i32, int32_t, 4, frac_ok_i32(cfg, n), normal_i32(c->ba, c->frac, s, x0))
+LANE_DRIVER(idsp_ref_normal_f32_df1, idsp_biquad_f32, float, 4, 1, normal_f32(c->ba, s, x0))
+LANE_DRIVER(idsp_ref_normal_f64_df1, idsp_biquad_f64, double, 8, 1, normal_f64(c->ba, s, x0))
+
+/* src/iir/normal.rs:62-76 */
+int idsp_ref_normal_from_sos(const double sos[6], double out[5])
+{
+    if (!sos || !out) return IDSP_EINVAL;
+    double a0 = 1.0 / sos[3], p2 = -0.5 * sos[4], pq = sos[3] * sos[5] - p2 * p2;
+    if (!(pq >= 0.0)) return IDSP_EINVAL;
+    out[0] = sos[0] * a0; out[1] = sos[1] * a0; out[2] = sos[2] * a0;
+    out[3] = p2 * a0; out[4] = sqrt(pq) * a0;
+    return IDSP_OK;
+}
+
+/* `Tpa::adapt` (src/iir/wdf.rs:65-100) */
+static inline int32_t wdf_mulq(int32_t c, int32_t a) { return (int32_t)(((int64_t)c * (int64_t)a) >> 32); }
+static void tpa_adapt(uint32_t nib, int32_t a, const int32_t x[2], int32_t o[2])
+{
+    int32_t c, y;
+    switch (nib) {
+    case 0xA: c = wsub32(x[1], x[0]); y = wadd32(wdf_mulq(c, a), x[1]); o[0] = wadd32(y, c); o[1] = y; break;
+    case 0xB: c = wsub32(x[0], x[1]); y = wadd32(wdf_mulq(c, a), x[1]); o[0] = y; o[1] = wadd32(y, c); break;
+    case 0xE: c = wsub32(x[0], x[1]); y = wdf_mulq(c, a); o[0] = wadd32(y, x[1]); o[1] = wadd32(y, x[0]); break;
+    case 0x1: o[0] = x[1]; o[1] = x[0]; break;
+    case 0xC: c = wsub32(x[1], x[0]); y = wsub32(wdf_mulq(c, a), x[1]); o[0] = y; o[1] = wadd32(y, c); break;
+    case 0xF: c = wsub32(x[1], x[0]); y = wdf_mulq(c, a); o[0] = wsub32(y, x[1]); o[1] = wsub32(y, x[0]); break;
+    case 0xD: c = wsub32(x[0], x[1]); y = wsub32(wdf_mulq(c, a), x[1]); o[0] = wadd32(y, c); o[1] = y; break;
+    default: o[0] = x[0]; o[1] = x[1]; break;
+    }
+}
+/* `Wdf::process` (src/iir/wdf.rs:153-169) */
+static int32_t wdf_step(const idsp_wdf *c, int32_t *z, int32_t x)
+{
+    int32_t y = 0;
+    int32_t *dst = &y;
+    uint32_t m = c->m;
+    for (int i = 0; i < c->n; i++, m >>= 4) {
+        int32_t in[2] = {x, z[i]}, o[2];
+        tpa_adapt(m & 0xf, c->a[i], in, o);
+        *dst = o[0];
+        x = o[1];
+        dst = &z[i];
+    }
+    *dst = x;
+    return y;
+}
+static int wdf_ok(const idsp_wdf *c, size_t n)
+{
+    for (size_t k = 0; k < n; k++) if (c[k].n < 1 || c[k].n > IDSP_WDF_MAX_ORDER) return 0;
+    return 1;
+}
+size_t idsp_ref_wdf_state_words(const idsp_wdf *cfg, size_t n)
+{
+    if (!cfg || !wdf_ok(cfg, n)) return 0;
+    size_t w = 0;
+    for (size_t k = 0; k < n; k++) w += (size_t)cfg[k].n;
+    return w;
+}
+/* `Wdf::quantize` (src/iir/wdf.rs:126-137) with `Tpa::quantize` (:50-62) */
+int idsp_ref_wdf_quantize(int n, uint32_t m, const double *g, idsp_wdf *out)
+{
+    if (!g || !out || n < 1 || n > IDSP_WDF_MAX_ORDER) return IDSP_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->n = n; out->m = m;
+    for (int i = 0; i < n; i++, m >>= 4) {
+        double a;
+        switch (m & 0xf) {
+        case 0xA: a = g[i] - 1.0; break;
+        case 0xB: case 0xE: a = -g[i]; break;
+        case 0xC: case 0xF: a = g[i]; break;
+        case 0xD: a = -1.0 - g[i]; break;
+        default: a = 0.0; break;
+        }
+        if (!(a >= -0.5 && a <= 0.0)) return IDSP_EOUTOFRANGE;
+        out->a[i] = idsp_ref_quantize_f64(a, 32);
+    }
+    return IDSP_OK;
+}
+int idsp_ref_wdf_i32(const idsp_wdf *cfg, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes,
+                     size_t frames, int layout)
+{
+    int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (!wdf_ok(cfg, n)) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        size_t w = 0;
+        if (n == 0)
+            for (size_t f = 0; f < frames; f++) { size_t i = idx_of(f, l, lanes, frames, layout); y[i] = x[i]; }
+        for (size_t k = 0; k < n; k++) { /* stage-major: section k over the whole lane, like compose.rs:43-77 */
+            int32_t z[IDSP_WDF_MAX_ORDER];
+            for (int i = 0; i < cfg[k].n; i++) z[i] = (int32_t)st[(w + i) * lanes + l];
+            const int32_t *src = k == 0 ? x : y;
+            for (size_t f = 0; f < frames; f++) {
+                size_t i = idx_of(f, l, lanes, frames, layout);
+                y[i] = wdf_step(&cfg[k], z, src[i]);
+            }
+            for (int i = 0; i < cfg[k].n; i++) st[(w + i) * lanes + l] = (uint32_t)z[i];
+            w += (size_t)cfg[k].n;
+        }
+    }
     return IDSP_OK;
 }
 

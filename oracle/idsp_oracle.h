@@ -114,6 +114,14 @@ size_t idsp_ref_fir_sym_state_words(const idsp_fir_sym_f32 *cfg);
 int idsp_ref_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const float *x, float *y,
                                  size_t lanes, size_t frames, int layout);
 
+/* Normal (src/iir/normal.rs) and Wdf (src/iir/wdf.rs) */
+int idsp_ref_normal_i32_df1(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_normal_f32_df1(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, float *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_normal_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_normal_from_sos(const double sos[6], double out[5]);
+int idsp_ref_wdf_quantize(int n, uint32_t m, const double *g, idsp_wdf *out);
+size_t idsp_ref_wdf_state_words(const idsp_wdf *cfg, size_t n_sections);
+int idsp_ref_wdf_i32(const idsp_wdf *cfg, size_t n_sections, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
 /* Cic (src/cic.rs) */
 int64_t idsp_ref_cic_gain(const idsp_cic *cfg);
 int idsp_ref_cic_gain_log2(const idsp_cic *cfg);

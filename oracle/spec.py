@@ -531,6 +531,100 @@ def atan2(y: int, x: int) -> int:
 
 
 # ----------------------------------------------------------------------------
+# Normal form (src/iir/normal.rs) and wave digital allpass sections (src/iir/wdf.rs)
+# ----------------------------------------------------------------------------
+def normal_i32(ba, frac: int, st: DirectForm1, x0: int) -> int:
+    """`Normal<Q32<F>>` x `DirectForm1<i32>` (normal.rs:43-57); ba = [b0, b1, b2, p.re, p.im];
+    st.y = [y0 (in-phase), y1 (quadrature)]."""
+    b0, b1, b2, re, im = ba
+    y0o, y1o = st.y
+    acc = i64(b0 * x0)
+    for c, v in ((b1, st.x[0]), (b2, st.x[1]), (re, y1o), (i32(-im), y0o)):
+        acc = i64(acc + c * v)
+    y1 = i32(acc >> frac)
+    y0 = i32(i64(im * y1o + re * y0o) >> frac)
+    st.x = [x0, st.x[0]]
+    st.y = [y0, y1]
+    return y0
+
+
+def normal_float(ba, st: DirectForm1, x0, F=np.float32):
+    """`Normal<f32|f64>` x `DirectForm1`: every product and sum rounded in F, left to right."""
+    b0, b1, b2, re, im = (F(v) for v in ba)
+    y0o, y1o = F(st.y[0]), F(st.y[1])
+    with np.errstate(all="ignore"):
+        acc = b0 * F(x0)
+        acc = acc + b1 * F(st.x[0])
+        acc = acc + b2 * F(st.x[1])
+        acc = acc + re * y1o
+        acc = acc + (-im) * y0o
+        y0 = im * y1o + re * y0o
+    st.x = [F(x0), F(st.x[0])]
+    st.y = [y0, acc]
+    return y0
+
+
+def normal_from_sos(sos):
+    """`From<&[[f64; 3]; 2]> for Normal<C>` (normal.rs:62-76) -> [b0, b1, b2, p.re, p.im] or None"""
+    a0 = 1.0 / sos[3]
+    p2 = -0.5 * sos[4]
+    pq = sos[3] * sos[5] - p2 * p2
+    if not pq >= 0.0:
+        return None
+    return [sos[0] * a0, sos[1] * a0, sos[2] * a0, p2 * a0, math.sqrt(pq) * a0]
+
+
+TPA = {"Z": 0x0, "A": 0xA, "B": 0xB, "B1": 0xE, "X": 0x1, "C": 0xC, "C1": 0xF, "D": 0xD}  # wdf.rs:14-32
+
+
+def _mulq32(c: int, a: int) -> int:
+    return i32((c * a) >> 32)
+
+
+def tpa_adapt(nib: int, a: int, x):
+    """`Tpa::adapt` (wdf.rs:65-100)"""
+    x0, x1 = x
+    if nib == 0xA:
+        c = i32(x1 - x0); y = i32(_mulq32(c, a) + x1); return [i32(y + c), y]
+    if nib == 0xB:
+        c = i32(x0 - x1); y = i32(_mulq32(c, a) + x1); return [y, i32(y + c)]
+    if nib == 0xE:
+        c = i32(x0 - x1); y = _mulq32(c, a); return [i32(y + x1), i32(y + x0)]
+    if nib == 0x1:
+        return [x1, x0]
+    if nib == 0xC:
+        c = i32(x1 - x0); y = i32(_mulq32(c, a) - x1); return [y, i32(y + c)]
+    if nib == 0xF:
+        c = i32(x1 - x0); y = _mulq32(c, a); return [i32(y - x1), i32(y - x0)]
+    if nib == 0xD:
+        c = i32(x0 - x1); y = i32(_mulq32(c, a) - x1); return [i32(y + c), y]
+    return [x0, x1]
+
+
+def tpa_quantize(nib: int, g: float):
+    """`Tpa::quantize` (wdf.rs:50-62) -> raw Q32<32> bits or None"""
+    a = {0xA: g - 1.0, 0xB: -g, 0xE: -g, 0xC: g, 0xF: g, 0xD: -1.0 - g}.get(nib, 0.0)
+    if not (-0.5 <= a <= 0.0):
+        return None
+    return quantize(a, 32)
+
+
+def wdf_process(n: int, m: int, a, z: list, x: int) -> int:
+    """`SplitProcess<i32, i32, WdfState<N>> for Wdf<N, M>` (wdf.rs:153-169): the fold writes the first
+    adaptor output into the PREVIOUS slot (the result for adaptor 0), the second output travels on."""
+    y = 0
+    for i in range(n):
+        o = tpa_adapt((m >> (4 * i)) & 0xF, a[i], [x, z[i]])
+        if i == 0:
+            y = o[0]
+        else:
+            z[i - 1] = o[0]
+        x = o[1]
+    z[n - 1] = x
+    return y
+
+
+# ----------------------------------------------------------------------------
 # Cic (src/cic.rs) and the modular composition its tests compare it with
 # ----------------------------------------------------------------------------
 class Cic:
