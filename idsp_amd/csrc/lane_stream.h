@@ -56,6 +56,17 @@ struct BatchOf<P, std::void_t<decltype(P::BATCH)>> {
     static constexpr int value = P::BATCH;
 };
 
+// Processors with a large per-sample body (many uniform branches) cap the register-window depth so that the
+// unrolled loop stays inside the instruction cache: `static constexpr int MAX_U`.
+template <class P, class = void>
+struct MaxU {
+    static constexpr int value = 24;
+};
+template <class P>
+struct MaxU<P, std::void_t<decltype(P::MAX_U)>> {
+    static constexpr int value = P::MAX_U;
+};
+
 // BATCH pre-stage values: processors may provide pre_batch(prm, Pre (&)[BATCH]) (e.g. to share
 // the work between the IN_DIV threads of a lane); the default evaluates pre() BATCH times.
 template <class P, class = void>
@@ -471,6 +482,8 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
                             to_words<Out>(p.step(prm, v, pre[b]), &tout[trow][(j0 + b) * OWR + tsub * OW]);
                         }
                     }
+                } else if constexpr (MaxU<P>::value < 24) {
+                    for (int j = 0; j < TS; j++) one(size_t(j));  // large body: keep the tile loop rolled
                 } else {
 #pragma unroll
                     for (int j = 0; j < TS; j++) one(size_t(j));
@@ -537,10 +550,11 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         // workgroups of 4) use one wave per workgroup (16384 lanes in 256-thread blocks would run on 64 CUs).
         const unsigned block = waves < 1024 ? unsigned(kWave) : unsigned(kFmBlock);
         const unsigned grid = unsigned((lanes + block - 1) / block);
+        constexpr int kDeep = MaxU<P>::value, kShallow = kDeep < 8 ? kDeep : 8;
         if (waves <= 2048)
-            hipLaunchKernelGGL((stream_frame_major<P, 24>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
+            hipLaunchKernelGGL((stream_frame_major<P, kDeep>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
         else
-            hipLaunchKernelGGL((stream_frame_major<P, 8>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
+            hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
     }
     return launch_status();
 }

@@ -10,64 +10,55 @@ namespace {
 // ------------------------------------------------------------------- Wdf
 constexpr int kWdfMaxSections = 4;  // sections fused per launch; longer chains run in passes
 
-struct WdfParams {
-    idsp_wdf sec[kWdfMaxSections];
-};
-
 // `i32 * Q32<32>` (dsp-fixedpoint/src/lib.rs:449-456)
 __device__ __forceinline__ int32_t mulq32(int32_t c, int32_t a) { return int32_t((int64_t(c) * int64_t(a)) >> 32); }
-__device__ __forceinline__ int32_t wadd32(int32_t a, int32_t b) { return int32_t(uint32_t(a) + uint32_t(b)); }
-__device__ __forceinline__ int32_t wsub32(int32_t a, int32_t b) { return int32_t(uint32_t(a) - uint32_t(b)); }
 
-// `Tpa::adapt` (src/iir/wdf.rs:65-100); x = [x0, x1] -> [o0, o1].  The nibble is wave-uniform.
-__device__ __forceinline__ void tpa_adapt(uint32_t nib, int32_t a, int32_t x0, int32_t x1, int32_t &o0, int32_t &o1)
+// One two-port adaptor `Tpa::adapt` (src/iir/wdf.rs:65-100) as host-precomputed integer coefficients.
+// Every variant is  c = s * (x1 - x0),  p = (c * a) >> 32,  o0 = p + k00*x0 + k01*x1,  o1 = p + k10*x0 + k11*x1
+// in wrapping 32-bit arithmetic (small integer multiples are exact mod 2^32):
+//   A : s=+1, o0 = p - x0 + 2 x1, o1 = p + x1        D : s=-1, o0 = p + x0 - 2 x1, o1 = p - x1
+//   B = B1: s=-1, o0 = p + x1, o1 = p + x0            C = C1: s=+1, o0 = p - x1,  o1 = p - x0
+//   X : a=0, o0 = x1, o1 = x0                         Z : a=0, o0 = x0, o1 = x1
+// (B1 / C1 only reassociate the same wrapping sums.)  No per-sample decoding of the architecture
+// nibbles: a first version with a uniform switch per adaptor spent its time in scalar compares,
+// branches and SGPR spills (2.9 ms instead of the 0.4 ms of a biquad at the C2 shape).
+struct Adaptor {
+    int32_t s, a, k00, k01, k10, k11;
+};
+
+template <int NMAX>
+struct WdfParamsT {
+    int32_t n[kWdfMaxSections];
+    Adaptor ad[kWdfMaxSections][NMAX];
+};
+
+inline Adaptor adaptor_of(uint32_t nib, int32_t a)
 {
     switch (nib) {
-        case 0xA: {
-            const int32_t c = wsub32(x1, x0), y = wadd32(mulq32(c, a), x1);
-            o0 = wadd32(y, c), o1 = y;
-            break;
-        }
-        case 0xB: {
-            const int32_t c = wsub32(x0, x1), y = wadd32(mulq32(c, a), x1);
-            o0 = y, o1 = wadd32(y, c);
-            break;
-        }
-        case 0xE: {
-            const int32_t c = wsub32(x0, x1), y = mulq32(c, a);
-            o0 = wadd32(y, x1), o1 = wadd32(y, x0);
-            break;
-        }
-        case 0x1: o0 = x1, o1 = x0; break;
-        case 0xC: {
-            const int32_t c = wsub32(x1, x0), y = wsub32(mulq32(c, a), x1);
-            o0 = y, o1 = wadd32(y, c);
-            break;
-        }
-        case 0xF: {
-            const int32_t c = wsub32(x1, x0), y = mulq32(c, a);
-            o0 = wsub32(y, x1), o1 = wsub32(y, x0);
-            break;
-        }
-        case 0xD: {
-            const int32_t c = wsub32(x0, x1), y = wsub32(mulq32(c, a), x1);
-            o0 = wadd32(y, c), o1 = y;
-            break;
-        }
-        default: o0 = x0, o1 = x1; break;  // Tpa::Z
+        case 0xA: return {1, a, -1, 2, 0, 1};
+        case 0xB: case 0xE: return {-1, a, 0, 1, 1, 0};
+        case 0xC: case 0xF: return {1, a, 0, -1, -1, 0};
+        case 0xD: return {-1, a, 1, -2, 0, -1};
+        case 0x1: return {0, 0, 0, 1, 1, 0};
+        default: return {0, 0, 1, 0, 0, 1};
     }
 }
 
-template <int K>
+// K sections padded to NMAX adaptors each.  Padding adaptors are Z on scratch state slots: the fold of
+// src/iir/wdf.rs:153-169 writes adaptor i's first output into slot i-1 and ends with `*z = x`, and a Z
+// adaptor at index n does exactly that final store (o0 = x -> z[n-1]); what flows on afterwards only touches
+// slots >= n, which are never written back.  The loops below are therefore fully static.
+template <int K, int NMAX>
 struct WdfChain {
+    static constexpr int MAX_U = 8;  // ~10 VALU per adaptor: keep the unrolled window inside the instruction cache
     using In = int32_t;
     using Out = int32_t;
     static constexpr bool HAS_IN = true;
     static constexpr int LDS_WORDS = 0;
     static constexpr int IN_DIV = 1;
-    static constexpr int COST = 40 * K;
-    using Params = WdfParams;
-    int32_t z[K][IDSP_WDF_MAX_ORDER];
+    static constexpr int COST = 200;  // never the LDS-DMA path
+    using Params = WdfParamsT<NMAX>;
+    int32_t z[K][NMAX];
 
     // state words: sections in order, N words each
     __device__ __forceinline__ void load(const Params &p, const uint32_t *st, size_t lanes, size_t lane)
@@ -76,8 +67,8 @@ struct WdfChain {
 #pragma unroll
         for (int k = 0; k < K; k++) {
 #pragma unroll
-            for (int i = 0; i < IDSP_WDF_MAX_ORDER; i++) z[k][i] = i < p.sec[k].n ? int32_t(st[size_t(w + i) * lanes + lane]) : 0;
-            w += p.sec[k].n;
+            for (int i = 0; i < NMAX; i++) z[k][i] = i < p.n[k] ? int32_t(st[size_t(w + i) * lanes + lane]) : 0;
+            w += p.n[k];
         }
     }
     __device__ __forceinline__ void store(const Params &p, uint32_t *st, size_t lanes, size_t lane)
@@ -86,39 +77,34 @@ struct WdfChain {
 #pragma unroll
         for (int k = 0; k < K; k++) {
 #pragma unroll
-            for (int i = 0; i < IDSP_WDF_MAX_ORDER; i++)
-                if (i < p.sec[k].n) st[size_t(w + i) * lanes + lane] = uint32_t(z[k][i]);
-            w += p.sec[k].n;
+            for (int i = 0; i < NMAX; i++)
+                if (i < p.n[k]) st[size_t(w + i) * lanes + lane] = uint32_t(z[k][i]);
+            w += p.n[k];
         }
     }
-    // src/iir/wdf.rs:153-169: adaptor i maps [x, z_i] -> [o0, o1]; o0 is the section output for i = 0 and
-    // the new z_{i-1} otherwise, o1 travels on as x; the last x becomes z_{N-1}
-    __device__ __forceinline__ Out step(const Params &p, In x)
+    __device__ __forceinline__ Out step(const Params &p, In xin)
     {
+        uint32_t x = uint32_t(xin);
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const idsp_wdf &c = p.sec[k];
-            int32_t y = 0;
-            uint32_t m = c.m;
+            uint32_t y = 0;
 #pragma unroll
-            for (int i = 0; i < IDSP_WDF_MAX_ORDER; i++) {
-                if (i < c.n) {
-                    int32_t o0, o1;
-                    tpa_adapt(m & 0xf, c.a[i], x, z[k][i], o0, o1);
-                    if (i == 0)
-                        y = o0;
-                    else
-                        z[k][i - 1] = o0;
-                    x = o1;
-                    m >>= 4;
-                }
+            for (int i = 0; i < NMAX; i++) {
+                const Adaptor &c = p.ad[k][i];
+                const uint32_t x0 = x, x1 = uint32_t(z[k][i]);
+                const uint32_t pr = uint32_t(mulq32(int32_t((x1 - x0) * uint32_t(c.s)), c.a));
+                const uint32_t o0 = pr + x0 * uint32_t(c.k00) + x1 * uint32_t(c.k01);
+                const uint32_t o1 = pr + x0 * uint32_t(c.k10) + x1 * uint32_t(c.k11);
+                if (i == 0)
+                    y = o0;
+                else
+                    z[k][i - 1] = int32_t(o0);
+                x = o1;
             }
-#pragma unroll
-            for (int i = 0; i < IDSP_WDF_MAX_ORDER; i++)
-                if (i == c.n - 1) z[k][i] = x;
+            z[k][NMAX - 1] = int32_t(x);
             x = y;
         }
-        return x;
+        return int32_t(x);
     }
 };
 
@@ -129,12 +115,26 @@ int wdf_cfg_check(const idsp_wdf *c, size_t n)
     return IDSP_OK;
 }
 
+template <int K, int NMAX>
+int wdf_launch_n(const idsp_wdf *c, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    WdfParamsT<NMAX> p{};
+    for (int k = 0; k < K; k++) {
+        p.n[k] = c[k].n;
+        uint32_t m = c[k].m;
+        for (int i = 0; i < NMAX; i++, m >>= 4) p.ad[k][i] = i < c[k].n ? adaptor_of(m & 0xf, c[k].a[i]) : adaptor_of(0, 0);
+    }
+    return launch_stream<WdfChain<K, NMAX>>(p, st, x, y, lanes, frames, layout, s);
+}
+
 template <int K>
 int wdf_launch(const idsp_wdf *c, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s)
 {
-    WdfParams p{};
-    for (int k = 0; k < K; k++) p.sec[k] = c[k];
-    return launch_stream<WdfChain<K>>(p, st, x, y, lanes, frames, layout, s);
+    int nmax = 0;
+    for (int k = 0; k < K; k++) nmax = c[k].n > nmax ? c[k].n : nmax;
+    if (nmax <= 2) return wdf_launch_n<K, 2>(c, st, x, y, lanes, frames, layout, s);
+    if (nmax <= 4) return wdf_launch_n<K, 4>(c, st, x, y, lanes, frames, layout, s);
+    return wdf_launch_n<K, IDSP_WDF_MAX_ORDER>(c, st, x, y, lanes, frames, layout, s);
 }
 
 }  // namespace

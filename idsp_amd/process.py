@@ -42,7 +42,7 @@ from ._lib import IdspError, call, load
 __all__ = [
     "FrameMajor", "LaneMajor", "View", "ViewMut", "Biquad", "BiquadClamp", "Cascade",
     "DirectForm1", "DirectForm2Transposed", "DirectForm1Wide", "DirectForm1Dither", "DirectForm",
-    "Split", "Lanes", "ByLane", "HbfDecCascade", "HbfIntCascade", "FirSym", "Cic", "HBF_TAPS", "HBF_TAPS_98",
+    "Split", "Lanes", "ByLane", "HbfDecCascade", "HbfIntCascade", "FirSym", "Cic", "Normal", "Wdf", "HBF_TAPS", "HBF_TAPS_98",
     "Lowpass", "Lockin", "Accu", "Dds", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
 ]
 
@@ -522,6 +522,113 @@ class FirSym(_LaneOp):
 
     def _run(self, x, y, frames, layout):
         call("fir_sym_f32_process", C.byref(self.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
+             C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
+
+
+class Normal:
+    """`iir::normal::Normal<C>` (src/iir/normal.rs:28-35): feed-forward b[3] and the pole p = re + j im.
+    `frac=F`: `Normal<Q32<F>>` on i32 samples (raw bits), else f32, or f64 with `f64=True`."""
+
+    def __init__(self, b: Sequence, p: Sequence, frac: Optional[int] = None, f64: bool = False):
+        if len(b) != 3 or len(p) != 2:
+            raise ValueError("Normal: b has 3 entries, p = (re, im)")
+        conv = int if frac is not None else float
+        self.ba = [conv(v) for v in list(b) + list(p)]
+        self.frac, self.f64 = frac, f64
+
+    @classmethod
+    def from_ba(cls, ba: Sequence[Sequence[float]]) -> "Normal":
+        """`Normal::<f64>::from(&[[b0,b1,b2],[a0,a1,a2]])` (normal.rs:62-76); real poles raise like the assert."""
+        load()
+        out = (C.c_double * 5)()
+        call("normal_from_sos", (C.c_double * 6)(*(list(ba[0]) + list(ba[1]))), out)
+        return cls(list(out)[:3], list(out)[3:], f64=True)
+
+    def lanes(self, n: int, device="cuda") -> "_NormalLanes":
+        """`Split::new(normal, DirectForm1::default()).lanes::<N>()`"""
+        return _NormalLanes([self], n, device)
+
+
+class _NormalLanes(_LaneOp):
+    def __init__(self, sections: Sequence[Normal], n: int, device):
+        first = sections[0]
+        self._n = len(sections)
+        if first.frac is not None:
+            self._cfg = (_abi.BiquadI32 * self._n)()
+            for a, s in zip(self._cfg, sections):
+                a.ba[:] = s.ba
+                a.frac = s.frac
+            self._name, dt = "normal_i32_df1", torch.int32
+        elif first.f64:
+            self._cfg = (_abi.BiquadF64 * self._n)()
+            for a, s in zip(self._cfg, sections):
+                a.ba[:] = s.ba
+            self._name, dt = "normal_f64_df1", torch.float64
+        else:
+            self._cfg = (_abi.BiquadF32 * self._n)()
+            for a, s in zip(self._cfg, sections):
+                a.ba[:] = s.ba
+            self._name, dt = "normal_f32_df1", torch.float32
+        self.dtype_in = self.dtype_out = dt
+        super().__init__(n, 4 * self._n * (2 if dt == torch.float64 else 1), device)
+
+    def _run(self, x, y, frames, layout):
+        call(self._name, C.cast(self._cfg, C.c_void_p), self._n, C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
+             C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
+
+
+class Wdf:
+    """`iir::wdf::Wdf<N, M>` (src/iir/wdf.rs:103-137): N two-port adaptors typed by the nibbles of M.
+    `Wdf.quantize(m, g)` is `Wdf::<N, M>::quantize(&g)` (None when a pole does not fit its adaptor);
+    a list of sections passed to `Wdf.chain([...]).lanes(n)` runs them in series."""
+
+    def __init__(self, cfg: _abi.Wdf):
+        self.cfg = cfg
+
+    @classmethod
+    def quantize(cls, m: int, g: Sequence[float]) -> Optional["Wdf"]:
+        load()
+        out = _abi.Wdf()
+        rc = load()[0]["wdf_quantize"](len(g), m, (C.c_double * len(g))(*g), C.byref(out))
+        if rc == _abi.IDSP_EOUTOFRANGE:
+            return None
+        if rc < 0:
+            raise ValueError("Wdf: order 1..8")
+        return cls(out)
+
+    @classmethod
+    def default(cls, n: int, m: int) -> "Wdf":
+        """`Wdf::<N, M>::default()` (wdf.rs:108-114): zero coefficients"""
+        c = _abi.Wdf()
+        c.n, c.m = n, m
+        return cls(c)
+
+    @staticmethod
+    def chain(sections: Sequence["Wdf"]) -> "_WdfChain":
+        return _WdfChain(list(sections))
+
+    def lanes(self, n: int, device="cuda") -> "_WdfChain":
+        return _WdfChain([self]).lanes(n, device)
+
+
+class _WdfChain(_LaneOp):
+    dtype_in = dtype_out = torch.int32
+
+    def __init__(self, sections: Sequence[Wdf]):
+        load()
+        self._n = len(sections)
+        self._cfg = (_abi.Wdf * max(self._n, 1))()
+        for d, s in zip(self._cfg, sections):
+            d.n, d.m = s.cfg.n, s.cfg.m
+            d.a[:] = list(s.cfg.a)
+
+    def lanes(self, n: int, device="cuda") -> "_WdfChain":
+        words = call("wdf_state_words", C.cast(self._cfg, C.c_void_p), self._n)
+        _LaneOp.__init__(self, n, max(words, 1), device)
+        return self
+
+    def _run(self, x, y, frames, layout):
+        call("wdf_i32", C.cast(self._cfg, C.c_void_p), self._n, C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
              C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
 
 

@@ -745,6 +745,73 @@ private:
 using HbfDecCascade = HbfCascade<true>;
 using HbfIntCascade = HbfCascade<false>;
 
+/// `iir::normal::Normal<C>` (src/iir/normal.rs:28-35) x `DirectForm1`: the record is `Biquad<C>` with
+/// ba = [b0, b1, b2, p.re, p.im]; `Split(normal, DirectForm1{})`-style lanes.
+template <class C>
+class NormalLanes {
+public:
+    using Sample = typename Biquad<C>::Sample;
+    NormalLanes(const std::vector<Biquad<C>> &sections, size_t lanes, void *stream = nullptr)
+        : lanes_(lanes), stream_(stream), state_(size_t(4) * (sizeof(Sample) / 4) * (sections.empty() ? 1 : sections.size()) * lanes)
+    {
+        for (const auto &c : sections) abi_.push_back(detail::to_abi(c));
+    }
+    /// `Normal::<f64>::from(&[[b0,b1,b2],[a0,a1,a2]])` (normal.rs:62-76) as the ba record; throws for real poles
+    static Biquad<double> from_ba(const std::array<double, 6> &sos)
+    {
+        Biquad<double> b;
+        check(idsp_normal_from_sos(sos.data(), b.ba.data()));
+        return b;
+    }
+    DeviceBuffer<uint32_t> &state() { return state_; }
+    template <class Layout>
+    void process_view(View<Sample, Layout> x, ViewMut<Sample, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        if constexpr (std::is_same<Sample, int32_t>::value)
+            check(idsp_normal_i32_df1(abi_.data(), abi_.size(), state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+        else if constexpr (std::is_same<Sample, float>::value)
+            check(idsp_normal_f32_df1(abi_.data(), abi_.size(), state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+        else
+            check(idsp_normal_f64_df1(abi_.data(), abi_.size(), state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
+
+private:
+    size_t lanes_;
+    void *stream_;
+    std::vector<decltype(detail::to_abi(std::declval<Biquad<C>>()))> abi_;
+    DeviceBuffer<uint32_t> state_;
+};
+
+/// Serial chain of `iir::wdf::Wdf<N, M>` sections (src/iir/wdf.rs:103-171) over `lanes` lanes.
+class WdfLanes {
+public:
+    /// `Wdf::<N, M>::quantize(&g)` (wdf.rs:126-137); throws Error(IDSP_EOUTOFRANGE) where the reference returns None
+    static idsp_wdf quantize(uint32_t m, const std::vector<double> &g)
+    {
+        idsp_wdf w;
+        check(idsp_wdf_quantize(int(g.size()), m, g.data(), &w));
+        return w;
+    }
+    WdfLanes(const std::vector<idsp_wdf> &sections, size_t lanes, void *stream = nullptr)
+        : sec_(sections), lanes_(lanes), stream_(stream), state_(idsp_wdf_state_words(sections.data(), sections.size()) * lanes)
+    {
+    }
+    DeviceBuffer<uint32_t> &state() { return state_; }
+    template <class Layout>
+    void process_view(View<int32_t, Layout> x, ViewMut<int32_t, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        check(idsp_wdf_i32(sec_.data(), sec_.size(), state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
+
+private:
+    std::vector<idsp_wdf> sec_;
+    size_t lanes_;
+    void *stream_;
+    DeviceBuffer<uint32_t> state_;
+};
+
 /// `Cic<T, N, M>::new(rate)` (src/cic.rs:13-47), T = int32_t or int64_t, chunked as
 /// `Split::stateful(cic).decimate()` / `.interpolate()` (src/cic.rs:338-346) over `lanes` lanes.
 template <class T, bool DEC>

@@ -205,6 +205,19 @@ int main()
         auto o = yi.to_host();
         for (size_t i = up.response_length(); i < o.size(); i++) EXPECT(o[i] == 640);
     }
+    // `Wdf<1, 0x1>::default()` is a unit delay; the bench's 0xad section quantises (tests/embedded/src/bin/biquad.rs:126)
+    {
+        idsp_wdf d{1, 0x1, {0}};
+        WdfLanes w({d}, 1);
+        DeviceBuffer<int32_t> x(std::vector<int32_t>{1, 2, 3, 4}), y(4);
+        w.process_view(View<int32_t, LaneMajor>::from_flat(x, 1), ViewMut<int32_t, LaneMajor>::from_flat(y, 1));
+        EXPECT((y.to_host() == std::vector<int32_t>{0, 1, 2, 3}));
+        auto q = WdfLanes::quantize(0xad, {-0.9, 0.9});
+        EXPECT(q.n == 2 && q.a[0] < 0 && q.a[1] < 0);
+        // Normal::from (normal.rs:62-76): |p|^2 = a2 / a0
+        auto nb = NormalLanes<double>::from_ba({0.2, 0.4, 0.2, 1.0, -1.2, 0.52});
+        EXPECT(std::fabs(nb.ba[3] * nb.ba[3] + nb.ba[4] * nb.ba[4] - 0.52) < 1e-12);
+    }
     // contract violations are reported as errors, never aborts
     {
         bool threw = false;

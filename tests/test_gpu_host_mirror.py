@@ -214,3 +214,30 @@ def test_cic_reference_properties():
     assert yd[-1].item() == 10 * 64 * 64
     with pytest.raises(ValueError):
         ia.Cic(0, 3)
+
+
+def test_normal_and_wdf_lanes():
+    """`Normal::from` (src/iir/normal.rs:62-76) and `Wdf` (src/iir/wdf.rs) through the mirror."""
+    nf = ia.Normal.from_ba([[0.2, 0.4, 0.2], [1.0, -1.2, 0.52]])
+    assert abs(nf.ba[3] ** 2 + nf.ba[4] ** 2 - 0.52) < 1e-12
+    with pytest.raises(ia.IdspError):
+        ia.Normal.from_ba([[1, 0, 0], [1.0, -3.0, 1.0]])  # real poles: assert!(pq >= 0.0)
+    p = nf.lanes(2)
+    x = torch.zeros(50, 2, dtype=torch.float64, device="cuda")
+    x[0] = 1.0
+    y = torch.empty_like(x)
+    p.block(x, y)
+    assert torch.equal(y[:, 0], y[:, 1]) and y[1, 0].item() != 0.0 and abs(y[-1, 0].item()) < 1e-3
+    delay = ia.Wdf.default(1, 0x1).lanes(1)
+    xi = dev([[1], [2], [3], [4]], torch.int32)
+    yi = torch.empty_like(xi)
+    delay.block(xi, yi)
+    assert yi.flatten().tolist() == [0, 1, 2, 3]
+    assert ia.Wdf.quantize(0xA, [0.3]) is None and ia.Wdf.quantize(0xAD, [-0.9, 0.9]).cfg.n == 2
+    chain = ia.Wdf.chain([ia.Wdf.quantize(0xAD, [-0.9, 0.9]), ia.Wdf.quantize(0xA, [0.8])]).lanes(3)
+    assert chain.state.shape == (3, 3)
+    xs = (torch.randn(4000, 3, device="cuda") * (1 << 20)).to(torch.int32)
+    ys = torch.empty_like(xs)
+    chain.block(xs, ys)
+    ex, ey = (xs.double() ** 2).sum().item(), (ys.double() ** 2).sum().item()
+    assert abs(ey / ex - 1.0) < 5e-3  # allpass

@@ -204,6 +204,22 @@ def cic(kind, dtype, order, rate, lanes, frames, layout, iters, tag):
            (R + 1) * esz * lanes * frames, med, mn)
 
 
+def wdf(lanes, frames, layout, iters, tag):
+    """three 2nd-order + one 1st-order section: the 7th-order branch of the reference's embedded bench"""
+    secs = (_abi.Wdf * 4)()
+    for d, (m, g) in zip(secs, [(0xAD, [-0.9, 0.9]), (0xAD, [-0.6, 0.7]), (0xAD, [-0.7, 0.6]), (0xA, [0.8])]):
+        call("wdf_quantize", len(g), m, (C.c_double * len(g))(*g), C.byref(d))
+    x = torch.randint(-(1 << 24), 1 << 24, (lanes * frames,), dtype=torch.int32, device=dev)
+    y = torch.empty_like(x)
+    st = torch.zeros((7, lanes), dtype=torch.int32, device=dev)
+
+    def run():
+        call("wdf_i32", C.cast(secs, C.c_void_p), 4, p(st), p(x), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:wdf 7th order {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample", 8 * lanes * frames, med, mn)
+
+
 def cossin(n, iters, tag):
     ph = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device=dev).to(torch.int32)
     out = torch.empty(2 * n, dtype=torch.int32, device=dev)
@@ -283,6 +299,11 @@ def main():
         for s in (1, 2, 3, 5):
             hbf("dec", s, 16384, 65536 >> s, LM, it, "hbf")
             hbf("int", s, 16384, 65536 >> s, LM, it, "hbf")
+    if want("nw"):
+        biquad("normal_i32_df1", torch.int32, 4, 65536, 4096, FM, 1, it, "nw")
+        biquad("normal_f32_df1", torch.float32, 4, 65536, 4096, FM, 1, it, "nw")
+        wdf(65536, 4096, FM, it, "nw")
+        wdf(65536, 4096, LM, it, "nw")
     if want("cic"):
         for layout in (FM, LM):
             cic("dec", torch.int32, 3, 15, 16384, 4096, layout, it, "cic")
