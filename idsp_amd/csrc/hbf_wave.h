@@ -275,7 +275,10 @@ template <class C, int s, bool FULL, bool LM>
 __device__ __forceinline__ void int_stage(float *lds, int n_rt, float *y, size_t lanes, size_t frames, size_t lane,
                                           size_t f0, int lid)
 {
-    constexpr int M = C::M(s), N = C::n(s), P = blocking(N), R = C::rate;
+    // the last stage stores to global memory: with P = 2 a thread owns 4 consecutive outputs = one 16-byte
+    // store, so a wave instruction writes 1 KiB of whole lines (P = 4 puts 32 bytes per thread behind two
+    // instructions that each cover half of every line)
+    constexpr int M = C::M(s), N = C::n(s), P = (s + 1 == C::stages && blocking(N) > 2) ? 2 : blocking(N), R = C::rate;
     constexpr int dx = pad4(2 * M - 1), ox = dx % P, NV = (ox + 2 * M + P - 1 + P - 1) / P;
     constexpr int ITER = (N / P + kW - 1) / kW;
     const float *X = lds + C::offA(s) + (dx - ox);

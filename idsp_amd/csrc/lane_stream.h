@@ -530,7 +530,8 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             // cheap per-sample arithmetic (the extra LDS hop and the two barriers per tile cost issue
             // slots), <= 2 waves per SIMD, whole 256-lane blocks, 16-byte aligned rows: LDS-DMA path
             static const int lds_cost_max = getenv("IDSP_LDS_COST") ? atoi(getenv("IDSP_LDS_COST")) : 120;
-            if (P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= 2048 && lanes % kFmBlock == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+            static const size_t lds_max_waves = getenv("IDSP_LDS_MAX_WAVES") ? size_t(atoll(getenv("IDSP_LDS_MAX_WAVES"))) : size_t(2048);
+            if (P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                 reinterpret_cast<uintptr_t>(y) % 16 == 0 && !getenv("IDSP_NO_LDS_PATH")) {
                 constexpr size_t ow = sizeof(typename P::Out) / 4;
                 constexpr size_t bytes = (size_t(kLdsNB) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
