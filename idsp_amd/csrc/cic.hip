@@ -208,18 +208,39 @@ __global__ __launch_bounds__(kBlock) void cic_int_kernel(const idsp_cic cfg, uin
     const size_t hstride = fm ? lanes * R : R;
     const T *lp = x + (fm ? lane : lane * frames);
     const size_t lstride = fm ? lanes : 1;
+    // FRAME_MAJOR, whole wave: the 64 chunks of a frame are one contiguous run of 64 * VPC vectors.  Writing
+    // each thread's own chunk directly means 16-byte pieces at a VPC*16-byte lane stride (<= 3.7 TB/s,
+    // tools/ubench_pattern.hip); instead the wave transposes the frame through a padded LDS tile and every
+    // store instruction writes 1 KiB of whole lines (6.6 TB/s for that shape).
+    using VT = typename Vec16<T>::type;
+    __shared__ VT tile[VPC > 0 ? kBlock * (VPC + 1) : 1];
+    const bool transposed = VPC > 0 && fm && (size_t(blockIdx.x) + 1) * kBlock <= lanes;
+    const int lid = threadIdx.x;
     auto chunk = [&](size_t f, T xin) {
         c.zoh = c.combs(xin, m);
         T *row = hp + f * hstride;
         if constexpr (VPC > 0) {
             using V = Vec16<T>;
             typename V::type *vr = reinterpret_cast<typename V::type *>(row);
+            typename V::type v[VPC];
 #pragma unroll
-            for (int i = 0; i < VPC; i++) {
-                typename V::type v;
+            for (int i = 0; i < VPC; i++)
 #pragma unroll
-                for (int k = 0; k < V::n; k++) v[k] = c.integrate(c.zoh);
-                vr[i] = v;
+                for (int k = 0; k < V::n; k++) v[i][k] = c.integrate(c.zoh);
+            if (transposed) {
+#pragma unroll
+                for (int i = 0; i < VPC; i++) tile[lid * (VPC + 1) + i] = v[i];
+                lds_wave_sync();
+                VT *run = reinterpret_cast<VT *>(y + (f * lanes + size_t(blockIdx.x) * kBlock) * R);
+#pragma unroll
+                for (int k = 0; k < VPC; k++) {
+                    const int j = k * kBlock + lid;  // vector j of the run = vector j % VPC of lane j / VPC
+                    run[j] = tile[(j / VPC) * (VPC + 1) + (j % VPC)];
+                }
+                lds_wave_sync();
+            } else {
+#pragma unroll
+                for (int i = 0; i < VPC; i++) vr[i] = v[i];
             }
         } else {
             for (size_t r = 0; r < R; r++) row[r] = c.integrate(c.zoh);
