@@ -278,6 +278,185 @@ __global__ __launch_bounds__(kBlock) void cic_int_kernel(const idsp_cic cfg, uin
     c.store(st, lanes, lane, m);
 }
 
+// ------------------------------------------------------------ LANE_MAJOR tiles
+// In LANE_MAJOR a lane's chunk stream is one contiguous row, rows are frames*R elements apart: per-thread
+// 16-byte pieces touch 64 different lines per instruction (dec 2.8-3.1, int 3.1 TB/s at 16384 lanes).  A wave
+// therefore moves tiles of 64 lanes x kTileVecs vectors (= F = kTileVecs / VPC frames): every global
+// instruction covers 4 lanes x 256 contiguous bytes, and a padded LDS tile (row stride kTileVecs + 1
+// vectors: conflict-free b128 on both sides) hands each thread its own row.  Whole waves only; frames
+// beyond the last whole tile take the per-thread path.
+constexpr int kTileVecs = 16;
+constexpr int kLmTilesAhead = 4;  // dec: tiles in flight per wave (register ring, 64 KiB)
+
+template <class T, int N, int VPC>
+__global__ __launch_bounds__(kBlock) void cic_dec_lm_kernel(const idsp_cic cfg, uint32_t *st, const T *x, T *y, const size_t lanes,
+                                                             const size_t frames)
+{
+    using V = Vec16<T>;
+    using VT = typename V::type;
+    constexpr int F = kTileVecs / VPC;  // frames per tile
+    __shared__ VT tile[kBlock * (kTileVecs + 1)];
+    const int lid = threadIdx.x;
+    const size_t lane0 = size_t(blockIdx.x) * kBlock, lane = lane0 + lid;
+    const size_t R = size_t(cfg.rate) + 1;
+    const int m = cfg.comb_delay;
+    CicRegs<T, N> c;
+    c.load(st, lanes, lane, m);
+    const size_t ntiles = frames / F;
+    // instruction k of a tile: lanes 4k .. 4k+3, this thread moves vector lid % 16 of lane 4k + lid / 16
+    const VT *src = reinterpret_cast<const VT *>(x + (lane0 + size_t(lid / kTileVecs)) * frames * R) + lid % kTileVecs;
+    const size_t lane4 = 4 * frames * R / V::n;  // vectors between lane groups
+    VT ring[kLmTilesAhead][kTileVecs];
+    auto fetch = [&](int u, size_t t) {
+#pragma unroll
+        for (int k = 0; k < kTileVecs; k++) ring[u][k] = src[size_t(k) * lane4 + t * kTileVecs];
+    };
+    T *yrow = y + lane * frames;
+    const bool vec_out = (frames * sizeof(T)) % 16 == 0;  // rows of y start 16-byte aligned (y itself is, checked by the host)
+    auto process = [&](int u, size_t t) {
+#pragma unroll
+        for (int k = 0; k < kTileVecs; k++) tile[(4 * k + lid / kTileVecs) * (kTileVecs + 1) + lid % kTileVecs] = ring[u][k];
+        lds_wave_sync();
+        T out[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            T first{};
+#pragma unroll
+            for (int i = 0; i < VPC; i++) {
+                const VT v = tile[lid * (kTileVecs + 1) + f * VPC + i];
+#pragma unroll
+                for (int e = 0; e < V::n; e++) {
+                    const T w = c.integrate(v[e]);
+                    if (i == 0 && e == 0) first = w;
+                }
+            }
+            c.zoh = c.combs(first, m);
+            out[f] = c.zoh;
+        }
+        lds_wave_sync();
+        // the F outputs of a tile are contiguous in this lane's row: 16-byte stores when they fill vectors
+        if constexpr ((F * sizeof(T)) % 16 == 0) {
+            if (vec_out) {
+#pragma unroll
+                for (int f = 0; f < F; f += V::n) {
+                    VT v;
+#pragma unroll
+                    for (int e = 0; e < V::n; e++) v[e] = out[f + e];
+                    *reinterpret_cast<VT *>(yrow + t * F + f) = v;
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < F; f++) yrow[t * F + f] = out[f];
+    };
+#pragma unroll
+    for (int u = 0; u < kLmTilesAhead; u++)
+        if (size_t(u) < ntiles) fetch(u, size_t(u));
+    size_t t = 0;
+    for (; t + 2 * kLmTilesAhead <= ntiles; t += kLmTilesAhead) {
+#pragma unroll
+        for (int u = 0; u < kLmTilesAhead; u++) {
+            process(u, t + u);
+            fetch(u, t + u + kLmTilesAhead);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kLmTilesAhead; u++) {
+        if (t + u < ntiles) {
+            process(u, t + u);
+            if (t + u + kLmTilesAhead < ntiles) fetch(u, t + u + kLmTilesAhead);
+        }
+    }
+    t += kLmTilesAhead;
+#pragma unroll
+    for (int u = 0; u < kLmTilesAhead; u++)
+        if (t + u < ntiles) process(u, t + u);
+    // frames beyond the last whole tile: per-thread pieces
+    const T *hp = x + lane * frames * R;
+    for (size_t f = ntiles * F; f < frames; f++) {
+        const T *row = hp + f * R;
+        const T first = c.integrate(row[0]);
+        c.zoh = c.combs(first, m);
+        for (size_t r = 1; r < R; r++) c.integrate(row[r]);
+        yrow[f] = c.zoh;
+    }
+    c.store(st, lanes, lane, m);
+}
+
+template <class T, int N, int VPC>
+__global__ __launch_bounds__(kBlock) void cic_int_lm_kernel(const idsp_cic cfg, uint32_t *st, const T *x, T *y, const size_t lanes,
+                                                             const size_t frames)
+{
+    using V = Vec16<T>;
+    using VT = typename V::type;
+    constexpr int F = kTileVecs / VPC;
+    __shared__ VT tile[kBlock * (kTileVecs + 1)];
+    const int lid = threadIdx.x;
+    const size_t lane0 = size_t(blockIdx.x) * kBlock, lane = lane0 + lid;
+    const size_t R = size_t(cfg.rate) + 1;
+    const int m = cfg.comb_delay;
+    CicRegs<T, N> c;
+    c.load(st, lanes, lane, m);
+    const size_t ntiles = frames / F;
+    VT *dst = reinterpret_cast<VT *>(y + (lane0 + size_t(lid / kTileVecs)) * frames * R) + lid % kTileVecs;
+    const size_t lane4 = 4 * frames * R / V::n;
+    const T *xrow = x + lane * frames;
+    // inputs of kInTiles tiles ahead, so that waiting for one does not drain the row stores issued since
+    constexpr int kInTiles = 8;
+    T ring[kInTiles][F];
+    auto fetch = [&](int u, size_t t) {
+#pragma unroll
+        for (int f = 0; f < F; f++) ring[u][f] = xrow[t * F + f];
+    };
+    auto process = [&](int u, size_t t) {
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            c.zoh = c.combs(ring[u][f], m);
+#pragma unroll
+            for (int i = 0; i < VPC; i++) {
+                VT v;
+#pragma unroll
+                for (int e = 0; e < V::n; e++) v[e] = c.integrate(c.zoh);
+                tile[lid * (kTileVecs + 1) + f * VPC + i] = v;
+            }
+        }
+        lds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < kTileVecs; k++)
+            dst[size_t(k) * lane4 + t * kTileVecs] = tile[(4 * k + lid / kTileVecs) * (kTileVecs + 1) + lid % kTileVecs];
+        lds_wave_sync();
+    };
+#pragma unroll
+    for (int u = 0; u < kInTiles; u++)
+        if (size_t(u) < ntiles) fetch(u, size_t(u));
+    size_t t = 0;
+    for (; t + 2 * kInTiles <= ntiles; t += kInTiles) {
+#pragma unroll
+        for (int u = 0; u < kInTiles; u++) {
+            process(u, t + u);
+            fetch(u, t + u + kInTiles);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kInTiles; u++) {
+        if (t + u < ntiles) {
+            process(u, t + u);
+            if (t + u + kInTiles < ntiles) fetch(u, t + u + kInTiles);
+        }
+    }
+    t += kInTiles;
+#pragma unroll
+    for (int u = 0; u < kInTiles; u++)
+        if (t + u < ntiles) process(u, t + u);
+    T *hp = y + lane * frames * R;
+    for (size_t f = ntiles * F; f < frames; f++) {
+        c.zoh = c.combs(xrow[f], m);
+        for (size_t r = 0; r < R; r++) hp[f * R + r] = c.integrate(c.zoh);
+    }
+    c.store(st, lanes, lane, m);
+}
+
 inline int cfg_check(const idsp_cic *c)
 {
     if (!c) return fail(IDSP_EINVAL, "cfg is NULL");
@@ -287,8 +466,9 @@ inline int cfg_check(const idsp_cic *c)
     return IDSP_OK;
 }
 
-template <class T, bool DEC>
-int run(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout, void *stream)
+// Orders NLO .. NLO+2; the two halves (NLO = 1, 4) are instantiated in separate translation units.
+template <class T, bool DEC, int NLO>
+int run_orders(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout, void *stream)
 {
     int rc = cfg_check(cfg);
     if (rc) return rc;
@@ -305,8 +485,21 @@ int run(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes, size_t
         const size_t v = R / V::n;
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) vpc = int(v);
     }
+    // LANE_MAJOR tile kernels: whole waves, at least one whole tile
+    const bool lm_tiles = layout == IDSP_LANE_MAJOR && vpc > 0 && lanes % kBlock == 0 && frames >= size_t(kTileVecs / (vpc ? vpc : 1)) &&
+                          reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+                          (frames * R * sizeof(T)) % 16 == 0 && !getenv("IDSP_CIC_NO_LM_TILES");
 #define IDSP_CIC_LAUNCH(NN, VV)                                                                                       \
     do {                                                                                                              \
+        if constexpr (VV > 0) {                                                                                       \
+            if (lm_tiles) {                                                                                           \
+                if constexpr (DEC)                                                                                    \
+                    hipLaunchKernelGGL((cic_dec_lm_kernel<T, NN, VV>), grid, block, 0, s, *cfg, st, x, y, lanes, frames); \
+                else                                                                                                  \
+                    hipLaunchKernelGGL((cic_int_lm_kernel<T, NN, VV>), grid, block, 0, s, *cfg, st, x, y, lanes, frames); \
+                break;                                                                                                \
+            }                                                                                                         \
+        }                                                                                                             \
         if constexpr (DEC)                                                                                            \
             hipLaunchKernelGGL((cic_dec_kernel<T, NN, VV>), grid, block, 0, s, *cfg, st, x, y, lanes, frames, layout); \
         else                                                                                                          \
@@ -324,16 +517,22 @@ int run(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes, size_t
         }                                            \
         break;
     switch (cfg->order) {
-        IDSP_CIC_CASE(1)
-        IDSP_CIC_CASE(2)
-        IDSP_CIC_CASE(3)
-        IDSP_CIC_CASE(4)
-        IDSP_CIC_CASE(5)
-        IDSP_CIC_CASE(6)
+        IDSP_CIC_CASE(NLO)
+        IDSP_CIC_CASE(NLO + 1)
+        IDSP_CIC_CASE(NLO + 2)
     }
 #undef IDSP_CIC_CASE
 #undef IDSP_CIC_LAUNCH
     return launch_status();
+}
+
+template <class T, bool DEC>
+int run(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout, void *stream)
+{
+    const int rc = cfg_check(cfg);
+    if (rc) return rc;
+    return cfg->order <= 3 ? run_orders<T, DEC, 1>(cfg, state, x, y, lanes, frames, layout, stream)
+                           : run_orders<T, DEC, 4>(cfg, state, x, y, lanes, frames, layout, stream);
 }
 
 

@@ -52,3 +52,26 @@ def test_cic_errors_and_helpers(bes):
     st = np.zeros((16, 1), np.uint32)
     assert K.run(gb, "dec", np.int32, _abi.Cic(0, 1, 1), st, x, 1, 4, K.LM)[0] == -1 and "order" in H.engine().err()
     assert K.run(gb, "int", np.int32, _abi.Cic(3, 5, 1), st, x, 1, 4, K.LM)[0] == -1 and "cic.rs:36" in H.engine().err()
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64], ids=["i32", "i64"])
+@pytest.mark.parametrize("kind", ["dec", "int"])
+def test_cic_lane_major_tile_kernels(bes, kind, dtype):
+    """Whole waves + vector chunk widths take the LANE_MAJOR tile kernels (64 lanes x 16 vectors through LDS);
+    frame counts that are and are not whole tiles, continuation, every chunk width with a tile kernel."""
+    ob, gb = bes
+    rng = np.random.default_rng(90 + (1 if kind == "dec" else 0) + (2 if dtype == np.int64 else 0))
+    epv = 16 // np.dtype(dtype).itemsize
+    for vpc, lanes, frames in [(1, 64, 40), (2, 128, 37), (4, 192, 64), (8, 64, 19), (16, 128, 8), (4, 64, 3)]:
+        R = vpc * epv
+        cfg = _abi.Cic(int(rng.integers(1, 7)), int(rng.integers(1, 5)), R - 1)
+        words = K.state_words(gb, cfg, dtype)
+        init = K.random_state(rng, words, lanes)
+        so, sg = init.copy(), init.copy()
+        for part in range(2):
+            x = K.samples(rng, dtype, lanes * frames * (R if kind == "dec" else 1))
+            rco, yo = K.run(ob, kind, dtype, cfg, so, x, lanes, frames, K.LM)
+            rcg, yg = K.run(gb, kind, dtype, cfg, sg, x, lanes, frames, K.LM)
+            assert rco == 0 and rcg == 0, H.engine().err()
+            assert np.array_equal(yo, yg), (vpc, lanes, frames, cfg.order, cfg.comb_delay)
+            assert np.array_equal(so, sg)
