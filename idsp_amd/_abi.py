@@ -71,6 +71,13 @@ class Wdf(C.Structure):
     _fields_ = [("n", C.c_int32), ("m", C.c_uint32), ("a", C.c_int32 * WDF_MAX_ORDER)]
 
 
+class FmDisc(C.Structure):
+    _fields_ = [("carrier", C.c_int32), ("deemph", BiquadI32)]
+
+
+FM_DISC_STATE_WORDS = 7
+
+
 class Cic(C.Structure):
     _fields_ = [("order", C.c_int32), ("comb_delay", C.c_int32), ("rate", C.c_uint32)]
 
@@ -168,6 +175,7 @@ PROCESSING = {
     "dds_i32": [_P, _P, _SZ, _SZ, _I, _P],
     "lockin_i32_process": _CFG_SIG,
     "lowpass_i32": _CFG_SIG,
+    "fm_disc_i32": _CFG_SIG,
 }
 
 # host-side helpers present in both libraries (same signature)

@@ -9,6 +9,7 @@
 // lowpass cascade so a phase never touches memory.
 #include "atan2_table.h"
 #include "cossin_table.h"
+#include "biquad_sections.h"
 #include "lane_stream.h"
 
 namespace idsp {
@@ -423,6 +424,59 @@ __global__ __launch_bounds__(256) void atan2_kernel(const Cplx *xy, int32_t *out
     }
 }
 
+// FM discriminator + deemphasis (examples/fm_disc.rs:25-50).  In = Complex<Q32<32>> bits as a 2-vector.
+typedef int32_t cplx_bits __attribute__((ext_vector_type(2)));
+struct FmDiscProc {
+    using In = cplx_bits;
+    using Out = int32_t;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 32;  // atan2 reciprocal table
+    static constexpr int IN_DIV = 1;
+    static constexpr int COST = 130;
+    struct Params {
+        int32_t carrier;
+        bq::SecI32 sec;
+    };
+    const uint32_t *tab;
+    uint32_t has_prev;
+    int32_t pre, pim;
+    uint32_t s[4];
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n)
+    {
+        for (int i = tid; i < 32; i += n) sh[i] = d_atan2_table[i];
+    }
+    __device__ __forceinline__ void set_shared(const uint32_t *sh) { tab = sh; }
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
+    {
+        has_prev = st[lane];
+        pre = int32_t(st[lanes + lane]);
+        pim = int32_t(st[2 * lanes + lane]);
+#pragma unroll
+        for (int w = 0; w < 4; w++) s[w] = st[size_t(3 + w) * lanes + lane];
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+        st[lane] = has_prev;
+        st[lanes + lane] = uint32_t(pre);
+        st[2 * lanes + lane] = uint32_t(pim);
+#pragma unroll
+        for (int w = 0; w < 4; w++) st[size_t(3 + w) * lanes + lane] = s[w];
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x)
+    {
+        int32_t d = 0;
+        // `prev.replace(x)`: None -> 0 (fm_disc.rs:33-35)
+        const int32_t cim = int32_t(0u - uint32_t(pim));  // conj (src/complex.rs:55-57)
+        const int64_t re = int64_t(uint64_t(int64_t(x.x) * pre) - uint64_t(int64_t(x.y) * cim));
+        const int64_t im = int64_t(uint64_t(int64_t(x.x) * cim) + uint64_t(int64_t(x.y) * pre));
+        const int32_t a = atan2_dev(int32_t(im >> 32), int32_t(re >> 32), tab);
+        d = has_prev ? int32_t(uint32_t(a) - uint32_t(p.carrier)) : 0;
+        has_prev = 1u;
+        pre = x.x, pim = x.y;
+        return bq::Df1I32<false>::step(p.sec, s, d);
+    }
+};
+
 int lockin_cfg_check(const idsp_lockin_i32 *c)
 {
     if (!c) return fail(IDSP_EINVAL, "cfg is NULL");
@@ -523,6 +577,21 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
     if (lanes <= kSplitMaxLanes)
         return dispatch_nk<LockinSplitProc, int32_t>(cfg, state, x, y, 2 * lanes, frames, layout, as_stream(stream));
     return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, as_stream(stream));
+}
+
+int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                     int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (cfg->deemph.frac < 0 || cfg->deemph.frac > 31) return fail(IDSP_EINVAL, "deemph frac = %d not in 0..31", cfg->deemph.frac);
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+    FmDiscProc::Params p;
+    p.carrier = cfg->carrier;
+    for (int i = 0; i < 5; i++) p.sec.ba[i] = cfg->deemph.ba[i];
+    p.sec.frac = cfg->deemph.frac;
+    p.sec.u = 0, p.sec.mn = INT32_MIN, p.sec.mx = INT32_MAX;
+    return launch_stream<FmDiscProc>(p, state, reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, layout, as_stream(stream));
 }
 
 int idsp_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes,

@@ -43,7 +43,7 @@ __all__ = [
     "FrameMajor", "LaneMajor", "View", "ViewMut", "Biquad", "BiquadClamp", "Cascade",
     "DirectForm1", "DirectForm2Transposed", "DirectForm1Wide", "DirectForm1Dither", "DirectForm",
     "Split", "Lanes", "ByLane", "HbfDecCascade", "HbfIntCascade", "FirSym", "Cic", "Normal", "Wdf", "HBF_TAPS", "HBF_TAPS_98",
-    "Lowpass", "Lockin", "Accu", "Dds", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
+    "Lowpass", "Lockin", "Accu", "Dds", "FmDisc", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
 ]
 
 FrameMajor = _abi.FRAME_MAJOR  # dsp-process/src/view.rs:10
@@ -788,6 +788,35 @@ class Dds:
         call("dds_i32", C.c_void_p(self.state.data_ptr()), C.c_void_p(out.data_ptr()), self.n_lanes, frames, layout,
              _stream_ptr(out))
         return out
+
+
+class FmDisc(_LaneOp):
+    """The receiver core of examples/fm_disc.rs:25-50: `(Split::new(FmDiscriminator { carrier }, None) *
+    Split::new(deemph, DirectForm1::default())).minor()` with `deemph: Biquad<Q32<F>>`.  Input
+    `Complex<Q32<32>>` bits as [..., 2] i32, output i32 phase increments (2^32 = one turn per sample)."""
+
+    dtype_in = dtype_out = torch.int32
+    in_width = 2
+
+    def __init__(self, carrier: int, deemph: Biquad):
+        load()
+        if not deemph.is_fixed:
+            raise ValueError("deemph must be a Biquad<Q32<F>>")
+        self.cfg = _abi.FmDisc()
+        self.cfg.carrier = ((int(carrier) + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)
+        self.cfg.deemph.ba[:] = deemph.ba
+        self.cfg.deemph.frac = deemph.frac
+
+    def lanes(self, n: int, device="cuda") -> "FmDisc":
+        _LaneOp.__init__(self, n, _abi.FM_DISC_STATE_WORDS, device)
+        return self
+
+    def inplace(self, xy):
+        raise ValueError("Complex in, real out: no in-place form")
+
+    def _run(self, x, y, frames, layout):
+        call("fm_disc_i32", C.byref(self.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
+             C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
 
 
 def cossin(p: torch.Tensor) -> torch.Tensor:

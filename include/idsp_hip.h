@@ -610,6 +610,21 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
 int idsp_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
                      size_t lanes, size_t frames, int layout, void *stream);
 
+/* FM discriminator receiver core of examples/fm_disc.rs:25-50, `(disc * deemph).minor()`:
+ *   z = x * conj(prev.into_bits())   (`Complex<Q32<32>> * Complex<i32>`, src/complex.rs:117-134:
+ *        re = (x.re*p.re - x.im*(-p.im)) >> 32, im = (x.re*(-p.im) + x.im*p.re) >> 32, i64 wrapping)
+ *   d = z.arg() - carrier            (src/complex.rs:254-256 -> atan2, wrapping; 0 while prev is None)
+ *   y = deemph(d)                    (`Biquad<Q32<F>>` x `DirectForm1`, src/iir/biquad.rs:366-383)
+ * x holds `Complex<Q32<32>>` bits [re, im] per sample (8 bytes), y one i32 per sample.
+ * State words per lane: {has_prev, prev.re, prev.im, x0, x1, y0, y1}; zero = (None, DirectForm1::default()). */
+typedef struct idsp_fm_disc {
+    int32_t carrier;
+    idsp_biquad_i32 deemph;
+} idsp_fm_disc;
+#define IDSP_FM_DISC_STATE_WORDS 7
+int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int32_t *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

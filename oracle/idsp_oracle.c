@@ -1204,6 +1204,36 @@ int idsp_ref_atan2_i32(const int32_t *xy, int32_t *out, size_t n)
     return IDSP_OK;
 }
 
+/* FM discriminator + deemphasis: examples/fm_disc.rs:25-50.  State words {has_prev, prev.re, prev.im, x0, x1, y0, y1}. */
+int idsp_ref_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                         int layout)
+{
+    int rc = check_common(cfg, 1, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (cfg->deemph.frac < 0 || cfg->deemph.frac > 31) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        uint32_t has_prev = st[l], s[4];
+        int32_t pre = (int32_t)st[lanes + l], pim = (int32_t)st[2 * lanes + l];
+        for (int w = 0; w < 4; w++) s[w] = st[(size_t)(3 + w) * lanes + l];
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            int32_t xr = x[2 * i], xi = x[2 * i + 1], d = 0;
+            if (has_prev) { /* `prev.replace(x)` returned Some(p): fm_disc.rs:33-37 */
+                int32_t cim = (int32_t)(0u - (uint32_t)pim);                       /* conj, complex.rs:55-57 */
+                int64_t re = (int64_t)((uint64_t)((int64_t)xr * pre) - (uint64_t)((int64_t)xi * cim)); /* complex.rs:128-133 */
+                int64_t im = wadd64((int64_t)xr * cim, (int64_t)xi * pre);
+                d = (int32_t)((uint32_t)idsp_ref_atan2((int32_t)(im >> 32), (int32_t)(re >> 32)) - (uint32_t)cfg->carrier);
+            }
+            has_prev = 1; pre = xr; pim = xi;
+            y[i] = df1_i32(cfg->deemph.ba, cfg->deemph.frac, s, d);
+        }
+        st[l] = has_prev; st[lanes + l] = (uint32_t)pre; st[2 * lanes + l] = (uint32_t)pim;
+        for (int w = 0; w < 4; w++) st[(size_t)(3 + w) * lanes + l] = s[w];
+    }
+    return IDSP_OK;
+}
+
 /* src/accu.rs:34-41 (state += step; yield state) -> src/complex.rs:237-240. */
 int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout)
 {

@@ -131,6 +131,7 @@ int idsp_ref_cic_dec_i32(const idsp_cic *cfg, void *state, const int32_t *x, int
 int idsp_ref_cic_dec_i64(const idsp_cic *cfg, void *state, const int64_t *x, int64_t *y, size_t lanes, size_t frames, int layout);
 int idsp_ref_cic_int_i32(const idsp_cic *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
 int idsp_ref_cic_int_i64(const idsp_cic *cfg, void *state, const int64_t *x, int64_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout);
 int32_t idsp_ref_atan2(int32_t y, int32_t x);
 int idsp_ref_atan2_i32(const int32_t *xy, int32_t *out, size_t n);
 int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n);

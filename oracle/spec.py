@@ -737,6 +737,22 @@ def cic_modular_interpolator(order: int, r: int, m: int, xs, bits: int = 64):
 
 
 # ----------------------------------------------------------------------------
+# FM discriminator graph (examples/fm_disc.rs:25-50)
+# ----------------------------------------------------------------------------
+def fm_disc(carrier: int, ba, frac: int, prev, st: DirectForm1, x):
+    """One sample of `(disc * deemph).minor()`; `prev` is a 1-element list holding None or (re, im)."""
+    p = prev[0]
+    prev[0] = (x[0], x[1])
+    d = 0
+    if p is not None:
+        cim = i32(-p[1])
+        re = i64(x[0] * p[0] - x[1] * cim)
+        im = i64(x[0] * cim + x[1] * p[0])
+        d = i32(atan2(i32(im >> 32), i32(re >> 32)) - carrier)
+    return biquad_i32_df1(ba, frac, st, d)
+
+
+# ----------------------------------------------------------------------------
 # Accu, Lowpass, Lockin
 # ----------------------------------------------------------------------------
 class Accu:

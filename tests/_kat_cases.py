@@ -355,6 +355,54 @@ def case_cic_modular_composition(be):
         assert y.reshape(len(xi), r).tolist() == spec.cic_modular_interpolator(n, r, m, xi)
 
 
+def fm_disc_fixture():
+    """examples/fm_disc.rs:57-75 (`fm_signal`) and :99-108 (`lowpass_reference`) in f32 like the example."""
+    e = KAT["fm_disc"]
+    f32 = np.float32
+    phase, phases, msg = 0, [], []
+    tau = f32(2 * math.pi)
+    for i in range(e["n"]):
+        m = f32(np.sin(tau * f32(e["message_freq"]) * f32(i)))
+        inc = e["carrier"] + int(f32(e["deviation"]) * m)  # `carrier as i32 + (deviation as f32 * msg) as i32`
+        phase = (phase + inc + (1 << 31)) % (1 << 32) - (1 << 31)
+        phases.append(phase)
+        msg.append(m)
+    return e, np.array(phases, np.int32), np.array(msg, f32)
+
+
+def case_fm_disc_tracks_known_modulation(be):
+    """examples/fm_disc.rs:148-157: corr > 0.999, 0.95 < gain < 1.05, rms < 5e-4."""
+    from oracle import spec_coeff as S
+
+    e, phases, msg = fm_disc_fixture()
+    rc, xs = be.cossin(phases)  # `Complex::new(Q32::from_bits(re), Q32::from_bits(im))`
+    assert rc == 0
+    # `Filter::default().critical_frequency(cutoff).lowpass()` in f32 -> Biquad<Q32<30>> / Biquad<f32>
+    sos = S.filter_build(np.float32, S.LOWPASS, np.float32(math.tau) * np.float32(e["cutoff"]), 1.0, 1.0, S.SHAPE_Q,
+                         np.float32(1.0) / np.float32(math.sqrt(2.0)))
+    qba = S.normalize(np.float32, sos, S.Out("i32", e["frac"]))
+    fba = S.normalize(np.float32, sos, S.Out("f32"))
+    cfg = _abi.FmDisc()
+    cfg.carrier = e["carrier"]
+    cfg.deemph.ba[:] = qba
+    cfg.deemph.frac = e["frac"]
+    st = np.zeros((_abi.FM_DISC_STATE_WORDS, 1), np.uint32)
+    rc, y = be.cfgcall("fm_disc_i32", cfg, st, xs.reshape(-1), (e["n"],), np.int32, 1, e["n"], LM)
+    assert rc == 0 and y[0] == 0 and st[0, 0] == 1
+    scale = np.float32(math.tau) / np.float32(4294967296.0)
+    yf = y.astype(np.float32) * scale
+    # lowpass_reference: Biquad<f32> DF1 over deviation * scale * msg
+    from oracle import spec
+
+    d1 = spec.DirectForm1()
+    m = np.array([spec.biquad_f32_df1(fba, d1, np.float32(e["deviation"]) * scale * v) for v in msg], np.float32)
+    yy, mm = yf[e["skip"]:].astype(np.float64), m[e["skip"]:].astype(np.float64)
+    gain = float((yy * mm).sum() / (mm * mm).sum())
+    rms = float(np.sqrt(((yy - gain * mm) ** 2).sum()) / yy.size)
+    corr = float((yy * mm).sum() / (np.sqrt((yy * yy).sum()) * np.sqrt((mm * mm).sum())))
+    assert corr > e["corr_min"] and e["gain"][0] < gain < e["gain"][1] and rms < e["rms_max"], (corr, gain, rms)
+
+
 def case_accu(be):
     e = KAT["accu"]
     st = np.array([[e["state"]], [e["step"]]], dtype=np.int64).astype(np.uint32)

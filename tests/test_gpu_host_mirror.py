@@ -241,3 +241,18 @@ def test_normal_and_wdf_lanes():
     chain.block(xs, ys)
     ex, ey = (xs.double() ** 2).sum().item(), (ys.double() ** 2).sum().item()
     assert abs(ey / ex - 1.0) < 5e-3  # allpass
+
+
+def test_fm_disc_receiver_core():
+    """examples/fm_disc.rs: a constant-frequency carrier demodulates to (frequency - carrier) after the deemphasis settles."""
+    from idsp_amd import coefficients as co
+
+    carrier, offset, n = 0x19341234, 0x00200000, 600
+    ph = (torch.arange(1, n + 1, dtype=torch.int64) * (carrier + offset)) & 0xFFFFFFFF
+    ph = torch.where(ph >= (1 << 31), ph - (1 << 32), ph).to(torch.int32).cuda()
+    x = ia.cossin(ph)  # [n, 2] = Complex<Q32<32>> bits
+    deemph = co.Filter(f32=True).critical_frequency(0.02).build_biquad(co.Type.Lowpass, frac=30)
+    rx = ia.FmDisc(carrier, deemph).lanes(1)
+    y = torch.empty(n, dtype=torch.int32, device="cuda")
+    rx.process_view(ia.View(x, ia.LaneMajor, 1, width=2), ia.ViewMut(y, ia.LaneMajor, 1))
+    assert y[0].item() == 0 and abs(y[-1].item() / offset - 1.0) < 2e-3

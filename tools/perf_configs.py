@@ -242,6 +242,22 @@ def atan2(n, iters, tag):
     report(f"{tag}:atan2 {n}", n, "angle", 12 * n, med, mn)
 
 
+def fm_disc(lanes, frames, layout, iters, tag):
+    cfg = _abi.FmDisc()
+    q = _abi.BiquadI32()
+    call("biquad_i32_from_sos", (C.c_double * 6)(*lowpass_sos(0.02)), 30, C.byref(q))
+    cfg.carrier, cfg.deemph = 0x19341234, q
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (2 * lanes * frames,), dtype=torch.int64, device=dev).to(torch.int32)
+    y = torch.empty(lanes * frames, dtype=torch.int32, device=dev)
+    st = torch.zeros((7, lanes), dtype=torch.int32, device=dev)
+
+    def run():
+        call("fm_disc_i32", C.byref(cfg), p(st), p(x), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:fm_disc {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample", 12 * lanes * frames, med, mn)
+
+
 def copy_ref(nbytes, iters):
     a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
     b = torch.empty_like(a)
@@ -320,6 +336,8 @@ def main():
         dds(65536, 4096, FM, it, "dds")
         cossin(1 << 27, it, "cossin")
         atan2(1 << 27, it, "atan2")
+        fm_disc(65536, 4096, FM, it, "fm")
+        fm_disc(65536, 4096, LM, it, "fm")
 
 
 if __name__ == "__main__":
