@@ -1,0 +1,55 @@
+"""The LDS-DMA FrameMajor kernel is normally chosen only for cheap processors on launches of 256+ waves.
+Force it (IDSP_LDS_COST / IDSP_LDS_MIN_WAVES, read once per process -> subprocess) for the heavy and the
+two-word-output processors too and check them against the oracle: lock-in (Complex out, LUT in LDS),
+8-section cascade, dither, Normal, a 4-section chain."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SNIPPET = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %r)
+from idsp_amd import _abi
+from tests import _harness as H
+from tests import _nw_cases as W
+from tests._backends import GpuBackend, OracleBackend
+ob, gb = OracleBackend(), GpuBackend()
+rng = np.random.default_rng(5)
+FM = H.FM
+lanes, frames = 512, 203   # whole 256-lane blocks, ragged last tile
+def both(op, cfg, n, words, x):
+    so = rng.integers(0, 1 << 32, size=(words, lanes), dtype=np.uint64).astype(np.uint32); sg = so.copy()
+    rco, yo = ob.stream(op, cfg, n, so, x, lanes, frames, FM)
+    rcg, yg = gb.stream(op, cfg, n, sg, x, lanes, frames, FM)
+    assert rco == 0 and rcg == 0, (op, H.engine().err())
+    assert np.array_equal(yo.view(np.uint32), yg.view(np.uint32)) and np.array_equal(so, sg), op
+xi = rng.integers(-(1 << 31), (1 << 31) - 1, size=lanes * frames, dtype=np.int64).astype(np.int32)
+rows = [(rng.integers(-(1 << 29), 1 << 29, size=5).tolist(), 29) for _ in range(8)]
+both("cascade_i32_df1", H.biquad_i32(rows), 8, 18, xi)
+both("biquad_i32_dither", H.biquad_i32(rows[:1]), 1, 5, xi)
+both("biquad_i32_wide", H.biquad_i32(rows[:4]), 4, 24, xi)
+both("normal_i32_df1", H.biquad_i32(rows[:2]), 2, 8, xi)
+xf = rng.standard_normal(lanes * frames).astype(np.float32)
+both("biquad_f32_df2t", H.biquad_f32([(rng.standard_normal(5) * 0.3).tolist() for _ in range(3)]), 3, 6, xf)
+lc = H.lockin_cfg([[1 << 20, -(1 << 27)]] * 2)
+st = rng.integers(0, 1 << 32, size=(18, 65536), dtype=np.uint64).astype(np.uint32)  # > split threshold: unsplit LockinProc
+L, F = 65536, 40
+x = rng.integers(-(1 << 28), 1 << 28, size=L * F, dtype=np.int32)
+so, sg = st.copy(), st.copy()
+rco, yo = ob.cfgcall("lockin_i32_process", lc, so, x, (L * F * 2,), np.int32, L, F, FM)
+rcg, yg = gb.cfgcall("lockin_i32_process", lc, sg, x, (L * F * 2,), np.int32, L, F, FM)
+assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), "lockin"
+print("forced LDS path ok")
+"""
+
+
+def test_heavy_processors_on_the_lds_dma_kernel(gpu):
+    env = dict(os.environ, IDSP_LDS_COST="100000", IDSP_LDS_MIN_WAVES="0")
+    r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced LDS path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
