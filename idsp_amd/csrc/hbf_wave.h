@@ -269,6 +269,105 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
     });
 }
 
+// FRAME_MAJOR decimator, kBlkLanes lanes per workgroup (one wave each).  The wave-per-lane kernel reads 64-byte
+// pieces and writes single floats y[f*lanes + lane]; the 32 lanes of an output line are different
+// workgroups, and L2 (refilled every ~10 us by the input stream) evicts the line between their writes
+// (PMC: WRITE_SIZE 3.4x the output bytes).  Here the waves of a workgroup load whole contiguous runs
+// (kBlkLanes * R * 4 bytes per frame) cooperatively into each other's stage-0 streams and stage a chunk's
+// outputs in an LDS tile [frame][lane] that is written as kBlkLanes * 4-byte pieces: FETCH 1.00x, WRITE 1.06x
+// at 16 lanes.  Two workgroup barriers per chunk; with 16 lanes (one workgroup per CU in lockstep) the
+// barriers cost what the traffic saved (1.45 ms), 4 lanes per workgroup (4 independent workgroups per CU)
+// measured best: 1.23-1.29 ms vs 1.37-1.46 ms for the wave-per-lane kernel at C3.
+constexpr int kBlkLanes = 4;
+
+template <class C>
+__global__ __launch_bounds__(kBlkLanes *kW) void hbf_dec_block_fm(uint32_t *st, const float *x, float *y, const size_t lanes,
+                                                                   const size_t frames)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = C::stages, R = C::rate;
+    constexpr int CHF = kCH / R;  // output frames per chunk
+    const int lid = threadIdx.x % kW, wave = threadIdx.x / kW;
+    float *lds = smem + wave * up4(C::lds_words);
+    float *otile = smem + kBlkLanes * up4(C::lds_words);  // [2][CHF][kBlkLanes]
+    const size_t ngroups = lanes / kBlkLanes, per = (ngroups + 7) / 8;
+    const size_t group = (blockIdx.x % 8) * per + blockIdx.x / 8;  // XCD-aware, see xcd_lane()
+    if (group >= ngroups) return;
+    const size_t lane = group * kBlkLanes + wave;
+
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1, so = C::state_off(s_);
+        if (lid < He) lds[C::offA(s_) + pad4(He) + lid] = __uint_as_float(st[size_t(so + lid) * lanes + lane]);
+        if (lid < Ho) lds[C::offB(s_) + pad4(Ho) + lid] = __uint_as_float(st[size_t(so + He + lid) * lanes + lane]);
+    });
+
+    // Cooperative input: a frame of the workgroup's 16 lanes is 16 * R * 4 contiguous bytes; thread t of the
+    // workgroup moves 16-byte vector v = t % VPF of frame t / VPF (+ FPI per instruction), so every wave
+    // instruction reads whole contiguous runs, and drops it into the owning lane's stage-0 streams.
+    constexpr int M0 = C::M(0), PPF = R / 4;          // 16-byte pieces per lane and frame
+    constexpr int VPF = kBlkLanes * PPF;              // vectors per frame of the workgroup
+    constexpr int NT = kBlkLanes * kW;                // threads
+    static_assert(NT % VPF == 0 && (CHF * VPF) % NT == 0, "chunk is a whole number of workgroup loads");
+    constexpr int FPI = NT / VPF;                     // frames per load instruction
+    constexpr int kPre = CHF * VPF / NT;              // loads per thread and chunk
+    const int tv = threadIdx.x % VPF, tf = threadIdx.x / VPF;
+    const int olane = tv / PPF, opiece = tv % PPF;    // owner lane (wave) and piece inside its frame
+    float *olds = smem + olane * up4(C::lds_words);
+    float *E0o = olds + C::offA(0) + up4(M0 - 1), *O0o = olds + C::offB(0) + up4(2 * M0 - 1);
+    const v4f *xg = reinterpret_cast<const v4f *>(x + group * kBlkLanes * size_t(R)) + tv;
+    const size_t fpitch = lanes * size_t(R) / 4;      // vectors per frame row
+    // two chunks in flight (register ring, statically indexed: the chunk loop is unrolled by two)
+    v4f pre[2][kPre];
+    auto fetch = [&](int slot, size_t f0) {
+        if (f0 >= frames) return;
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int fr = tf + i * FPI;
+            if (fr < nf) pre[slot][i] = xg[(f0 + size_t(fr)) * fpitch];
+        }
+    };
+    auto chunk = [&](int slot, size_t f0) {
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+        const int nin = nf * R;
+        // stage-0 input of the owner lane: pairs [even, odd] split into the two streams (piece q of its chunk)
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int fr = tf + i * FPI;
+            if (fr < nf) {
+                const int q = fr * PPF + opiece;
+                *reinterpret_cast<v2f *>(E0o + 2 * q) = v2f{pre[slot][i].x, pre[slot][i].z};
+                *reinterpret_cast<v2f *>(O0o + 2 * q) = v2f{pre[slot][i].y, pre[slot][i].w};
+            }
+        }
+        fetch(slot, f0 + 2 * size_t(CHF));
+        lds_barrier();  // every lane's chunk is in place
+        float *ot = otile + slot * CHF * kBlkLanes;
+        if (nf == CHF)
+            dec_chunk<C, true>(lds, nin, ot + wave, size_t(kBlkLanes), lid);
+        else
+            dec_chunk<C, false>(lds, nin, ot + wave, size_t(kBlkLanes), lid);
+        lds_barrier();  // outputs staged, and nobody still reads the stage-0 streams
+        // 16 threads write one frame's 64 bytes; the other tile is free until the next chunk's barrier
+        for (int t = threadIdx.x; t < nf * kBlkLanes; t += NT)
+            y[(f0 + size_t(t / kBlkLanes)) * lanes + group * kBlkLanes + (t % kBlkLanes)] = ot[t];
+    };
+    fetch(0, 0);
+    fetch(1, size_t(CHF));
+    for (size_t f0 = 0; f0 < frames; f0 += 2 * size_t(CHF)) {
+        chunk(0, f0);
+        if (f0 + CHF < frames) chunk(1, f0 + CHF);
+    }
+
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1, so = C::state_off(s_);
+        if (lid < He) st[size_t(so + lid) * lanes + lane] = __float_as_uint(lds[C::offA(s_) + pad4(He) + lid]);
+        if (lid < Ho) st[size_t(so + He + lid) * lanes + lane] = __float_as_uint(lds[C::offB(s_) + pad4(Ho) + lid]);
+    });
+}
+
 // ------------------------------------------------------------ interpolator
 // stage s of `HbfInt` (src/hbf.rs:207-227): pair i = [get(x)[i], x[M + i]]
 template <class C, int s, bool FULL, bool LM>
@@ -419,8 +518,24 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
             hipLaunchKernelGGL((hbf_int_wave<C, true>), grid, block, 0, stream, st, x, y, lanes, frames);
     } else {
         if constexpr (S >= 2) {
-            if constexpr (DEC)
+            if constexpr (DEC) {
+                constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + 2 * (kCH / C::rate) * kBlkLanes) * sizeof(float);
+                static const bool use_block = !getenv("IDSP_HBF_NO_BLOCK_FM");
+                if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
+                    static bool attr_done = false;
+                    if (!attr_done) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(hbf_dec_block_fm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                int(bytes)) != hipSuccess)
+                            return 1;
+                        attr_done = true;
+                    }
+                    const size_t ngroups = lanes / kBlkLanes;
+                    hipLaunchKernelGGL((hbf_dec_block_fm<C>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(kBlkLanes * kW), bytes, stream,
+                                       st, x, y, lanes, frames);
+                    return 0;
+                }
                 hipLaunchKernelGGL((hbf_dec_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
+            }
             else
                 hipLaunchKernelGGL((hbf_int_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
         } else {

@@ -294,7 +294,8 @@ HBF_CASES = [(_cascade, 0, s) for s in (1, 2, 3, 4, 5)] + [(_cascade, 1, s) for 
 
 def hbf_shapes(stages):
     ch = 4096 >> stages
-    return [(1, 1), (3, 5), (2, ch - 1), (2, ch), (3, ch + 1), (1, 2 * ch + 7), (17, 40)]
+    return [(1, 1), (3, 5), (2, ch - 1), (2, ch), (3, ch + 1), (1, 2 * ch + 7), (17, 40),
+            (4, 1), (4, ch + 3), (8, 130), (12, 2 * ch + 5), (64, 3 * (1024 >> stages) + 1)]  # whole 4-lane workgroups: FM block kernel
 
 
 @pytest.mark.parametrize("tap_set,stages", [(c[1], c[2]) for c in HBF_CASES])
