@@ -479,7 +479,9 @@ __global__ __launch_bounds__(kW) void hbf_int_wave(uint32_t *st, const float *x,
 #pragma unroll
         for (int i = 0; i < kPre; i++) {
             const int j = lid + i * kW;
-            if (j < nf) pre[i] = __builtin_nontemporal_load(LM ? x + lane * frames + f0 + size_t(j) : x + (f0 + size_t(j)) * lanes + lane);
+            // LANE_MAJOR: contiguous, streamed once -> nontemporal.  FRAME_MAJOR: a line holds one frame of 32 lanes,
+            // i.e. of 32 workgroups; it must stay cached for them (nontemporal re-fetched it for every lane)
+            if (j < nf) pre[i] = LM ? __builtin_nontemporal_load(x + lane * frames + f0 + size_t(j)) : x[(f0 + size_t(j)) * lanes + lane];
         }
     };
     fetch(0);
@@ -496,6 +498,78 @@ __global__ __launch_bounds__(kW) void hbf_int_wave(uint32_t *st, const float *x,
             int_chunk<C, true, LM>(lds, nf, y, lanes, frames, lane, f0, lid);
         else
             int_chunk<C, false, LM>(lds, nf, y, lanes, frames, lane, f0, lid);
+    }
+
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int H = 2 * C::M(s_) - 1;
+        if (lid < H) st[size_t(C::state_off(s_) + lid) * lanes + lane] = __float_as_uint(lds[C::offA(s_) + pad4(H) + lid]);
+    });
+}
+
+// FRAME_MAJOR interpolator, kBlkLanes lanes per workgroup: each wave interpolates its lane's chunk into an
+// LDS staging row (as if LANE_MAJOR), then the workgroup writes the chunk frame by frame as contiguous
+// kBlkLanes * R * 4-byte runs (whole lines) instead of 64-byte pieces at a lanes*R*4 pitch per wave.
+template <class C>
+__global__ __launch_bounds__(kBlkLanes *kW) void hbf_int_block_fm(uint32_t *st, const float *x, float *y, const size_t lanes,
+                                                                   const size_t frames)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = C::stages, R = C::rate;
+    constexpr int CHF = kCH / R;  // input frames per chunk
+    constexpr int NT = kBlkLanes * kW;
+    const int lid = threadIdx.x % kW, wave = threadIdx.x / kW;
+    float *lds = smem + wave * up4(C::lds_words);
+    float *stage = smem + kBlkLanes * up4(C::lds_words);  // [kBlkLanes][kCH]
+    const size_t ngroups = lanes / kBlkLanes, per = (ngroups + 7) / 8;
+    const size_t group = (blockIdx.x % 8) * per + blockIdx.x / 8;  // XCD-aware, see xcd_lane()
+    if (group >= ngroups) return;
+    const size_t lane = group * kBlkLanes + wave;
+
+    static_for<0, S>([&](auto s) {
+        constexpr int s_ = decltype(s)::value;
+        constexpr int H = 2 * C::M(s_) - 1;
+        if (lid < H) lds[C::offA(s_) + pad4(H) + lid] = __uint_as_float(st[size_t(C::state_off(s_) + lid) * lanes + lane]);
+    });
+
+    constexpr int kPre = (CHF + kW - 1) / kW;
+    float *X0n = lds + C::offA(0) + up4(2 * C::M(0) - 1);
+    float pre[kPre];
+    auto fetch = [&](size_t f0) {
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int j = lid + i * kW;
+            if (j < nf) pre[i] = x[(f0 + size_t(j)) * lanes + lane];
+        }
+    };
+    // write-out: vector v of the workgroup's frame = 16-byte piece v % (R/4) of lane v / (R/4)
+    constexpr int PPF = R / 4, VPF = kBlkLanes * PPF;
+    static_assert(NT % VPF == 0, "threads cover whole frames");
+    constexpr int FPI = NT / VPF;
+    const int tv = threadIdx.x % VPF, tf = threadIdx.x / VPF;
+    const float *src = stage + (tv / PPF) * kCH + (tv % PPF) * 4;
+    v4f *dst = reinterpret_cast<v4f *>(y + group * kBlkLanes * size_t(R)) + tv;
+    const size_t fpitch = lanes * size_t(R) / 4;
+
+    fetch(0);
+    for (size_t f0 = 0; f0 < frames; f0 += CHF) {
+        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
+#pragma unroll
+        for (int i = 0; i < kPre; i++) {
+            const int j = lid + i * kW;
+            if (j < nf) X0n[j] = pre[i];
+        }
+        if (f0 + CHF < frames) fetch(f0 + CHF);
+        lds_wave_sync();
+        // LANE_MAJOR addressing onto the staging row: y' + (0 * frames + 0) * R + o
+        if (nf == CHF)
+            int_chunk<C, true, true>(lds, nf, stage + wave * kCH, 1, 0, 0, 0, lid);
+        else
+            int_chunk<C, false, true>(lds, nf, stage + wave * kCH, 1, 0, 0, 0, lid);
+        lds_barrier();  // every lane's chunk is staged
+        for (int fr = tf; fr < nf; fr += FPI) dst[(f0 + size_t(fr)) * fpitch] = *reinterpret_cast<const v4f *>(src + fr * R);
+        lds_barrier();  // staging rows free again
     }
 
     static_for<0, S>([&](auto s) {
@@ -536,8 +610,24 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
                 }
                 hipLaunchKernelGGL((hbf_dec_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
             }
-            else
+            else {
+                constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + size_t(kBlkLanes) * kCH) * sizeof(float);
+                static const bool use_block = !getenv("IDSP_HBF_NO_BLOCK_FM");
+                if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
+                    static bool attr_done = false;
+                    if (!attr_done) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(hbf_int_block_fm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                int(bytes)) != hipSuccess)
+                            return 1;
+                        attr_done = true;
+                    }
+                    const size_t ngroups = lanes / kBlkLanes;
+                    hipLaunchKernelGGL((hbf_int_block_fm<C>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(kBlkLanes * kW), bytes, stream,
+                                       st, x, y, lanes, frames);
+                    return 0;
+                }
                 hipLaunchKernelGGL((hbf_int_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
+            }
         } else {
             return 1;  // not handled here
         }

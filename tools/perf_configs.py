@@ -311,6 +311,7 @@ def main():
         hbf("dec", 4, 16384, 4096, LM, it, "C3")
         hbf("dec", 4, 16384, 4096, FM, max(3, it // 3), "C3")
         hbf("int", 4, 16384, 4096, LM, it, "C3i")
+        hbf("int", 4, 16384, 4096, FM, max(3, it // 3), "C3i")
     if want("hbfvar"):
         for s in (1, 2, 3, 5):
             hbf("dec", s, 16384, 65536 >> s, LM, it, "hbf")
