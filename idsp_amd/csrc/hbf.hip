@@ -155,7 +155,9 @@ __global__ __launch_bounds__(kThreads) void hbf_dec_kernel(const HbfArgs a, uint
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const size_t lane = blockIdx.x;
+    // FRAME_MAJOR: neighbouring lanes share cache lines -> give each XCD (own L2) a contiguous eighth of the lanes
+    const size_t lane = lane_major ? size_t(blockIdx.x) : (blockIdx.x % 8) * ((lanes + 7) / 8) + blockIdx.x / 8;
+    if (lane >= lanes) return;
     const int S = a.stages;
     const int R = 1 << S;
 
@@ -356,7 +358,9 @@ __global__ __launch_bounds__(kThreads) void hbf_int_kernel(const HbfArgs a, uint
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const size_t lane = blockIdx.x;
+    // FRAME_MAJOR: neighbouring lanes share cache lines -> give each XCD (own L2) a contiguous eighth of the lanes
+    const size_t lane = lane_major ? size_t(blockIdx.x) : (blockIdx.x % 8) * ((lanes + 7) / 8) + blockIdx.x / 8;
+    if (lane >= lanes) return;
     const int S = a.stages;
     const int R = 1 << S;
 
@@ -456,7 +460,9 @@ __global__ __launch_bounds__(kThreads) void fir_sym_kernel(const FirArgs a, uint
 {
     __shared__ float buf[2 * IDSP_HBF_MAX_TAPS + kChunk + 8];
     const int tid = threadIdx.x;
-    const size_t lane = blockIdx.x;
+    // FRAME_MAJOR: neighbouring lanes share cache lines -> give each XCD (own L2) a contiguous eighth of the lanes
+    const size_t lane = lane_major ? size_t(blockIdx.x) : (blockIdx.x % 8) * ((lanes + 7) / 8) + blockIdx.x / 8;
+    if (lane >= lanes) return;
     const int M = a.m, len = 2 * M - 1 + a.odd, win = 2 * M + a.odd;
     for (int w = tid; w < len; w += kThreads) buf[w] = __uint_as_float(st[size_t(w) * lanes + lane]);
     for (size_t f0 = 0; f0 < frames; f0 += kChunk) {
@@ -572,7 +578,7 @@ int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state,
     const size_t bytes = size_t(lds_words) * sizeof(float);
     if (bytes > 64 * 1024)
         IDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
-    hipLaunchKernelGGL(kernel, dim3(unsigned(lanes)), dim3(kThreads), bytes, as_stream(stream), a,
+    hipLaunchKernelGGL(kernel, dim3(unsigned(layout == IDSP_LANE_MAJOR ? lanes : 8 * ((lanes + 7) / 8))), dim3(kThreads), bytes, as_stream(stream), a,
                        static_cast<uint32_t *>(state), x, y, lanes, frames, layout == IDSP_LANE_MAJOR ? 1 : 0);
     return launch_status();
 }
@@ -615,7 +621,7 @@ int idsp_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const flo
     a.odd = (cfg->kind == IDSP_FIR_ODD_SYMMETRIC || cfg->kind == IDSP_FIR_ODD_ANTISYMMETRIC) ? 1 : 0;
     a.sym = (cfg->kind == IDSP_FIR_ODD_SYMMETRIC || cfg->kind == IDSP_FIR_EVEN_SYMMETRIC) ? 1 : 0;
     for (int k = 0; k < IDSP_HBF_MAX_TAPS; k++) a.taps[k] = k < cfg->m ? cfg->taps[k] : 0.f;
-    hipLaunchKernelGGL(fir_sym_kernel, dim3(unsigned(lanes)), dim3(kThreads), 0, as_stream(stream), a,
+    hipLaunchKernelGGL(fir_sym_kernel, dim3(unsigned(layout == IDSP_LANE_MAJOR ? lanes : 8 * ((lanes + 7) / 8))), dim3(kThreads), 0, as_stream(stream), a,
                        static_cast<uint32_t *>(state), x, y, lanes, frames, layout == IDSP_LANE_MAJOR ? 1 : 0);
     return launch_status();
 }
