@@ -109,6 +109,26 @@ def test_c3_hbf_dec16_16384_lanes(eng):
     st.zero_()
     assert eng.cfgcall("hbf_dec_f32", cfg, st, x, y, lanes, frames, LM) == 0
     assert torch.allclose(y[:, 100:], torch.full_like(y[:, 100:], 16.0), atol=1e-4)
+    # interpolator x16 at full width: oracle on a lane subset, FRAME_MAJOR (4-lane workgroups) == LANE_MAJOR
+    icfg = _abi.HbfCascadeF32()
+    assert o.fn["hbf_int_cascade"](0, 4, C.byref(icfg)) == 0
+    fi = 1024
+    words = o.fn["hbf_int_state_words"](C.byref(icfg))
+    xi = torch.randn((lanes, fi), dtype=torch.float32, device=DEV, generator=g)
+    yi = torch.empty((lanes, fi * R), dtype=torch.float32, device=DEV)
+    sti = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)
+    assert eng.cfgcall("hbf_int_f32", icfg, sti, xi, yi, lanes, fi, LM) == 0
+    torch.cuda.synchronize()
+    xs = np.ascontiguousarray(xi.cpu().numpy()[idx])
+    ys = np.empty((idx.size, fi * R), np.float32)
+    ss = np.zeros((words, idx.size), np.uint32)
+    assert o.cfgcall("hbf_int_f32", icfg, ss, xs, ys, idx.size, fi, LM) == 0
+    assert H.ulp_diff_f32(yi.cpu().numpy()[idx], ys).max() == 0
+    assert np.array_equal(sti.cpu().numpy().view(np.uint32)[:, idx], ss)
+    yif = torch.empty((fi, lanes, R), dtype=torch.float32, device=DEV)
+    sti2 = torch.zeros_like(sti)
+    assert eng.cfgcall("hbf_int_f32", icfg, sti2, xi.t().contiguous(), yif, lanes, fi, FM) == 0
+    assert torch.equal(yif.permute(1, 0, 2).reshape(lanes, fi * R).view(torch.int32), yi.view(torch.int32)) and torch.equal(sti, sti2)
 
 
 def test_c4_lockin_32768_lanes(eng):
