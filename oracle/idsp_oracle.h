@@ -16,12 +16,17 @@
  *   pinned by reference known-answer tests (tests/golden/ref_kat.json):
  *     i32 DF1 biquad + float->Q quantisation, BiquadClamp, DF2T identity,
  *     DF1Dither doctest, HbfDec KAT + response lengths, cossin error bounds,
- *     Accu doctest, Lanes/LaneMajor view semantics.
+ *     Accu doctest, Lanes/LaneMajor view semantics; atan2 (exact zero-axis
+ *     values + error bounds over the reference's grid); Cic (the reference's
+ *     quickcheck properties and its "Cic == Integrator^N -> Downsample ->
+ *     Comb^N" tests); the fm_disc example's own test (corr / gain / rms).
  *   PARITY UNPINNED (no asserted value exists in the reference): Lowpass<1|2>,
  *     Lockin, DirectForm1Wide, clamp on Dither/Wide, HbfInt sample values,
- *     HBF_TAPS_98, exact cossin outputs at given phases.  For these the pin is
+ *     HBF_TAPS_98, exact cossin outputs at given phases, ByLane (pinned only
+ *     through "lane i == the pinned shared-coefficient entry run alone"),
+ *     Normal and Wdf (no test module in the reference).  For these the pin is
  *     the agreement of two independent restatements (this file and
- *     oracle/spec.py).
+ *     oracle/spec.py) plus properties that follow from the cited lines.
  * The reference itself is Rust and cannot be built in this image (no
  * rustc/cargo), so there is no oracle/_ref.
  */
