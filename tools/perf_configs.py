@@ -279,6 +279,15 @@ def main():
 
     if want("ref"):
         copy_ref(1 << 30, it)
+    if sel == {"lmstride"}:  # probe: does the LaneMajor row pitch (frames * 4 bytes) alias HBM channels?
+        for fr in (4096, 4160, 4224, 4352, 5120, 8192):
+            biquad("biquad_i32_df1", torch.int32, 4, 65536, fr, LM, 1, it, "lmstride")
+        for fr in (4096, 5120):
+            hbf("dec", 4, 16384, fr, LM, it, "lmstride")
+            hbf("int", 4, 16384, fr, LM, it, "lmstride")
+            cic("dec", torch.int32, 3, 15, 16384, fr, LM, it, "lmstride")
+            cic("int", torch.int32, 3, 15, 16384, fr // 4, LM, it, "lmstride")
+            lockin(2, 2, 32768, fr, LM, it, "lmstride")
     if want("c2"):
         for layout in (FM, LM):
             biquad("biquad_i32_df1", torch.int32, 4, 65536, 4096, layout, 1, it, "C2")
