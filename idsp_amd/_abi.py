@@ -174,6 +174,8 @@ PROCESSING = {
     "atan2_i32": [_P, _P, _SZ, _P],
     "dds_i32": [_P, _P, _SZ, _SZ, _I, _P],
     "lockin_i32_process": _CFG_SIG,
+    "lockin_i32_arg": _CFG_SIG,
+    "lockin_i32_norm_sqr": _CFG_SIG,
     "lowpass_i32": _CFG_SIG,
     "fm_disc_i32": _CFG_SIG,
 }

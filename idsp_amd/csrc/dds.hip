@@ -477,6 +477,155 @@ struct FmDiscProc {
     }
 };
 
+// Lock-in with the polar read-out fused on the same thread: `Lockin::process(..)` (src/lockin.rs:30-39)
+// followed by `Complex::<i32>::arg()` (src/complex.rs:254-256, MODE 0, i32) or `norm_sqr()`
+// (src/complex.rs:214-217, MODE 1, i64 with the wrapping sum of a release build).  Saves the 8 byte/sample
+// Complex<i32> round trip through HBM of `lockin` + `atan2`.
+template <int N, int K, int MODE>
+struct LockinPolarProc {
+    using In = int32_t;
+    using Out = std::conditional_t<MODE == 0, int32_t, int64_t>;
+    static constexpr bool HAS_IN = true;
+    static constexpr int kLut = 1 << kCossinDepth;
+    static constexpr int LDS_WORDS = kLut + (MODE == 0 ? 32 : 0);  // cossin table, atan2 reciprocal table
+    static constexpr int IN_DIV = 1;
+    static constexpr int COST = 110 + 80 * N * K + (MODE == 0 ? 80 : 10);
+    using Params = LpParams;
+    const uint32_t *lut;
+    uint32_t acc, inc;
+    LpBank<N, K> bi, bq;
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n)
+    {
+        fill_cossin(sh, tid, n);
+        if constexpr (MODE == 0)
+            for (int i = tid; i < 32; i += n) sh[kLut + i] = d_atan2_table[i];
+    }
+    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
+    {
+        acc = st[lane];
+        inc = st[lanes + lane];
+        bi.load(st, lanes, lane, 2);
+        bq.load(st, lanes, lane, 2 + 2 * N * K);
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+        st[lane] = acc;
+        bi.store(st, lanes, lane, 2);
+        bq.store(st, lanes, lane, 2 + 2 * N * K);
+    }
+    static constexpr int BATCH = 4;
+    using Pre = Cplx;
+    __device__ __forceinline__ Pre pre(const Params &)
+    {
+        acc += inc;
+        return cossin_dev(int32_t(acc), lut);
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo)
+    {
+        const int32_t re = bi.step(p, __mulhi(lo.re, x));
+        const int32_t im = bq.step(p, __mulhi(lo.im, x));
+        if constexpr (MODE == 0)
+            return atan2_dev(im, re, lut + kLut);
+        else
+            return int64_t(uint64_t(int64_t(re) * re) + uint64_t(int64_t(im) * im));
+    }
+};
+template <int N, int K>
+using LockinArgProc = LockinPolarProc<N, K, 0>;
+template <int N, int K>
+using LockinNormSqrProc = LockinPolarProc<N, K, 1>;
+
+// FrameMajor lock-in -> arg with the work of one lane spread over two waves.  A single thread per lane runs
+// ~100 VALU instructions per frame (cossin 16, two arms ~20 each, atan2 ~45) on one wave per SIMD at the C4
+// lane counts, which is slower than the two-pass form.  Here a workgroup is 64 lanes x 2 waves: wave 0 owns
+// the I arm, wave 1 the Q arm.  Per batch of kPairB frames each wave evaluates the LO of alternate frames and
+// publishes cos/sin through LDS, runs its own mixer + lowpass arm, publishes the arm outputs, and then takes
+// atan2 of alternate frames, so every store instruction still writes one contiguous 256-byte row.
+constexpr int kPairB = 8;
+
+template <int N, int K>
+__global__ __launch_bounds__(2 * kWave) void lockin_arg_pair_fm(const LpParams prm, uint32_t *st, const int32_t *x, int32_t *y,
+                                                                const size_t lanes, const size_t frames)
+{
+    constexpr int B = kPairB, kLut = 1 << kCossinDepth;
+    __shared__ uint32_t lut[kLut];
+    __shared__ uint32_t tab[32];
+    __shared__ Cplx lo[B][kWave];
+    __shared__ int32_t arm[2][B][kWave];
+    const int w = threadIdx.x / kWave, lid = threadIdx.x % kWave;
+    const size_t lane = size_t(blockIdx.x) * kWave + lid;
+    const bool active = lane < lanes;
+    const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
+    fill_cossin(lut, threadIdx.x, 2 * kWave);
+    if (threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
+    uint32_t acc = st[la];
+    const uint32_t inc = st[lanes + la];
+    LpBank<N, K> bank;
+    bank.load(st, lanes, la, 2 + (w ? 2 * N * K : 0));
+    // row base pointers are wave-uniform (SGPR pair) and the lane offset is one 32-bit register: no per-access
+    // 64-bit vector address arithmetic in the loop
+    const uint32_t lo32 = uint32_t(la), lane32 = uint32_t(lane);
+    const int32_t *const lo_mine = reinterpret_cast<const int32_t *>(&lo[0][lid]) + w;  // this arm's LO component
+    int32_t xn[B];
+    auto fetch = [&](size_t f0, auto full) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int32_t *row = x + (f0 + b) * lanes;
+            xn[b] = (decltype(full)::value || f0 + b < frames) ? row[lo32] : 0;
+        }
+    };
+    auto batch = [&](size_t f0, int nb, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        int32_t xv[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) xv[b] = xn[b];
+        if (f0 + 2 * B <= frames)
+            fetch(f0 + B, std::true_type{});
+        else if (f0 + B < frames)
+            fetch(f0 + B, std::false_type{});
+#pragma unroll
+        for (int j = 0; j < B / 2; j++) {
+            const int b = 2 * j + w;
+            lo[b][lid] = cossin_dev(int32_t(acc + inc * uint32_t(b + 1)), lut);
+        }
+        acc += inc * uint32_t(FULL ? B : nb);
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (FULL || b < nb) arm[w][b][lid] = bank.step(prm, __mulhi(lo_mine[b * kWave * 2], xv[b]));
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < B / 2; j++) {
+            const int b = 2 * j + w;
+            if ((FULL || b < nb) && active) {
+                int32_t *row = y + (f0 + b) * lanes;
+                row[lane32] = atan2_dev(arm[1][b][lid], arm[0][b][lid], tab);
+            }
+        }
+    };
+    if (frames >= size_t(B))
+        fetch(0, std::true_type{});
+    else
+        fetch(0, std::false_type{});
+    __syncthreads();
+    size_t f0 = 0;
+    for (; f0 + B <= frames; f0 += B) batch(f0, B, std::true_type{});
+    if (f0 < frames) batch(f0, int(frames - f0), std::false_type{});
+    if (active) {
+        if (w == 0) st[lane] = acc;
+        bank.store(st, lanes, lane, 2 + (w ? 2 * N * K : 0));
+    }
+}
+
+template <int N, int K>
+int launch_lockin_arg_pair(const LpParams &p, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, hipStream_t s)
+{
+    hipLaunchKernelGGL((lockin_arg_pair_fm<N, K>), dim3(unsigned((lanes + kWave - 1) / kWave)), dim3(2 * kWave), 0, s, p,
+                       static_cast<uint32_t *>(state), x, y, lanes, frames);
+    return launch_status();
+}
+
 int lockin_cfg_check(const idsp_lockin_i32 *c)
 {
     if (!c) return fail(IDSP_EINVAL, "cfg is NULL");
@@ -577,6 +726,41 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
     if (lanes <= kSplitMaxLanes)
         return dispatch_nk<LockinSplitProc, int32_t>(cfg, state, x, y, 2 * lanes, frames, layout, as_stream(stream));
     return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, as_stream(stream));
+}
+
+int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                        int layout, void *stream)
+{
+    int rc = lockin_cfg_check(cfg);
+    if (rc) return rc;
+    if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
+    if (lanes == 0) return IDSP_OK;
+    static const bool pair = !getenv("IDSP_LOCKIN_ARG_NO_PAIR");
+    if (layout == IDSP_FRAME_MAJOR && pair && frames) {
+        const LpParams p = lp_params(cfg);
+#define IDSP_CASE(N, K) \
+    if (cfg->order == N && cfg->cascade == K) return launch_lockin_arg_pair<N, K>(p, state, x, y, lanes, frames, as_stream(stream))
+        IDSP_CASE(1, 1);
+        IDSP_CASE(1, 2);
+        IDSP_CASE(1, 3);
+        IDSP_CASE(1, 4);
+        IDSP_CASE(2, 1);
+        IDSP_CASE(2, 2);
+        IDSP_CASE(2, 3);
+        IDSP_CASE(2, 4);
+#undef IDSP_CASE
+    }
+    return dispatch_nk<LockinArgProc, int32_t>(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
+}
+
+int idsp_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y, size_t lanes,
+                             size_t frames, int layout, void *stream)
+{
+    int rc = lockin_cfg_check(cfg);
+    if (rc) return rc;
+    if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
+    if (lanes == 0) return IDSP_OK;
+    return dispatch_nk<LockinNormSqrProc, int64_t>(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 
 int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,

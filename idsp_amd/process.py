@@ -751,12 +751,18 @@ class LowpassLanes(_LaneOp):
 class Lockin(_LaneOp):
     """`Lockin<[Lowpass<N>; K]>` fed by a per-lane `Accu` phase accumulator:
     per sample `Lockin::process(state, (x, Wrapping(accu.next())))`
-    (src/lockin.rs:30-39).  Output element `Complex<i32>` = [re, im]."""
+    (src/lockin.rs:30-39).  Output element `Complex<i32>` = [re, im] (`output="iq"`), or with the
+    polar read-out fused into the same pass: `output="arg"` -> `Complex::arg()` as i32
+    (src/complex.rs:254-256), `output="norm_sqr"` -> `Complex::norm_sqr()` as i64 (src/complex.rs:214-217)."""
 
-    out_width = 2
+    _OUTPUTS = {"iq": ("lockin_i32_process", 2, torch.int32), "arg": ("lockin_i32_arg", 1, torch.int32),
+                "norm_sqr": ("lockin_i32_norm_sqr", 1, torch.int64)}
 
-    def __init__(self, lowpasses: Sequence[Lowpass]):
+    def __init__(self, lowpasses: Sequence[Lowpass], output: str = "iq"):
+        if output not in self._OUTPUTS:
+            raise ValueError(f"output must be one of {sorted(self._OUTPUTS)}")
         self.cfg = _lockin_cfg(lowpasses)
+        self._entry, self.out_width, self.dtype_out = self._OUTPUTS[output]
 
     def lanes(self, n: int, step, state=0, device="cuda") -> "Lockin":
         words = call("lockin_state_words", C.byref(self.cfg))
@@ -766,7 +772,7 @@ class Lockin(_LaneOp):
         return self
 
     def _run(self, x, y, frames, layout):
-        call("lockin_i32_process", C.byref(self.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
+        call(self._entry, C.byref(self.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
              C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
 
 

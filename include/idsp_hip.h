@@ -604,6 +604,17 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
                             int32_t *y, size_t lanes, size_t frames, int layout,
                             void *stream);
 
+/* The lock-in above with the polar read-out of its `Complex<i32>` output fused in (SURVEY 8f rank 2:
+ * cossin -> mix -> lowpass -> atan2 in one pass, no Complex<i32> round trip through memory):
+ *   _arg:      y[index(f,l)] = `Lockin::process(..).arg()`       (src/complex.rs:254-256 -> src/atan2.rs:66-82), i32
+ *   _norm_sqr: y[index(f,l)] = `Lockin::process(..).norm_sqr()`  (src/complex.rs:214-217), i64; the sum wraps
+ *              for (i32::MIN, i32::MIN) as in a release build.
+ * Same cfg and state as idsp_lockin_i32_process; the three entries may be mixed on one state. */
+int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x,
+                             int64_t *y, size_t lanes, size_t frames, int layout, void *stream);
+
 /* `Lowpass<N>` cascade alone on a real stream (src/lowpass.rs:47-78; array
  * composition dsp-process/src/compose.rs:80-113).  State: `[LowpassState<N>; K]`
  * words ((c*N + j)*2 + {lo,hi}). */

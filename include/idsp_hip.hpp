@@ -893,6 +893,20 @@ public:
         require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
         check(idsp_lockin_i32_process(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
     }
+    /// Same pass with `Complex::arg()` fused in (src/complex.rs:254-256): y = one i32 phase per sample
+    template <class Layout>
+    void process_view_arg(View<int32_t, Layout> x, ViewMut<int32_t, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        check(idsp_lockin_i32_arg(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
+    /// Same pass with `Complex::norm_sqr()` fused in (src/complex.rs:214-217): y = one i64 per sample
+    template <class Layout>
+    void process_view_norm_sqr(View<int32_t, Layout> x, ViewMut<int64_t, Layout> y)
+    {
+        require(x.frames == y.frames && x.lanes == lanes_ && y.lanes == lanes_, "view shape mismatch");
+        check(idsp_lockin_i32_norm_sqr(&cfg_, state_.data(), x.flat, y.flat, lanes_, x.frames, Layout::value, stream_));
+    }
 
 private:
     idsp_lockin_i32 cfg_{};

@@ -1326,9 +1326,12 @@ int idsp_ref_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t 
 
 /* src/lockin.rs:30-39 then :17-27; `x * lo` = `i32 * Q32<32>` =
  * ((q as i64 * x as i64) >> 32) as i32 (dsp-fixedpoint/src/lib.rs:449-456,324-326). */
-int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
-                                size_t lanes, size_t frames, int layout)
+enum { LOCKIN_IQ = 0, LOCKIN_ARG = 1, LOCKIN_NORM_SQR = 2 };
+
+static int lockin_run(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *yv, size_t lanes, size_t frames,
+                      int layout, int mode)
 {
+    int32_t *y = (int32_t *)yv;
     if (!lockin_cfg_ok(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
     if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
     uint32_t *st = (uint32_t *)state;
@@ -1348,8 +1351,17 @@ int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const i
             idsp_ref_cossin((int32_t)acc, &c, &sn);
             int32_t xi = trunc32(mul_wide(c, x[i]) >> 32);
             int32_t xq = trunc32(mul_wide(sn, x[i]) >> 32);
-            y[2 * i] = lowpass_cascade(cfg, s[0], xi);
-            y[2 * i + 1] = lowpass_cascade(cfg, s[1], xq);
+            int32_t re = lowpass_cascade(cfg, s[0], xi);
+            int32_t im = lowpass_cascade(cfg, s[1], xq);
+            if (mode == LOCKIN_IQ) {
+                y[2 * i] = re;
+                y[2 * i + 1] = im;
+            } else if (mode == LOCKIN_ARG) {
+                y[i] = idsp_ref_atan2(im, re); /* Complex::arg, src/complex.rs:254-256 */
+            } else {
+                /* Complex::<i32>::norm_sqr, src/complex.rs:214-217; the sum wraps for (MIN, MIN) as in release */
+                ((int64_t *)yv)[i] = (int64_t)((uint64_t)mul_wide(re, re) + (uint64_t)mul_wide(im, im));
+            }
         }
         st[l] = acc;
         for (int q = 0; q < 2; q++)
@@ -1360,4 +1372,24 @@ int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const i
             }
     }
     return IDSP_OK;
+}
+
+int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                                size_t lanes, size_t frames, int layout)
+{
+    return lockin_run(cfg, state, x, y, lanes, frames, layout, LOCKIN_IQ);
+}
+
+/* `Lockin::process(..).arg()` (src/lockin.rs:30-39, src/complex.rs:254-256) */
+int idsp_ref_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                            size_t lanes, size_t frames, int layout)
+{
+    return lockin_run(cfg, state, x, y, lanes, frames, layout, LOCKIN_ARG);
+}
+
+/* `Lockin::process(..).norm_sqr()` (src/lockin.rs:30-39, src/complex.rs:214-217) */
+int idsp_ref_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y,
+                                 size_t lanes, size_t frames, int layout)
+{
+    return lockin_run(cfg, state, x, y, lanes, frames, layout, LOCKIN_NORM_SQR);
 }

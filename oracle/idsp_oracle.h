@@ -144,6 +144,10 @@ int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int
 size_t idsp_ref_lockin_state_words(const idsp_lockin_i32 *cfg);
 int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x,
                                 int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
+                            size_t lanes, size_t frames, int layout);
+int idsp_ref_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y,
+                                 size_t lanes, size_t frames, int layout);
 int idsp_ref_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
                          size_t lanes, size_t frames, int layout);
 

@@ -137,6 +137,27 @@ def test_lockin_recovers_dc_iq():
     iq = y[12288:].double().mean(dim=0).cpu().numpy() / amp
     assert np.allclose(iq[:, 0], 0.25 * math.cos(phi), atol=3e-3)
     assert np.allclose(iq[:, 1], 0.25 * math.sin(phi), atol=3e-3)
+    # polar read-out fused into the same pass: phase = phi (1 << 31 == pi), |IQ|^2 = (A/4)^2
+    for layout_lm in (False, True):
+        pa = ia.Lockin([lp, lp], output="arg").lanes(lanes, step=step)
+        pp = ia.Lockin([lp, lp], output="norm_sqr").lanes(lanes, step=step)
+        if layout_lm:
+            xl = xd.t().contiguous()
+            arg = torch.empty((lanes, n), dtype=torch.int32, device="cuda")
+            pw = torch.empty((lanes, n), dtype=torch.int64, device="cuda")
+            pa.process_view(ia.View(xl, ia.LaneMajor, lanes), ia.ViewMut(arg, ia.LaneMajor, lanes))
+            pp.process_view(ia.View(xl, ia.LaneMajor, lanes), ia.ViewMut(pw, ia.LaneMajor, lanes))
+            arg, pw = arg.t(), pw.t()
+        else:
+            arg = torch.empty((n, lanes), dtype=torch.int32, device="cuda")
+            pw = torch.empty((n, lanes), dtype=torch.int64, device="cuda")
+            pa.block(xd, arg)
+            pp.block(xd, pw)
+        assert torch.equal(pa.state, p.state) and torch.equal(pp.state, p.state)
+        z = y.to(torch.int64)
+        assert torch.equal(pw, z[..., 0] * z[..., 0] + z[..., 1] * z[..., 1])
+        ph = arg[12288:].double().mean(dim=0).cpu().numpy() * math.pi / (1 << 31)
+        assert np.allclose(ph, phi, atol=2e-2)
 
 
 def test_f64_biquad_and_fir_through_the_mirror():

@@ -443,6 +443,35 @@ def test_lowpass_and_lockin_parity(bes, order, cascade, layout):
             _, yo = ob.cfgcall("lockin_i32_process", cfg, so, x, (lanes * frames * 2,), np.int32, lanes, frames, layout)
             rc, yg = gb.cfgcall("lockin_i32_process", cfg, sg, x, (lanes * frames * 2,), np.int32, lanes, frames, layout)
             assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg)
+        # polar read-outs fused into the same pass; the three entries share one state
+        for name, dt in (("lockin_i32_arg", np.int32), ("lockin_i32_norm_sqr", np.int64), ("lockin_i32_arg", np.int32)):
+            _, yo = ob.cfgcall(name, cfg, so, x, (lanes * frames,), dt, lanes, frames, layout)
+            rc, yg = gb.cfgcall(name, cfg, sg, x, (lanes * frames,), dt, lanes, frames, layout)
+            assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), name
+
+
+def test_lockin_arg_equals_lockin_then_atan2(bes):
+    """The fused entry is the composition the reference writes as `lockin.process(..).arg()`:
+    HIP lock-in -> HIP atan2 (two passes) == HIP fused pass, at a size that takes the tiled paths."""
+    _, gb = bes
+    rng = np.random.default_rng(77)
+    lanes, frames = 320, 257
+    cfg = H.lockin_cfg([[1 << 22, -(1 << 27)]] * 2)
+    x = adversarial_i32(rng, lanes * frames)
+    st = np.zeros((2 + 16, lanes), np.uint32)
+    st[0] = rng.integers(0, 1 << 32, lanes, dtype=np.uint64).astype(np.uint32)
+    st[1] = rng.integers(0, 1 << 32, lanes, dtype=np.uint64).astype(np.uint32)
+    for layout in (FM, LM):
+        s1, s2, s3 = st.copy(), st.copy(), st.copy()
+        rc, iq = gb.cfgcall("lockin_i32_process", cfg, s1, x, (lanes * frames * 2,), np.int32, lanes, frames, layout)
+        assert rc == 0
+        rc, want = gb.atan2(iq.reshape(-1, 2))
+        assert rc == 0
+        rc, arg = gb.cfgcall("lockin_i32_arg", cfg, s2, x, (lanes * frames,), np.int32, lanes, frames, layout)
+        assert rc == 0 and np.array_equal(arg, np.asarray(want).ravel()) and np.array_equal(s1, s2)
+        rc, pw = gb.cfgcall("lockin_i32_norm_sqr", cfg, s3, x, (lanes * frames,), np.int64, lanes, frames, layout)
+        z = iq.reshape(-1, 2).astype(np.int64)
+        assert rc == 0 and np.array_equal(pw, z[:, 0] * z[:, 0] + z[:, 1] * z[:, 1]) and np.array_equal(s1, s3)
 
 
 def test_concurrent_streams_distinct_states(bes):

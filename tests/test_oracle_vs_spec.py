@@ -245,6 +245,23 @@ def test_lowpass_and_lockin(o, order, cascade):
     want = [spec.lockin(ks, siq, int(v), acc.next()) for v in x]
     assert y.reshape(-1, 2).tolist() == [list(w) for w in want]
     assert spec.i32(int(st[0, 0])) == acc.state
+    # polar read-outs fused into the lock-in == Complex::arg / norm_sqr of the Complex<i32> output
+    # (src/complex.rs:254-256 -> atan2.rs:66-82; complex.rs:214-217, wrapping sum)
+    for layout in (FM, LM):
+        lanes, fr = 3, 50
+        x3 = rand_i32(rng, lanes * fr)
+        st3 = rng.integers(0, 1 << 32, size=(2 + 4 * order * cascade, lanes), dtype=np.uint64).astype(np.uint32)
+        s_iq, s_arg, s_pow = st3.copy(), st3.copy(), st3.copy()
+        iq = np.empty(2 * lanes * fr, np.int32)
+        arg = np.empty(lanes * fr, np.int32)
+        pw = np.empty(lanes * fr, np.int64)
+        assert o.cfgcall("lockin_i32_process", cfg, s_iq, x3, iq, lanes, fr, layout) == 0
+        assert o.cfgcall("lockin_i32_arg", cfg, s_arg, x3, arg, lanes, fr, layout) == 0
+        assert o.cfgcall("lockin_i32_norm_sqr", cfg, s_pow, x3, pw, lanes, fr, layout) == 0
+        assert np.array_equal(s_iq, s_arg) and np.array_equal(s_iq, s_pow)
+        z = iq.reshape(-1, 2)
+        assert arg.tolist() == [spec.atan2(int(im), int(re)) for re, im in z]
+        assert pw.tolist() == [spec.wrap(int(re) * int(re) + int(im) * int(im), 64) for re, im in z]
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3])

@@ -118,7 +118,8 @@ def hbf(kind, stages, lanes, frames_low, layout, iters, tag):
            4 * n_hi + 4 * lanes * frames_low, med, mn)
 
 
-def lockin(order, cascade, lanes, frames, layout, iters, tag):
+def lockin(order, cascade, lanes, frames, layout, iters, tag, out="iq"):
+    """out: "iq" (Complex<i32>), "arg" / "norm_sqr" (polar read-out fused), "iq+atan2" (two passes, for comparison)"""
     cfg = _abi.LockinI32()
     cfg.order, cfg.cascade = order, cascade
     k = math.pi * (1 << 31) * 1e-3  # f0 = 1e-3 fn (src/lowpass.rs:31-38)
@@ -133,12 +134,20 @@ def lockin(order, cascade, lanes, frames, layout, iters, tag):
     st = torch.zeros((words, lanes), dtype=torch.int32, device=dev)
     st[1] = torch.randint(-(1 << 31), (1 << 31) - 1, (lanes,), dtype=torch.int64, device=dev).to(torch.int32)
 
+    a = torch.empty(lanes * frames, dtype=torch.int32, device=dev)
+    entry = {"iq": "lockin_i32_process", "iq+atan2": "lockin_i32_process", "arg": "lockin_i32_arg", "norm_sqr": "lockin_i32_norm_sqr"}[out]
+    # algorithmic bytes per sample: 4 in + 8 (Complex<i32> or i64) or 4 (arg) out; the two-pass form is
+    # priced at the fused form's bytes so that the GB/s figures compare the same job
+    nbytes = {"iq": 12, "norm_sqr": 12, "arg": 8, "iq+atan2": 8}[out]
+
     def run():
-        call("lockin_i32_process", C.byref(cfg), p(st), p(x), p(y), lanes, frames, layout, sptr())
+        call(entry, C.byref(cfg), p(st), p(x), p(y), lanes, frames, layout, sptr())
+        if out == "iq+atan2":
+            call("atan2_i32", p(y), p(a), lanes * frames, sptr())
 
     med, mn = timeit(run, iters)
-    report(f"{tag}:lockin Lowpass<{order}>x{cascade} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample",
-           12 * lanes * frames, med, mn)
+    report(f"{tag}:lockin{'' if out == 'iq' else '->' + out} Lowpass<{order}>x{cascade} {'LM' if layout else 'FM'} {lanes}x{frames}",
+           lanes * frames, "sample", nbytes * lanes * frames, med, mn)
 
 
 def dds(lanes, frames, layout, iters, tag):
@@ -342,6 +351,10 @@ def main():
             lockin(2, 2, 32768, 4096, layout, it, "C4")
         lockin(1, 1, 32768, 4096, FM, it, "C4v")
         lockin(2, 2, 65536, 4096, FM, it, "C4v")
+        for lanes in (32768, 65536):
+            for out in ("arg", "iq+atan2", "norm_sqr"):
+                lockin(2, 2, lanes, 4096, FM, it, "C4p", out)
+        lockin(2, 2, 32768, 4096, LM, it, "C4p", "arg")
         dds(32768, 4096, FM, it, "dds")
         dds(65536, 4096, FM, it, "dds")
         cossin(1 << 27, it, "cossin")
