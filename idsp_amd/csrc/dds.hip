@@ -536,93 +536,155 @@ using LockinArgProc = LockinPolarProc<N, K, 0>;
 template <int N, int K>
 using LockinNormSqrProc = LockinPolarProc<N, K, 1>;
 
-// FrameMajor lock-in -> arg with the work of one lane spread over two waves.  A single thread per lane runs
-// ~100 VALU instructions per frame (cossin 16, two arms ~20 each, atan2 ~45) on one wave per SIMD at the C4
-// lane counts, which is slower than the two-pass form.  Here a workgroup is 64 lanes x 2 waves: wave 0 owns
-// the I arm, wave 1 the Q arm.  Per batch of kPairB frames each wave evaluates the LO of alternate frames and
-// publishes cos/sin through LDS, runs its own mixer + lowpass arm, publishes the arm outputs, and then takes
-// atan2 of alternate frames, so every store instruction still writes one contiguous 256-byte row.
+// FrameMajor lock-in -> arg with the work of one lane spread over four or six waves.  A single thread per lane runs
+// ~150 VALU instructions per frame (cossin ~20, two arms ~30 each, atan2 ~70), many of them multi-pass 64-bit
+// operations, on one wave per SIMD at the C4 lane counts, where a SIMD issues an instruction every 6-10 cycles
+// instead of every 3-5.  Here a workgroup is 64 lanes x 4 (6) waves: wave 0 runs the I arm, wave 1 the Q arm,
+// the other 2 (4) the LO (cossin) and the atan2 of every 2nd (4th) frame; cos/sin and the arm outputs travel through
+// LDS and every store instruction still writes one contiguous 256-byte row.  The stages are software-pipelined
+// over batches of kPairB frames -- arms of batch n beside LO of batch n + 1 and atan2 of batch n - 1 in one
+// barrier interval, double-buffered in LDS.
 constexpr int kPairB = 8;
 
-template <int N, int K>
-__global__ __launch_bounds__(2 * kWave) void lockin_arg_pair_fm(const LpParams prm, uint32_t *st, const int32_t *x, int32_t *y,
-                                                                const size_t lanes, const size_t frames)
+// LM: LaneMajor rows (whole batches and 16-byte aligned rows only): an arm thread reads its lane's 8 samples of a
+// batch as two 16-byte vectors, a polar thread writes its 4 (2) consecutive phases as one 16 (8) byte vector.
+template <int N, int K, int kPairWaves, bool LM>  // kPairWaves = 2 arm waves + 2 or 4 polar waves
+__global__ __launch_bounds__(kPairWaves * kWave) void lockin_arg_pair_fm(const LpParams prm, uint32_t *st, const int32_t *x,
+                                                                         int32_t *y, const size_t lanes, const size_t frames)
 {
     constexpr int B = kPairB, kLut = 1 << kCossinDepth;
     __shared__ uint32_t lut[kLut];
     __shared__ uint32_t tab[32];
-    __shared__ Cplx lo[B][kWave];
-    __shared__ int32_t arm[2][B][kWave];
+    __shared__ Cplx lo[2][B][kWave];
+    __shared__ int32_t arm[2][2][B][kWave];  // [buffer][I/Q][frame][lane]
     const int w = threadIdx.x / kWave, lid = threadIdx.x % kWave;
+    const bool arm_wave = w < 2;  // wave-uniform role
+    constexpr int P = kPairWaves - 2, C = kPairB / P;  // polar waves, each takes frames b = r * C + j, j < C, of a batch
+    static_assert(kPairB % P == 0 && kPairB == 8, "batch splits evenly over the polar waves");
+    const int r = arm_wave ? w : w - 2;  // arm waves: I / Q; polar waves: frame group
     const size_t lane = size_t(blockIdx.x) * kWave + lid;
     const bool active = lane < lanes;
     const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
-    fill_cossin(lut, threadIdx.x, 2 * kWave);
+    fill_cossin(lut, threadIdx.x, kPairWaves * kWave);
     if (threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
-    uint32_t acc = st[la];
-    const uint32_t inc = st[lanes + la];
+    const uint32_t acc0 = st[la], inc = st[lanes + la];
     LpBank<N, K> bank;
-    bank.load(st, lanes, la, 2 + (w ? 2 * N * K : 0));
-    // row base pointers are wave-uniform (SGPR pair) and the lane offset is one 32-bit register: no per-access
-    // 64-bit vector address arithmetic in the loop
+    if (arm_wave) bank.load(st, lanes, la, 2 + (r ? 2 * N * K : 0));
+    // row base pointers are wave-uniform and the lane offset is one 32-bit register
     const uint32_t lo32 = uint32_t(la), lane32 = uint32_t(lane);
-    const int32_t *const lo_mine = reinterpret_cast<const int32_t *>(&lo[0][lid]) + w;  // this arm's LO component
+    uint32_t phase = acc0;  // accumulator before the batch whose LO is produced next
     int32_t xn[B];
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    typedef int32_t i32xc __attribute__((ext_vector_type(C)));
     auto fetch = [&](size_t f0, auto full) {
+        if constexpr (LM) {
+            const i32x4 *row = reinterpret_cast<const i32x4 *>(x + la * frames + f0);
+            const i32x4 a = row[0], c = row[1];
+            xn[0] = a.x, xn[1] = a.y, xn[2] = a.z, xn[3] = a.w, xn[4] = c.x, xn[5] = c.y, xn[6] = c.z, xn[7] = c.w;
+        } else {
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-            const int32_t *row = x + (f0 + b) * lanes;
-            xn[b] = (decltype(full)::value || f0 + b < frames) ? row[lo32] : 0;
-        }
-    };
-    auto batch = [&](size_t f0, int nb, auto full) {
-        constexpr bool FULL = decltype(full)::value;
-        int32_t xv[B];
-#pragma unroll
-        for (int b = 0; b < B; b++) xv[b] = xn[b];
-        if (f0 + 2 * B <= frames)
-            fetch(f0 + B, std::true_type{});
-        else if (f0 + B < frames)
-            fetch(f0 + B, std::false_type{});
-#pragma unroll
-        for (int j = 0; j < B / 2; j++) {
-            const int b = 2 * j + w;
-            lo[b][lid] = cossin_dev(int32_t(acc + inc * uint32_t(b + 1)), lut);
-        }
-        acc += inc * uint32_t(FULL ? B : nb);
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < B; b++)
-            if (FULL || b < nb) arm[w][b][lid] = bank.step(prm, __mulhi(lo_mine[b * kWave * 2], xv[b]));
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < B / 2; j++) {
-            const int b = 2 * j + w;
-            if ((FULL || b < nb) && active) {
-                int32_t *row = y + (f0 + b) * lanes;
-                row[lane32] = atan2_dev(arm[1][b][lid], arm[0][b][lid], tab);
+            for (int b = 0; b < B; b++) {
+                const int32_t *row = x + (f0 + b) * lanes;
+                xn[b] = (decltype(full)::value || f0 + b < frames) ? row[lo32] : 0;
             }
         }
     };
-    if (frames >= size_t(B))
-        fetch(0, std::true_type{});
-    else
-        fetch(0, std::false_type{});
+    auto lo_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            const int b = r * C + j;
+            lo[buf][b][lid] = cossin_dev(int32_t(phase + inc * uint32_t(b + 1)), lut);
+        }
+        phase += inc * uint32_t(B);
+    };
+    auto arg_stage = [&](size_t f0, int buf, int nb, auto full) {
+        if constexpr (LM) {
+            i32xc v;
+#pragma unroll
+            for (int j = 0; j < C; j++) v[j] = atan2_dev(arm[buf][1][r * C + j][lid], arm[buf][0][r * C + j][lid], tab);
+            if (active) *reinterpret_cast<i32xc *>(y + lane * frames + f0 + r * C) = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const int b = r * C + j;
+                if ((decltype(full)::value || b < nb) && active) {
+                    int32_t *row = y + (f0 + b) * lanes;
+                    row[lane32] = atan2_dev(arm[buf][1][b][lid], arm[buf][0][b][lid], tab);
+                }
+            }
+        }
+    };
+    auto iter = [&](size_t n, int nb, auto full, auto first) {
+        const size_t f0 = n * B;
+        const int buf = int(n & 1);
+        if (arm_wave) {
+            int32_t xv[B];
+#pragma unroll
+            for (int b = 0; b < B; b++) xv[b] = xn[b];
+            if (f0 + 2 * B <= frames)
+                fetch(f0 + B, std::true_type{});
+            else if (f0 + B < frames)
+                fetch(f0 + B, std::false_type{});
+            const int32_t *lo_mine = reinterpret_cast<const int32_t *>(&lo[buf][0][lid]) + r;  // this arm's LO component
+#pragma unroll
+            for (int b = 0; b < B; b++)
+                if (decltype(full)::value || b < nb) arm[buf][r][b][lid] = bank.step(prm, __mulhi(lo_mine[b * kWave * 2], xv[b]));
+        } else {
+            lo_stage(buf ^ 1);
+            if constexpr (!decltype(first)::value) arg_stage(f0 - B, buf ^ 1, B, std::true_type{});
+        }
+        __syncthreads();
+    };
+    if (arm_wave) {
+        if (frames >= size_t(B))
+            fetch(0, std::true_type{});
+        else
+            fetch(0, std::false_type{});
+    }
+    __syncthreads();  // tables
+    if (!arm_wave) lo_stage(0);
     __syncthreads();
-    size_t f0 = 0;
-    for (; f0 + B <= frames; f0 += B) batch(f0, B, std::true_type{});
-    if (f0 < frames) batch(f0, int(frames - f0), std::false_type{});
-    if (active) {
-        if (w == 0) st[lane] = acc;
-        bank.store(st, lanes, lane, 2 + (w ? 2 * N * K : 0));
+    const size_t nfull = frames / B;
+    const int tail = int(frames % B);
+    if (nfull) {
+        iter(0, B, std::true_type{}, std::true_type{});
+        for (size_t n = 1; n < nfull; n++) iter(n, B, std::true_type{}, std::false_type{});
+    }
+    if (tail) {
+        if (nfull)
+            iter(nfull, tail, std::false_type{}, std::false_type{});
+        else
+            iter(0, tail, std::false_type{}, std::true_type{});
+        if (!arm_wave) arg_stage(nfull * B, int(nfull & 1), tail, std::false_type{});
+    } else if (!arm_wave) {
+        arg_stage((nfull - 1) * B, int((nfull - 1) & 1), B, std::true_type{});
+    }
+    if (active && arm_wave) {
+        if (r == 0) st[lane] = acc0 + inc * uint32_t(frames);
+        bank.store(st, lanes, lane, 2 + (r ? 2 * N * K : 0));
     }
 }
 
 template <int N, int K>
-int launch_lockin_arg_pair(const LpParams &p, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, hipStream_t s)
+int launch_lockin_arg_pair(const LpParams &p, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout,
+                           hipStream_t s)
 {
-    hipLaunchKernelGGL((lockin_arg_pair_fm<N, K>), dim3(unsigned((lanes + kWave - 1) / kWave)), dim3(2 * kWave), 0, s, p,
-                       static_cast<uint32_t *>(state), x, y, lanes, frames);
+    const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
+    uint32_t *st = static_cast<uint32_t *>(state);
+    // measured at 4096 frames, FrameMajor: 6 waves per 64 lanes 0.64 ms at 32768 lanes (4 waves: 0.73), 4 waves 1.07 ms at
+    // 65536 (6: 1.12)
+    const bool six = lanes <= kSplitMaxLanes;
+    if (layout == IDSP_LANE_MAJOR) {
+        if (six)
+            hipLaunchKernelGGL((lockin_arg_pair_fm<N, K, 6, true>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
+        else
+            hipLaunchKernelGGL((lockin_arg_pair_fm<N, K, 4, true>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
+    } else {
+        if (six)
+            hipLaunchKernelGGL((lockin_arg_pair_fm<N, K, 6, false>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
+        else
+            hipLaunchKernelGGL((lockin_arg_pair_fm<N, K, 4, false>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
+    }
     return launch_status();
 }
 
@@ -736,10 +798,12 @@ int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *
     if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
     if (lanes == 0) return IDSP_OK;
     static const bool pair = !getenv("IDSP_LOCKIN_ARG_NO_PAIR");
-    if (layout == IDSP_FRAME_MAJOR && pair && frames) {
+    // LaneMajor takes the multi-wave kernel for whole batches on 16-byte aligned rows, the generic stream kernel otherwise
+    const bool lm_ok = frames % kPairB == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0;
+    if (pair && frames && (layout == IDSP_FRAME_MAJOR || lm_ok)) {
         const LpParams p = lp_params(cfg);
 #define IDSP_CASE(N, K) \
-    if (cfg->order == N && cfg->cascade == K) return launch_lockin_arg_pair<N, K>(p, state, x, y, lanes, frames, as_stream(stream))
+    if (cfg->order == N && cfg->cascade == K) return launch_lockin_arg_pair<N, K>(p, state, x, y, lanes, frames, layout, as_stream(stream))
         IDSP_CASE(1, 1);
         IDSP_CASE(1, 2);
         IDSP_CASE(1, 3);

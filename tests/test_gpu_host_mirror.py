@@ -156,6 +156,9 @@ def test_lockin_recovers_dc_iq():
         assert torch.equal(pa.state, p.state) and torch.equal(pp.state, p.state)
         z = y.to(torch.int64)
         assert torch.equal(pw, z[..., 0] * z[..., 0] + z[..., 1] * z[..., 1])
+        if layout_lm:
+            assert torch.equal(arg, arg_fm)  # LaneMajor multi-wave kernel == FrameMajor one
+        arg_fm = arg
         ph = arg[12288:].double().mean(dim=0).cpu().numpy() * math.pi / (1 << 31)
         assert np.allclose(ph, phi, atol=2e-2)
 

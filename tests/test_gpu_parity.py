@@ -448,6 +448,16 @@ def test_lowpass_and_lockin_parity(bes, order, cascade, layout):
             _, yo = ob.cfgcall(name, cfg, so, x, (lanes * frames,), dt, lanes, frames, layout)
             rc, yg = gb.cfgcall(name, cfg, sg, x, (lanes * frames,), dt, lanes, frames, layout)
             assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), name
+    # whole 8-frame batches: the multi-wave arg kernel in both layouts (LaneMajor takes it only for these), 1..3 batches
+    for lanes, frames in [(3, 8), (70, 16), (129, 24), (64, 64)]:
+        cfg = H.lockin_cfg(lowpass_ks(rng, order, cascade))
+        x = adversarial_i32(rng, lanes * frames)
+        st = rng.integers(0, 1 << 32, size=(2 + 4 * order * cascade, lanes), dtype=np.uint64).astype(np.uint32)
+        so, sg = st.copy(), st.copy()
+        for _ in range(2):
+            _, yo = ob.cfgcall("lockin_i32_arg", cfg, so, x, (lanes * frames,), np.int32, lanes, frames, layout)
+            rc, yg = gb.cfgcall("lockin_i32_arg", cfg, sg, x, (lanes * frames,), np.int32, lanes, frames, layout)
+            assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
 
 
 def test_lockin_arg_equals_lockin_then_atan2(bes):
@@ -455,7 +465,7 @@ def test_lockin_arg_equals_lockin_then_atan2(bes):
     HIP lock-in -> HIP atan2 (two passes) == HIP fused pass, at a size that takes the tiled paths."""
     _, gb = bes
     rng = np.random.default_rng(77)
-    lanes, frames = 320, 257
+    lanes, frames = 320, 256
     cfg = H.lockin_cfg([[1 << 22, -(1 << 27)]] * 2)
     x = adversarial_i32(rng, lanes * frames)
     st = np.zeros((2 + 16, lanes), np.uint32)
