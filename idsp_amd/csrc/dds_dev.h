@@ -1,0 +1,204 @@
+// dds_dev.h — device helpers shared by the cossin / DDS / lock-in translation units: the cossin and atan2
+// tables, `cossin()` (src/cossin.rs:14-67), `atan2()` (src/atan2.rs:6-82), `Lowpass<N>` (src/lowpass.rs:47-78) and
+// the `[Lowpass<N>; K]` bank.  Everything sits in an anonymous namespace: each translation unit gets its own copy of
+// the constant tables (no relocatable device code in this build).
+#pragma once
+#include "atan2_table.h"
+#include "cossin_table.h"
+#include "biquad_sections.h"
+#include "lane_stream.h"
+
+namespace idsp {
+namespace {
+
+__device__ const uint32_t d_cossin_table[1 << kCossinDepth] = {
+#define T8(i) kCossinTable[i], kCossinTable[i + 1], kCossinTable[i + 2], kCossinTable[i + 3], \
+              kCossinTable[i + 4], kCossinTable[i + 5], kCossinTable[i + 6], kCossinTable[i + 7]
+    T8(0),  T8(8),  T8(16), T8(24), T8(32), T8(40), T8(48),  T8(56),
+    T8(64), T8(72), T8(80), T8(88), T8(96), T8(104), T8(112), T8(120)
+#undef T8
+};
+
+// Largest lane count that still runs the I and Q arms on two threads (IDSP_SPLIT_MAX_LANES overrides).
+inline size_t split_max_lanes()
+{
+    static const size_t v = [] {
+        const char *e = getenv("IDSP_SPLIT_MAX_LANES");
+        return e ? size_t(strtoull(e, nullptr, 10)) : size_t(40960);
+    }();
+    return v;
+}
+#define kSplitMaxLanes split_max_lanes()
+
+struct Cplx {
+    int32_t re, im;
+};
+static_assert(sizeof(Cplx) == 8, "Complex<i32> is [re, im]");
+
+// src/cossin.rs:14-67
+__device__ __forceinline__ Cplx cossin_dev(int32_t phase_in, const uint32_t *lut)
+{
+    constexpr int kAlign = 32 - 16 - 1;  // ALIGN_MSB
+    uint32_t octant = uint32_t(phase_in);
+    uint32_t ph = uint32_t(phase_in);
+    if (octant & (1u << 29)) ph = ~ph;  // phase = pi/4 - phase
+    ph = (ph << 3) >> (32 - kCossinDepth - kAlign);
+    const uint32_t lookup = lut[ph >> kAlign];
+    int32_t p = int32_t(ph & ((1u << kAlign) - 1u)) - (1 << (kAlign - 1));
+    constexpr int32_t kPi4 = 51471;  // (FRAC_PI_4 * 65536.0) as i32
+    const int32_t dphi = (p * kPi4) >> 16;
+    int32_t c = int32_t(lookup & 0xffffu) + (1 << 16);
+    int32_t s = int32_t(lookup >> 16);
+    const int32_t dcos = (s * dphi) >> kCossinDepth;
+    const int32_t dsin = (c * dphi) >> (kCossinDepth + 1);
+    c = int32_t(uint32_t(c) << (kAlign - 1)) - dcos;
+    s = int32_t(uint32_t(s) << kAlign) + dsin;
+    octant ^= octant >> 1;
+    if (octant & (1u << 29)) {
+        const int32_t t = c;
+        c = s;
+        s = t;
+    }
+    if (octant & (1u << 30)) c = int32_t(0u - uint32_t(c));
+    if (octant & (1u << 31)) s = int32_t(0u - uint32_t(s));
+    return Cplx{c, s};
+}
+
+__device__ __forceinline__ void fill_cossin(uint32_t *sh, int tid, int nthreads)
+{
+    for (int i = tid; i < (1 << kCossinDepth); i += nthreads) sh[i] = d_cossin_table[i];
+}
+
+// src/lowpass.rs:47-78; all i64 arithmetic wraps (the library is built with
+// -fwrapv, so plain signed arithmetic has Rust release semantics and the two
+// products map onto v_mad_i64_i32).
+template <int N>
+__device__ __forceinline__ int32_t lowpass_step(const int32_t (&k)[2], int64_t (&s)[N], int32_t x)
+{
+    int64_t d = int64_t(__builtin_elementwise_sub_sat(x, int32_t(s[0] >> 32))) * int64_t(k[0]);
+    int32_t y;
+    if constexpr (N == 1) {
+        s[0] += d;
+        y = int32_t(s[0] >> 32);
+        s[0] += d;
+    } else {
+        d += int64_t(int32_t(s[1] >> 32)) * int64_t(k[1]);
+        s[1] += d;
+        s[0] += s[1];
+        y = int32_t(s[0] >> 32);
+        s[0] += s[1];
+        s[1] += d;
+    }
+    return y;
+}
+
+struct LpParams {
+    int32_t k[IDSP_LOCKIN_MAX_CASCADE][2];
+};
+
+template <int N, int K>
+struct LpBank {
+    int64_t s[K][N];
+    __device__ __forceinline__ void load(const uint32_t *st, size_t lanes, size_t lane, int word0)
+    {
+#pragma unroll
+        for (int c = 0; c < K; c++)
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const size_t w = size_t(word0 + (c * N + j) * 2);
+                s[c][j] = int64_t(uint64_t(st[w * lanes + lane]) | (uint64_t(st[(w + 1) * lanes + lane]) << 32));
+            }
+    }
+    __device__ __forceinline__ void store(uint32_t *st, size_t lanes, size_t lane, int word0) const
+    {
+#pragma unroll
+        for (int c = 0; c < K; c++)
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const size_t w = size_t(word0 + (c * N + j) * 2);
+                st[w * lanes + lane] = uint32_t(uint64_t(s[c][j]));
+                st[(w + 1) * lanes + lane] = uint32_t(uint64_t(s[c][j]) >> 32);
+            }
+    }
+    // `[Lowpass<N>; K]` array composition (dsp-process/src/compose.rs:84-93)
+    __device__ __forceinline__ int32_t step(const LpParams &p, int32_t x)
+    {
+#pragma unroll
+        for (int c = 0; c < K; c++) x = lowpass_step<N>(p.k[c], s[c], x);
+        return x;
+    }
+};
+
+// value of the other thread of an adjacent-thread pair (v_mov_b32 quad_perm:[1,0,3,2])
+__device__ __forceinline__ int32_t pair_swap(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
+
+// src/atan2.rs:6-82, all integer.  tab[0..16) = reciprocal bases, tab[16..32) = slopes.
+__device__ __forceinline__ uint32_t mul_q31(uint32_t x, uint32_t y) { return uint32_t((uint64_t(x) * uint64_t(y)) >> 31); }
+
+__device__ __forceinline__ int32_t atan2_dev(int32_t y, int32_t x, const uint32_t *tab)
+{
+    uint32_t k = 0;
+    if (y < 0) {
+        y = y == INT32_MIN ? INT32_MAX : -y;  // saturating_neg
+        k ^= 0xffffffffu;
+    }
+    if (x < 0) {
+        x = x == INT32_MIN ? INT32_MAX : -x;
+        k ^= 0x7fffffffu;
+    }
+    if (y > x) {
+        const int32_t t = y;
+        y = x;
+        x = t;
+        k ^= 0x3fffffffu;
+    }
+    // divi(y, x), y <= x: normalise x to [1, 2) in Q1.31, LUT reciprocal seed + one Newton step
+    uint32_t q = 0;
+    if (x != 0) {
+        const int shift = __builtin_clz(uint32_t(x));
+        const uint32_t yn = uint32_t(y) << shift, xn = uint32_t(x) << shift;
+        constexpr int kFrac = 31 - kAtan2DiviDepth;
+        const uint32_t rem = xn & ((1u << kFrac) - 1u);
+        const uint32_t idx = (xn << 1) >> (1 + kFrac);
+        const uint32_t step = uint32_t((int64_t(int32_t(tab[16 + idx])) * int64_t(rem)) >> kFrac);
+        const uint32_t r0 = tab[idx] + step;
+        q = mul_q31(yn, mul_q31(r0, 0u - mul_q31(xn, r0)));
+    }
+    // atani(q): odd polynomial q * P(q^2 / 4), Horner in Q32<32> from the highest coefficient
+    const int32_t x2 = int32_t((int64_t(q) * int64_t(q)) >> 32);
+    int32_t r = 0;
+    constexpr int32_t kAtani[6] = {0x0517c2cd, -0x06c6496b, 0x0fbdb021, -0x25b32e0a, 0x43b34c81, -0x3bc823dd};
+#pragma unroll
+    for (int i = 5; i >= 0; i--) r = int32_t(uint32_t(int32_t((int64_t(r) * int64_t(x2)) >> 32)) + uint32_t(kAtani[i]));
+    const uint32_t a = uint32_t((int64_t(r) * int64_t(q)) >> 28);
+    return int32_t(a ^ k);
+}
+
+__device__ const uint32_t d_atan2_table[32] = {
+    kAtan2Base[0], kAtan2Base[1], kAtan2Base[2], kAtan2Base[3], kAtan2Base[4], kAtan2Base[5], kAtan2Base[6], kAtan2Base[7],
+    kAtan2Base[8], kAtan2Base[9], kAtan2Base[10], kAtan2Base[11], kAtan2Base[12], kAtan2Base[13], kAtan2Base[14], kAtan2Base[15],
+    uint32_t(kAtan2Slope[0]), uint32_t(kAtan2Slope[1]), uint32_t(kAtan2Slope[2]), uint32_t(kAtan2Slope[3]),
+    uint32_t(kAtan2Slope[4]), uint32_t(kAtan2Slope[5]), uint32_t(kAtan2Slope[6]), uint32_t(kAtan2Slope[7]),
+    uint32_t(kAtan2Slope[8]), uint32_t(kAtan2Slope[9]), uint32_t(kAtan2Slope[10]), uint32_t(kAtan2Slope[11]),
+    uint32_t(kAtan2Slope[12]), uint32_t(kAtan2Slope[13]), uint32_t(kAtan2Slope[14]), uint32_t(kAtan2Slope[15])};
+
+inline int lockin_cfg_check(const idsp_lockin_i32 *c)
+{
+    if (!c) return fail(IDSP_EINVAL, "cfg is NULL");
+    if (c->order != 1 && c->order != 2) return fail(IDSP_EINVAL, "Lowpass order %d not in {1,2} (src/lowpass.rs:75)", c->order);
+    if (c->cascade < 1 || c->cascade > IDSP_LOCKIN_MAX_CASCADE) return fail(IDSP_EINVAL, "cascade %d not in 1..4", c->cascade);
+    return IDSP_OK;
+}
+
+inline LpParams lp_params(const idsp_lockin_i32 *c)
+{
+    LpParams p;
+    for (int i = 0; i < IDSP_LOCKIN_MAX_CASCADE; i++) {
+        p.k[i][0] = c->k[i][0];
+        p.k[i][1] = c->k[i][1];
+    }
+    return p;
+}
+
+}  // namespace
+}  // namespace idsp

@@ -1,0 +1,242 @@
+// lockin_waves.h — the lock-in (src/lockin.rs:30-39) with the work of one lane spread over several waves.
+//
+// One thread per lane runs, per frame, cossin (~20 VALU instructions), two `[Lowpass<N>; K]` arms (~30 each for
+// N = K = 2: a mixer `v_mul_hi`, four `v_mad_i64_i32`, eight 64-bit adds) and, for the phase read-out, atan2 (~70),
+// many of them multi-pass 64-bit operations.  At the C4 lane counts that is one wave per SIMD or fewer, where a SIMD
+// issues an instruction only every 6-10 cycles instead of every 3-5, and the kernel is VALU-bound far below the HBM
+// roofline.  Here a workgroup is 64 lanes x W waves with wave-uniform roles: wave 0 runs the I arm, wave 1 the Q arm,
+// the other W - 2 "read-out" waves evaluate the LO (cossin) for a share of each 8-frame batch and turn the arm outputs
+// of the previous batch into the output element: `Complex<i32>` [re, im] (MODE_IQ), `Complex::arg()` (MODE_ARG,
+// src/complex.rs:254-256) or `Complex::norm_sqr()` (MODE_NORM_SQR, src/complex.rs:214-217).  cos/sin and the arm
+// outputs travel through double-buffered LDS with one barrier per batch, so arms of batch n, LO of batch n + 1 and
+// read-out of batch n - 1 overlap.  Every FrameMajor store instruction writes one contiguous row segment of the 64
+// lanes (256 or 512 bytes); LaneMajor (whole batches on 16-byte aligned rows only) moves 16-byte vectors per thread.
+//
+// Input (IN): the arm waves are a serial recurrence with nothing to hide a global load behind, and a register
+// prefetch one batch ahead leaves most of the HBM latency exposed (measured: 0.58 ms with, 0.44 ms without the loads
+// at 32768 lanes x 4096 frames).  IN_FM_DMA (whole 64-lane workgroups, 16-byte aligned rows) therefore has each arm
+// wave issue one `global_load_lds_dwordx4` per batch -- 4 rows x 256 bytes straight into an LDS ring, three batches
+// ahead, no VGPRs -- and waits with `vmcnt(2)` at the end of an interval for the one issued two intervals earlier.
+// IN_FM_REG / IN_LM_REG fetch the next batch into registers (any shape the kernel takes; the same DMA on LaneMajor
+// rows, 32 lanes x 32 bytes per instruction, re-fetches every 128-byte line four times and was slower: 0.79 vs 0.64 ms).
+#pragma once
+#include "dds_dev.h"
+
+namespace idsp {
+namespace {
+
+constexpr int kLwB = 8;  // frames per batch
+enum { MODE_IQ = 0, MODE_ARG = 1, MODE_NORM_SQR = 2 };
+enum { IN_FM_REG = 0, IN_FM_DMA = 1, IN_LM_REG = 2 };
+constexpr int kLwRing = 4, kLwAhead = 3;  // LDS input ring slots, batches in flight
+
+template <int MODE>
+struct LwOut {
+    using type = int32_t;
+};
+template <>
+struct LwOut<MODE_IQ> {
+    using type = Cplx;
+};
+template <>
+struct LwOut<MODE_NORM_SQR> {
+    using type = int64_t;
+};
+
+template <int N, int K, int W, int IN, int MODE>
+__global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams prm, uint32_t *st, const int32_t *x,
+                                                                 typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames)
+{
+    using Out = typename LwOut<MODE>::type;
+    constexpr bool LM = IN == IN_LM_REG, DMA = IN == IN_FM_DMA;
+    constexpr int B = kLwB, kLut = 1 << kCossinDepth;
+    constexpr int P = W - 2, C = B / P;  // read-out waves; each takes frames b = r * C + j, j < C, of a batch
+    static_assert(B % P == 0 && B == 8, "batch splits evenly over the read-out waves");
+    __shared__ uint32_t lut[kLut];
+    __shared__ uint32_t tab[32];
+    __shared__ Cplx lo[2][B][kWave];
+    __shared__ int32_t arm[2][2][B][kWave];  // [buffer][I/Q][frame][lane]
+    __shared__ __attribute__((aligned(16))) int32_t xs[DMA ? kLwRing : 1][B * kWave];  // [frame][lane]
+    const int w = threadIdx.x / kWave, lid = threadIdx.x % kWave;
+    const bool arm_wave = w < 2;         // wave-uniform role
+    const int r = arm_wave ? w : w - 2;  // arm waves: I / Q; read-out waves: frame group
+    const size_t lane = size_t(blockIdx.x) * kWave + lid;
+    const bool active = lane < lanes;
+    const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
+    fill_cossin(lut, threadIdx.x, W * kWave);
+    if (MODE == MODE_ARG && threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
+    const uint32_t acc0 = st[la], inc = st[lanes + la];
+    LpBank<N, K> bank;
+    if (arm_wave) bank.load(st, lanes, la, 2 + (r ? 2 * N * K : 0));
+    // FrameMajor row base pointers are wave-uniform and the lane offset is one 32-bit register
+    const uint32_t lo32 = uint32_t(la), lane32 = uint32_t(lane);
+    uint32_t phase = acc0;  // accumulator before the batch whose LO is produced next
+    int32_t xn[B];
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    auto fetch = [&](size_t f0, auto full) {
+        if constexpr (LM) {
+            const i32x4 *row = reinterpret_cast<const i32x4 *>(x + la * frames + f0);
+            const i32x4 a = row[0], c = row[1];
+            xn[0] = a.x, xn[1] = a.y, xn[2] = a.z, xn[3] = a.w, xn[4] = c.x, xn[5] = c.y, xn[6] = c.z, xn[7] = c.w;
+        } else {
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                const int32_t *row = x + (f0 + b) * lanes;
+                xn[b] = (decltype(full)::value || f0 + b < frames) ? row[lo32] : 0;
+            }
+        }
+    };
+    // arm wave r moves rows 4r .. 4r + 3 of batch n: lane l takes the 16 bytes at column (l % 16) * 4 of row 4r + l / 16;
+    // rows past the end re-read the last frame (never consumed) so that every interval issues exactly one operation
+    auto dma = [&](size_t n) {
+        size_t row = n * B + size_t(4 * r + lid / 16);
+        row = row < frames ? row : frames - 1;
+        glds16(x + row * lanes + size_t(blockIdx.x) * kWave + size_t(lid % 16) * 4,
+               uint32_t(reinterpret_cast<uintptr_t>(&xs[n % kLwRing][4 * r * kWave])));
+    };
+    auto lo_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            const int b = r * C + j;
+            lo[buf][b][lid] = cossin_dev(int32_t(phase + inc * uint32_t(b + 1)), lut);
+        }
+        phase += inc * uint32_t(B);
+    };
+    auto element = [&](int buf, int b) -> Out {
+        const int32_t re = arm[buf][0][b][lid], im = arm[buf][1][b][lid];
+        if constexpr (MODE == MODE_IQ)
+            return Cplx{re, im};
+        else if constexpr (MODE == MODE_ARG)
+            return atan2_dev(im, re, tab);
+        else
+            return int64_t(uint64_t(int64_t(re) * re) + uint64_t(int64_t(im) * im));  // wraps for (MIN, MIN) as in release
+    };
+    auto out_stage = [&](size_t f0, int buf, int nb, auto full) {
+        if constexpr (LM) {
+            struct alignas(sizeof(Out) * C > 16 ? 16 : sizeof(Out) * C) Group {
+                Out v[C];
+            };
+            Group g;
+#pragma unroll
+            for (int j = 0; j < C; j++) g.v[j] = element(buf, r * C + j);
+            if (active) *reinterpret_cast<Group *>(y + lane * frames + f0 + r * C) = g;
+        } else {
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const int b = r * C + j;
+                if ((decltype(full)::value || b < nb) && active) {
+                    Out *row = y + (f0 + b) * lanes;
+                    nt_store<true>(row + lane32, element(buf, b));  // 8-byte elements leave as one 2-word vector
+                }
+            }
+        }
+    };
+    auto iter = [&](size_t n, int nb, auto full, auto first) {
+        const size_t f0 = n * B;
+        const int buf = int(n & 1);
+        if (arm_wave) {
+            int32_t xv[B];
+            if constexpr (DMA) {
+                dma(n + kLwAhead);
+#pragma unroll
+                for (int b = 0; b < B; b++) xv[b] = xs[n % kLwRing][b * kWave + lid];
+            } else {
+#pragma unroll
+                for (int b = 0; b < B; b++) xv[b] = xn[b];
+                if (f0 + 2 * B <= frames)
+                    fetch(f0 + B, std::true_type{});
+                else if (f0 + B < frames)
+                    fetch(f0 + B, std::false_type{});
+            }
+            const int32_t *lo_mine = reinterpret_cast<const int32_t *>(&lo[buf][0][lid]) + r;  // this arm's LO component
+#pragma unroll
+            for (int b = 0; b < B; b++)
+                if (decltype(full)::value || b < nb) arm[buf][r][b][lid] = bank.step(prm, __mulhi(lo_mine[b * kWave * 2], xv[b]));
+            if constexpr (DMA) wait_vmcnt<kLwAhead - 1>();  // batch n + 1 has landed
+        } else {
+            lo_stage(buf ^ 1);
+            if constexpr (!decltype(first)::value) out_stage(f0 - B, buf ^ 1, B, std::true_type{});
+        }
+        __syncthreads();
+    };
+    if (arm_wave) {
+        if constexpr (DMA) {
+            for (int n = 0; n < kLwAhead; n++) dma(size_t(n));
+            wait_vmcnt<kLwAhead - 1>();  // batch 0 has landed
+        } else if (frames >= size_t(B)) {
+            fetch(0, std::true_type{});
+        } else {
+            fetch(0, std::false_type{});
+        }
+    }
+    __syncthreads();  // tables
+    if (!arm_wave) lo_stage(0);
+    __syncthreads();
+    const size_t nfull = frames / B;
+    const int tail = int(frames % B);
+    if (nfull) {
+        iter(0, B, std::true_type{}, std::true_type{});
+        for (size_t n = 1; n < nfull; n++) iter(n, B, std::true_type{}, std::false_type{});
+    }
+    if (tail) {
+        if (nfull)
+            iter(nfull, tail, std::false_type{}, std::false_type{});
+        else
+            iter(0, tail, std::false_type{}, std::true_type{});
+        if (!arm_wave) out_stage(nfull * B, int(nfull & 1), tail, std::false_type{});
+    } else if (!arm_wave) {
+        out_stage((nfull - 1) * B, int((nfull - 1) & 1), B, std::true_type{});
+    }
+    if (active && arm_wave) {
+        if (r == 0) st[lane] = acc0 + inc * uint32_t(frames);
+        bank.store(st, lanes, lane, 2 + (r ? 2 * N * K : 0));
+    }
+}
+
+template <int MODE, int N, int K, int IN>
+int launch_lockin_waves_in(const LpParams &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
+                           size_t frames, int waves, hipStream_t s)
+{
+    const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
+    if (waves == 6)
+        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 6, IN, MODE>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
+    else
+        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 4, IN, MODE>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
+    return launch_status();
+}
+
+template <int MODE, int N, int K>
+int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, void *yv, size_t lanes, size_t frames, int layout,
+                           int waves, hipStream_t s)
+{
+    using Out = typename LwOut<MODE>::type;
+    uint32_t *st = static_cast<uint32_t *>(state);
+    Out *y = static_cast<Out *>(yv);
+    static const bool no_dma = getenv("IDSP_LOCKIN_NO_DMA") != nullptr;
+    if (layout == IDSP_LANE_MAJOR) return launch_lockin_waves_in<MODE, N, K, IN_LM_REG>(p, st, x, y, lanes, frames, waves, s);
+    if (!no_dma && lanes % kWave == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+        return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA>(p, st, x, y, lanes, frames, waves, s);
+    return launch_lockin_waves_in<MODE, N, K, IN_FM_REG>(p, st, x, y, lanes, frames, waves, s);
+}
+
+template <int MODE>
+int launch_lockin_waves(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames, int layout,
+                        int waves, hipStream_t s)
+{
+    const LpParams p = lp_params(cfg);
+#define IDSP_CASE(N, K) \
+    if (cfg->order == N && cfg->cascade == K) return launch_lockin_waves_nk<MODE, N, K>(p, state, x, y, lanes, frames, layout, waves, s)
+    IDSP_CASE(1, 1);
+    IDSP_CASE(1, 2);
+    IDSP_CASE(1, 3);
+    IDSP_CASE(1, 4);
+    IDSP_CASE(2, 1);
+    IDSP_CASE(2, 2);
+    IDSP_CASE(2, 3);
+    IDSP_CASE(2, 4);
+#undef IDSP_CASE
+    return fail(IDSP_EINVAL, "unsupported lowpass configuration");
+}
+
+}  // namespace
+}  // namespace idsp

@@ -1,0 +1,13 @@
+// lockin_waves_norm_sqr.hip — the MODE_NORM_SQR instantiations of lockin_waves.h (one translation unit per read-out so the
+// three sets of 32 kernels compile in parallel).
+#include "lockin_waves.h"
+
+namespace idsp {
+
+int lockin_waves_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames, int layout,
+                         int waves, hipStream_t s)
+{
+    return launch_lockin_waves<MODE_NORM_SQR>(cfg, state, x, y, lanes, frames, layout, waves, s);
+}
+
+}  // namespace idsp

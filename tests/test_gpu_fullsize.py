@@ -165,6 +165,21 @@ def test_c4_lockin_32768_lanes(eng):
     yl = torch.empty((lanes, frames, 2), dtype=torch.int32, device=DEV)
     assert eng.cfgcall("lockin_i32_process", cfg, st3, x.t().contiguous(), yl, lanes, frames, LM) == 0
     assert torch.equal(yl.permute(1, 0, 2), y) and torch.equal(st, st3)
+    # polar read-outs fused into the pass == Complex::arg / norm_sqr of the Complex<i32> output, both layouts
+    want_arg = torch.empty((frames, lanes), dtype=torch.int32, device=DEV)
+    assert eng.fn["atan2_i32"](C.c_void_p(y.data_ptr()), C.c_void_p(want_arg.data_ptr()), frames * lanes, None) == 0
+    z = y.to(torch.int64)
+    want_pow = z[..., 0] * z[..., 0] + z[..., 1] * z[..., 1]
+    del z
+    for layout in (FM, LM):
+        xin = x if layout == FM else x.t().contiguous()
+        shape = (frames, lanes) if layout == FM else (lanes, frames)
+        for name, dt, want in (("lockin_i32_arg", torch.int32, want_arg), ("lockin_i32_norm_sqr", torch.int64, want_pow)):
+            st4 = st0.clone()
+            out = torch.empty(shape, dtype=dt, device=DEV)
+            assert eng.cfgcall(name, cfg, st4, xin, out, lanes, frames, layout) == 0
+            got = out if layout == FM else out.t()
+            assert torch.equal(got, want) and torch.equal(st, st4), (name, layout)
 
 
 def test_c5_f32_df2t_one_million_lanes(eng):

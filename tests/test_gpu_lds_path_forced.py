@@ -45,11 +45,21 @@ so, sg = st.copy(), st.copy()
 rco, yo = ob.cfgcall("lockin_i32_process", lc, so, x, (L * F * 2,), np.int32, L, F, FM)
 rcg, yg = gb.cfgcall("lockin_i32_process", lc, sg, x, (L * F * 2,), np.int32, L, F, FM)
 assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), "lockin"
+# the one- / two-thread-per-lane stream kernels behind the multi-wave lock-in (IDSP_LOCKIN_NO_WAVES=1), all three outputs
+for L, F in ((512, 203), (100, 64)):
+    x = rng.integers(-(1 << 28), 1 << 28, size=L * F, dtype=np.int32)
+    st = rng.integers(0, 1 << 32, size=(18, L), dtype=np.uint64).astype(np.uint32)
+    for layout in (H.FM, H.LM):
+        for name, width, dt in (("lockin_i32_process", 2, np.int32), ("lockin_i32_arg", 1, np.int32), ("lockin_i32_norm_sqr", 1, np.int64)):
+            so, sg = st.copy(), st.copy()
+            rco, yo = ob.cfgcall(name, lc, so, x, (L * F * width,), dt, L, F, layout)
+            rcg, yg = gb.cfgcall(name, lc, sg, x, (L * F * width,), dt, L, F, layout)
+            assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (name, L, F, layout)
 print("forced LDS path ok")
 """
 
 
 def test_heavy_processors_on_the_lds_dma_kernel(gpu):
-    env = dict(os.environ, IDSP_LDS_COST="100000", IDSP_LDS_MIN_WAVES="0")
+    env = dict(os.environ, IDSP_LDS_COST="100000", IDSP_LDS_MIN_WAVES="0", IDSP_LOCKIN_NO_WAVES="1")
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "forced LDS path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -82,6 +82,83 @@ __global__ void k_pkfma(uint32_t *out, uint32_t seed)
     if (r == 0x12345678u) out[threadIdx.x] = uint32_t(r);
 }
 
+// ---- dependent-chain latency: CH independent chains per wave (1 = every instruction waits for the previous one)
+template <int CH>
+__global__ void k_lat_add64(uint32_t *out, uint32_t seed)
+{
+    uint64_t a[CH];
+    for (int c = 0; c < CH; c++) a[c] = seed + c;
+    uint64_t b = seed * 3 + 1;
+    for (int i = 0; i < kIters * kChains / CH; i++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a[c]) : "v"(b));
+    }
+    uint64_t r = 0;
+    for (int c = 0; c < CH; c++) r ^= a[c];
+    if (r == 0x12345678u) out[threadIdx.x] = uint32_t(r);
+}
+template <int CH>
+__global__ void k_lat_addc_pair(uint32_t *out, uint32_t seed)  // 64-bit add as v_add_co_u32 + v_addc_co_u32 (2 instructions)
+{
+    uint32_t lo[CH], hi[CH];
+    for (int c = 0; c < CH; c++) lo[c] = seed + c, hi[c] = seed;
+    uint32_t b = seed * 3 + 1, d = seed + 5;
+    for (int i = 0; i < kIters * kChains / CH; i++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+            asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(lo[c]), "+v"(hi[c]) : "v"(b), "v"(d) : "vcc");
+    }
+    uint32_t r = 0;
+    for (int c = 0; c < CH; c++) r ^= lo[c] ^ hi[c];
+    if (r == 0x12345678u) out[threadIdx.x] = r;
+}
+template <int CH>
+__global__ void k_lat_mad64(uint32_t *out, uint32_t seed)  // accumulate chain: C operand depends on the previous result
+{
+    uint64_t a[CH];
+    for (int c = 0; c < CH; c++) a[c] = seed + c;
+    uint32_t b = seed * 3 + 1, d = seed + 7;
+    for (int i = 0; i < kIters * kChains / CH; i++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(a[c]) : "v"(b), "v"(d) : "vcc");
+    }
+    uint64_t r = 0;
+    for (int c = 0; c < CH; c++) r ^= a[c];
+    if (r == 0x12345678u) out[threadIdx.x] = uint32_t(r);
+}
+template <int CH>
+__global__ void k_lat_mad64_mul(uint32_t *out, uint32_t seed)  // multiplicand chain: the high word of the result feeds the next multiply
+{
+    uint64_t a[CH];
+    for (int c = 0; c < CH; c++) a[c] = seed + c;
+    uint32_t d = seed + 7;
+    uint64_t z = seed;
+    for (int i = 0; i < kIters * kChains / CH; i++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t h = uint32_t(a[c] >> 32);
+            asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(a[c]) : "v"(h), "v"(d), "v"(z) : "vcc");
+        }
+    }
+    uint64_t r = 0;
+    for (int c = 0; c < CH; c++) r ^= a[c];
+    if (r == 0x12345678u) out[threadIdx.x] = uint32_t(r);
+}
+template <int CH>
+__global__ void k_lat_add32(uint32_t *out, uint32_t seed)
+{
+    uint32_t a[CH];
+    for (int c = 0; c < CH; c++) a[c] = seed + c;
+    uint32_t b = seed * 3 + 1;
+    for (int i = 0; i < kIters * kChains / CH; i++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
+    }
+    uint32_t r = 0;
+    for (int c = 0; c < CH; c++) r ^= a[c];
+    if (r == 0x12345678u) out[threadIdx.x] = r;
+}
+
 template <class K>
 int run(const char *name, K kern, uint32_t *out, int cus, double ghz)
 {
@@ -130,5 +207,20 @@ int main()
     run("v_mul_lo_u32", k_mullo, out, cus, ghz);
     run("v_mul_hi_i32", k_mulhi, out, cus, ghz);
     run("v_mad_i64_i32", k_mad64, out, cus, ghz);
+    std::printf("dependent chains per wave (same instruction totals; 1 chain = pure latency)\n");
+    run("add_u32 x1", k_lat_add32<1>, out, cus, ghz);
+    run("add_u32 x2", k_lat_add32<2>, out, cus, ghz);
+    run("lshl_add_u64 x1", k_lat_add64<1>, out, cus, ghz);
+    run("lshl_add_u64 x2", k_lat_add64<2>, out, cus, ghz);
+    run("lshl_add_u64 x4", k_lat_add64<4>, out, cus, ghz);
+    run("lshl_add_u64 x8", k_lat_add64<8>, out, cus, ghz);
+    run("add_co+addc x1", k_lat_addc_pair<1>, out, cus, ghz);
+    run("add_co+addc x2", k_lat_addc_pair<2>, out, cus, ghz);
+    run("add_co+addc x8", k_lat_addc_pair<8>, out, cus, ghz);
+    run("mad_i64 acc x1", k_lat_mad64<1>, out, cus, ghz);
+    run("mad_i64 acc x2", k_lat_mad64<2>, out, cus, ghz);
+    run("mad_i64 acc x4", k_lat_mad64<4>, out, cus, ghz);
+    run("mad_i64 mul x1", k_lat_mad64_mul<1>, out, cus, ghz);
+    run("mad_i64 mul x2", k_lat_mad64_mul<2>, out, cus, ghz);
     return 0;
 }
