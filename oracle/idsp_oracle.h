@@ -21,7 +21,9 @@
  *     quickcheck properties and its "Cic == Integrator^N -> Downsample ->
  *     Comb^N" tests); the fm_disc example's own test (corr / gain / rms).
  *   PARITY UNPINNED (no asserted value exists in the reference): Lowpass<1|2>,
- *     Lockin, DirectForm1Wide, clamp on Dither/Wide, HbfInt sample values,
+ *     Lockin (and its fused arg / norm_sqr read-outs = Lockin followed by the
+ *     KAT-pinned atan2 / a wrapping sum of squares), DirectForm1Wide, clamp on
+ *     Dither/Wide, HbfInt sample values,
  *     HBF_TAPS_98, exact cossin outputs at given phases, ByLane (pinned only
  *     through "lane i == the pinned shared-coefficient entry run alone"),
  *     Normal and Wdf (no test module in the reference).  For these the pin is
