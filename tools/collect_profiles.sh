@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd $R
-rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python bench.py --no-cpu --steps 30 --warmup 5 > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python bench.py --no-cpu > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python bench.py --no-cpu --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python bench.py --no-cpu --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/pmc_sq -o bench -- python bench.py --no-cpu --steps 5 --warmup 2 > $O/pmc_sq.log 2>&1
