@@ -18,7 +18,9 @@
 // wave issue one `global_load_lds_dwordx4` per batch -- 4 rows x 256 bytes straight into an LDS ring, three batches
 // ahead, no VGPRs -- and waits with `vmcnt(2)` at the end of an interval for the one issued two intervals earlier.
 // IN_FM_REG / IN_LM_REG fetch the next batch into registers (any shape the kernel takes; the same DMA on LaneMajor
-// rows, 32 lanes x 32 bytes per instruction, re-fetches every 128-byte line four times and was slower: 0.79 vs 0.64 ms).
+// rows, 32 lanes x 32 bytes per instruction, re-fetches every 128-byte line four times and was slower: 0.79 vs 0.64 ms;
+// so was staging the LaneMajor input through LDS by the read-out waves with cached loads: 0.65 vs 0.58 ms -- the
+// LaneMajor form is bound by its 32-byte-per-lane output pieces, not by the input).
 #pragma once
 #include "dds_dev.h"
 
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
         }
         phase += inc * uint32_t(B);
     };
-    auto element = [&](int buf, int b) -> Out {
-        const int32_t re = arm[buf][0][b][lid], im = arm[buf][1][b][lid];
+    auto element = [&](int buf, int b, int ln) -> Out {
+        const int32_t re = arm[buf][0][b][ln], im = arm[buf][1][b][ln];
         if constexpr (MODE == MODE_IQ)
             return Cplx{re, im};
         else if constexpr (MODE == MODE_ARG)
@@ -113,20 +115,24 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
     };
     auto out_stage = [&](size_t f0, int buf, int nb, auto full) {
         if constexpr (LM) {
+            // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the 8 frames of one lane, so that one store
+            // instruction leaves 8 * sizeof(Out) contiguous bytes per lane instead of two (four) pieces at different times
             struct alignas(sizeof(Out) * C > 16 ? 16 : sizeof(Out) * C) Group {
                 Out v[C];
             };
+            const int ll = r * (kWave / P) + lid / P, part = lid % P;
+            const size_t gl = size_t(blockIdx.x) * kWave + size_t(ll);
             Group g;
 #pragma unroll
-            for (int j = 0; j < C; j++) g.v[j] = element(buf, r * C + j);
-            if (active) *reinterpret_cast<Group *>(y + lane * frames + f0 + r * C) = g;
+            for (int j = 0; j < C; j++) g.v[j] = element(buf, part * C + j, ll);
+            if (gl < lanes) *reinterpret_cast<Group *>(y + gl * frames + f0 + part * C) = g;
         } else {
 #pragma unroll
             for (int j = 0; j < C; j++) {
                 const int b = r * C + j;
                 if ((decltype(full)::value || b < nb) && active) {
                     Out *row = y + (f0 + b) * lanes;
-                    nt_store<true>(row + lane32, element(buf, b));  // 8-byte elements leave as one 2-word vector
+                    nt_store<true>(row + lane32, element(buf, b, lid));  // 8-byte elements leave as one 2-word vector
                 }
             }
         }

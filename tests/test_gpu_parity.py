@@ -454,10 +454,11 @@ def test_lowpass_and_lockin_parity(bes, order, cascade, layout):
         x = adversarial_i32(rng, lanes * frames)
         st = rng.integers(0, 1 << 32, size=(2 + 4 * order * cascade, lanes), dtype=np.uint64).astype(np.uint32)
         so, sg = st.copy(), st.copy()
-        for _ in range(2):
-            _, yo = ob.cfgcall("lockin_i32_arg", cfg, so, x, (lanes * frames,), np.int32, lanes, frames, layout)
-            rc, yg = gb.cfgcall("lockin_i32_arg", cfg, sg, x, (lanes * frames,), np.int32, lanes, frames, layout)
-            assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
+        for name, width, dt in (("lockin_i32_arg", 1, np.int32), ("lockin_i32_process", 2, np.int32),
+                                ("lockin_i32_norm_sqr", 1, np.int64), ("lockin_i32_arg", 1, np.int32)):
+            _, yo = ob.cfgcall(name, cfg, so, x, (lanes * frames * width,), dt, lanes, frames, layout)
+            rc, yg = gb.cfgcall(name, cfg, sg, x, (lanes * frames * width,), dt, lanes, frames, layout)
+            assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (name, lanes, frames)
 
 
 def test_lockin_arg_equals_lockin_then_atan2(bes):
