@@ -67,6 +67,18 @@ def p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def out_like(x):
+    """Output buffer of x's shape placed as bench.py places it: in one allocation with x's copy, 48 KiB past x's size
+    (the offset y - x moves a streaming kernel by up to 15 %; two torch allocations land anywhere).
+    Returns (x_in_arena, y)."""
+    if os.environ.get("IDSP_PERF_TORCH_PLACEMENT"):
+        return x, torch.empty_like(x)
+    n, pad = x.numel(), (48 << 10) // x.element_size()
+    arena = torch.empty(2 * n + pad, dtype=x.dtype, device=x.device)
+    arena[:n].copy_(x)
+    return arena[:n], arena[n + pad:]
+
+
 def sptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -94,7 +106,7 @@ def biquad(op, dtype, words, lanes, frames, layout, n_sections, iters, tag):
         else:
             cfg = (_abi.BiquadF32 * n_sections)(*([q] * n_sections))
         x = torch.randn(lanes * frames, dtype=torch.float32, device=dev)
-    y = torch.empty_like(x)
+    x, y = out_like(x)
     st = torch.zeros((words * n_sections if "cascade" not in op else 2 + 2 * n_sections, lanes), dtype=torch.int32, device=dev)
 
     def run():
@@ -189,7 +201,7 @@ def biquad_bylane(op, dtype, words, cv, lanes, frames, layout, n_sections, iters
     if cv == 8:
         coef = torch.cat([coef, extra.view(1, 3, 1).expand(n_sections, 3, lanes)], 1)
     coef = coef.contiguous().to(dev)
-    y = torch.empty_like(x)
+    x, y = out_like(x)
     st = torch.zeros((words * n_sections, lanes), dtype=torch.int32, device=dev)
     pre = (p(coef), 30) if dtype == torch.int32 else (p(coef),)
 
@@ -227,7 +239,7 @@ def wdf(lanes, frames, layout, iters, tag):
     for d, (m, g) in zip(secs, [(0xAD, [-0.9, 0.9]), (0xAD, [-0.6, 0.7]), (0xAD, [-0.7, 0.6]), (0xA, [0.8])]):
         call("wdf_quantize", len(g), m, (C.c_double * len(g))(*g), C.byref(d))
     x = torch.randint(-(1 << 24), 1 << 24, (lanes * frames,), dtype=torch.int32, device=dev)
-    y = torch.empty_like(x)
+    x, y = out_like(x)
     st = torch.zeros((7, lanes), dtype=torch.int32, device=dev)
 
     def run():
