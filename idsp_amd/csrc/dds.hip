@@ -21,7 +21,7 @@ int lockin_waves_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t
 
 namespace {
 
-// The multi-wave kernels take FrameMajor always and LaneMajor for whole 8-frame batches on 16-byte aligned rows
+// The multi-wave kernels take FrameMajor always and LaneMajor for whole 16-frame batches on 16-byte aligned rows
 // (IDSP_LOCKIN_NO_WAVES=1 keeps everything on the one- / two-thread-per-lane stream kernels below).
 // Returns the wave count per 64 lanes, 0 = use the stream kernels.
 inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t frames, int layout, bool heavy_readout)
@@ -32,7 +32,7 @@ inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t f
         return e ? atoi(e) : 0;
     }();
     if (off || frames == 0) return 0;
-    if (layout == IDSP_LANE_MAJOR && !(frames % 8 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0))
+    if (layout == IDSP_LANE_MAJOR && !(frames % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0))
         return 0;
     if (forced == 4 || forced == 6) return forced;
     // measured at 4096 frames (arg read-out): 6 waves 0.64 ms at 32768 lanes (4 waves: 0.73), 4 waves 1.07 ms at 65536 (6: 1.12)

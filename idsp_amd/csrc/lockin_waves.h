@@ -27,7 +27,8 @@
 namespace idsp {
 namespace {
 
-constexpr int kLwB = 8;  // frames per batch
+constexpr int kLwB = 8;     // frames per batch, FrameMajor
+constexpr int kLwBLm = 16;  // LaneMajor: 16 frames = one whole 128-byte line of 8-byte output elements per lane and batch
 enum { MODE_IQ = 0, MODE_ARG = 1, MODE_NORM_SQR = 2 };
 enum { IN_FM_REG = 0, IN_FM_DMA = 1, IN_LM_REG = 2 };
 constexpr int kLwRing = 4, kLwAhead = 3;  // LDS input ring slots, batches in flight
@@ -45,15 +46,15 @@ struct LwOut<MODE_NORM_SQR> {
     using type = int64_t;
 };
 
-template <int N, int K, int W, int IN, int MODE>
+template <int N, int K, int W, int IN, int MODE, int B>
 __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams prm, uint32_t *st, const int32_t *x,
                                                                  typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames)
 {
     using Out = typename LwOut<MODE>::type;
     constexpr bool LM = IN == IN_LM_REG, DMA = IN == IN_FM_DMA;
-    constexpr int B = kLwB, kLut = 1 << kCossinDepth;
+    constexpr int kLut = 1 << kCossinDepth;
     constexpr int P = W - 2, C = B / P;  // read-out waves; each takes frames b = r * C + j, j < C, of a batch
-    static_assert(B % P == 0 && B == 8, "batch splits evenly over the read-out waves");
+    static_assert(B % P == 0 && B % 8 == 0, "batch splits evenly over the read-out waves and into 4-row DMA groups per arm wave");
     __shared__ uint32_t lut[kLut];
     __shared__ uint32_t tab[32];
     __shared__ Cplx lo[2][B][kWave];
@@ -78,8 +79,11 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
     auto fetch = [&](size_t f0, auto full) {
         if constexpr (LM) {
             const i32x4 *row = reinterpret_cast<const i32x4 *>(x + la * frames + f0);
-            const i32x4 a = row[0], c = row[1];
-            xn[0] = a.x, xn[1] = a.y, xn[2] = a.z, xn[3] = a.w, xn[4] = c.x, xn[5] = c.y, xn[6] = c.z, xn[7] = c.w;
+#pragma unroll
+            for (int v = 0; v < B / 4; v++) {
+                const i32x4 a = row[v];
+                xn[4 * v] = a.x, xn[4 * v + 1] = a.y, xn[4 * v + 2] = a.z, xn[4 * v + 3] = a.w;
+            }
         } else {
 #pragma unroll
             for (int b = 0; b < B; b++) {
@@ -88,13 +92,17 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
             }
         }
     };
-    // arm wave r moves rows 4r .. 4r + 3 of batch n: lane l takes the 16 bytes at column (l % 16) * 4 of row 4r + l / 16;
+    // arm wave r moves rows r B/2 .. of batch n, 4 rows per instruction: lane l takes the 16 bytes at column (l % 16) * 4 of row l / 16;
     // rows past the end re-read the last frame (never consumed) so that every interval issues exactly one operation
     auto dma = [&](size_t n) {
-        size_t row = n * B + size_t(4 * r + lid / 16);
-        row = row < frames ? row : frames - 1;
-        glds16(x + row * lanes + size_t(blockIdx.x) * kWave + size_t(lid % 16) * 4,
-               uint32_t(reinterpret_cast<uintptr_t>(&xs[n % kLwRing][4 * r * kWave])));
+#pragma unroll
+        for (int g = 0; g < B / 8; g++) {
+            const int r0 = r * (B / 2) + 4 * g;  // first of the 4 rows this instruction moves
+            size_t row = n * B + size_t(r0 + lid / 16);
+            row = row < frames ? row : frames - 1;
+            glds16(x + row * lanes + size_t(blockIdx.x) * kWave + size_t(lid % 16) * 4,
+                   uint32_t(reinterpret_cast<uintptr_t>(&xs[n % kLwRing][r0 * kWave])));
+        }
     };
     auto lo_stage = [&](int buf) {
 #pragma unroll
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
     };
     auto out_stage = [&](size_t f0, int buf, int nb, auto full) {
         if constexpr (LM) {
-            // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the 8 frames of one lane, so that one store
+            // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the 16 frames of one lane, so that one store
             // instruction leaves 8 * sizeof(Out) contiguous bytes per lane instead of two (four) pieces at different times
             struct alignas(sizeof(Out) * C > 16 ? 16 : sizeof(Out) * C) Group {
                 Out v[C];
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
 #pragma unroll
             for (int b = 0; b < B; b++)
                 if (decltype(full)::value || b < nb) arm[buf][r][b][lid] = bank.step(prm, __mulhi(lo_mine[b * kWave * 2], xv[b]));
-            if constexpr (DMA) wait_vmcnt<kLwAhead - 1>();  // batch n + 1 has landed
+            if constexpr (DMA) wait_vmcnt<(kLwAhead - 1) * (B / 8)>();  // batch n + 1 has landed
         } else {
             lo_stage(buf ^ 1);
             if constexpr (!decltype(first)::value) out_stage(f0 - B, buf ^ 1, B, std::true_type{});
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
     if (arm_wave) {
         if constexpr (DMA) {
             for (int n = 0; n < kLwAhead; n++) dma(size_t(n));
-            wait_vmcnt<kLwAhead - 1>();  // batch 0 has landed
+            wait_vmcnt<(kLwAhead - 1) * (B / 8)>();  // batch 0 has landed
         } else if (frames >= size_t(B)) {
             fetch(0, std::true_type{});
         } else {
@@ -199,15 +207,15 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
     }
 }
 
-template <int MODE, int N, int K, int IN>
+template <int MODE, int N, int K, int IN, int B>
 int launch_lockin_waves_in(const LpParams &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
                            size_t frames, int waves, hipStream_t s)
 {
     const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
     if (waves == 6)
-        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 6, IN, MODE>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
+        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
     else
-        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 4, IN, MODE>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
+        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
     return launch_status();
 }
 
@@ -219,10 +227,20 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
     uint32_t *st = static_cast<uint32_t *>(state);
     Out *y = static_cast<Out *>(yv);
     static const bool no_dma = getenv("IDSP_LOCKIN_NO_DMA") != nullptr;
-    if (layout == IDSP_LANE_MAJOR) return launch_lockin_waves_in<MODE, N, K, IN_LM_REG>(p, st, x, y, lanes, frames, waves, s);
-    if (!no_dma && lanes % kWave == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
-        return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA>(p, st, x, y, lanes, frames, waves, s);
-    return launch_lockin_waves_in<MODE, N, K, IN_FM_REG>(p, st, x, y, lanes, frames, waves, s);
+    // 16-frame batches halve the barriers per frame: 0.37 -> 0.35 ms (Complex<i32>), 0.61 -> 0.59 ms (arg) at 32768 lanes x 4096
+    // frames, but 1.06 -> 1.19 ms (arg) at 65536 lanes, where the longer intervals cost more than the barriers
+    // (IDSP_LOCKIN_B = 8 / 16 forces one)
+    static const int forced_b = [] {
+        const char *e = getenv("IDSP_LOCKIN_B");
+        return e ? atoi(e) : 0;
+    }();
+    const bool b16 = forced_b == 16 || (forced_b != 8 && lanes <= kSplitMaxLanes);
+    if (layout == IDSP_LANE_MAJOR) return launch_lockin_waves_in<MODE, N, K, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
+    if (!no_dma && lanes % kWave == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
+        if (b16) return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s);
+        return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s);
+    }
+    return launch_lockin_waves_in<MODE, N, K, IN_FM_REG, kLwB>(p, st, x, y, lanes, frames, waves, s);
 }
 
 template <int MODE>

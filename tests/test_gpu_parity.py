@@ -448,8 +448,9 @@ def test_lowpass_and_lockin_parity(bes, order, cascade, layout):
             _, yo = ob.cfgcall(name, cfg, so, x, (lanes * frames,), dt, lanes, frames, layout)
             rc, yg = gb.cfgcall(name, cfg, sg, x, (lanes * frames,), dt, lanes, frames, layout)
             assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), name
-    # whole 8-frame batches: the multi-wave arg kernel in both layouts (LaneMajor takes it only for these), 1..3 batches
-    for lanes, frames in [(3, 8), (70, 16), (129, 24), (64, 64)]:
+    # whole 16-frame batches: the multi-wave kernel in both layouts (LaneMajor takes it only for these), 1..4 batches;
+    # (3, 8) and (129, 24) stay on the LaneMajor stream kernels
+    for lanes, frames in [(3, 8), (70, 16), (129, 24), (130, 48), (64, 64)]:
         cfg = H.lockin_cfg(lowpass_ks(rng, order, cascade))
         x = adversarial_i32(rng, lanes * frames)
         st = rng.integers(0, 1 << 32, size=(2 + 4 * order * cascade, lanes), dtype=np.uint64).astype(np.uint32)
