@@ -558,8 +558,8 @@ int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state,
     if (lanes && (!state || (frames && (!x || !y)))) return fail(IDSP_EINVAL, "state, x or y is NULL");
     if (lanes > (size_t(1) << 31) - 1 || frames > (size_t(1) << 40)) return fail(IDSP_EINVAL, "lanes/frames out of range");
     if (lanes == 0 || frames == 0) return IDSP_OK;
-    if (reinterpret_cast<uintptr_t>(x) % 8 || reinterpret_cast<uintptr_t>(y) % 8)
-        return fail(IDSP_EINVAL, "x and y must be 8-byte aligned");
+    // f32 slices are 4-byte aligned in the reference; the generic kernels' 8- and 16-byte global accesses are legal at that
+    // alignment on gfx950 (unaligned access mode), the wave kernels below are taken only when their accesses are aligned
     // Fast path: the reference's own cascades run on the specialised one-wave-per-lane
     // kernels when every 16-byte access they make is aligned; anything else (custom taps,
     // odd shapes) takes the generic workgroup-per-lane kernel below.

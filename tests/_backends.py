@@ -69,12 +69,24 @@ class GpuBackend:
         self.e = H.engine()
         self.dev = torch.device("cuda:0")
 
+    # IDSP_TEST_MISALIGN=1: every device buffer starts one element (4 or 8 bytes) into its allocation, so the whole parity
+    # suite can be replayed on buffers without 16-byte alignment (tests/test_gpu_misaligned.py does that in a subprocess)
+    def _alloc(self, n, dtype):
+        import os
+
+        if os.environ.get("IDSP_TEST_MISALIGN"):
+            return self.torch.empty(int(n) + 1, dtype=dtype, device=self.dev)[1:]
+        return self.torch.empty(int(n), dtype=dtype, device=self.dev)
+
     def _up(self, a):
         if a is None:
             return None
         a = np.ascontiguousarray(a)
         view = a.view(np.int32) if a.dtype == np.uint32 else a
-        return self.torch.from_numpy(view.copy()).to(self.dev)
+        host = self.torch.from_numpy(view.copy())
+        t = self._alloc(host.numel(), host.dtype)
+        t.copy_(host.reshape(-1))
+        return t.reshape(host.shape)
 
     def _down(self, t, like_dtype):
         a = t.cpu().numpy()
@@ -83,7 +95,7 @@ class GpuBackend:
     def stream(self, op, cfg, n, state, x, lanes, frames, layout, inplace=False):
         torch = self.torch
         xs = self._up(x)
-        ys = xs if inplace else torch.empty_like(xs)
+        ys = xs if inplace else self._alloc(xs.numel(), xs.dtype).reshape(xs.shape)
         if not inplace:
             ys.fill_(-77 if xs.dtype == torch.int32 else float("nan"))  # poison: every element must be written
         ss = self._up(state)
@@ -96,7 +108,7 @@ class GpuBackend:
     def bylane(self, op, coef, frac, n, state, x, lanes, frames, layout, inplace=False):
         torch = self.torch
         xs, cs, ss = self._up(x), self._up(coef), self._up(state)
-        ys = xs if inplace else torch.empty_like(xs)
+        ys = xs if inplace else self._alloc(xs.numel(), xs.dtype).reshape(xs.shape)
         if not inplace:
             ys.fill_(-77 if xs.dtype == torch.int32 else float("nan"))
         args = (H._ptr(cs),) + (() if frac is None else (frac,)) + (n, H._ptr(ss), H._ptr(xs), H._ptr(ys), lanes, frames, layout, None)
@@ -111,7 +123,7 @@ class GpuBackend:
         torch = self.torch
         xs = self._up(x)
         tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int64): torch.int64}.get(np.dtype(y_dtype), torch.int32)
-        ys = torch.empty(int(np.prod(y_shape)), dtype=tdt, device=self.dev)
+        ys = self._alloc(int(np.prod(y_shape)), tdt)
         ys.fill_(float("nan") if tdt == torch.float32 else -77)  # poison: every element must be written
         ss = self._up(state)
         rc = self.e.cfgcall(op, cfg, ss, xs, ys, lanes, frames, layout)
@@ -122,7 +134,7 @@ class GpuBackend:
     def cossin(self, phases):
         torch = self.torch
         ps = self._up(np.ascontiguousarray(phases, dtype=np.int32))
-        out = torch.empty(ps.numel() * 2, dtype=torch.int32, device=self.dev)
+        out = self._alloc(ps.numel() * 2, torch.int32)
         rc = self.e.fn["cossin_i32"](H._ptr(ps), H._ptr(out), ps.numel(), None)
         torch.cuda.synchronize()
         return rc, out.cpu().numpy().reshape(-1, 2)
@@ -130,7 +142,7 @@ class GpuBackend:
     def atan2(self, xy):
         torch = self.torch
         xs = self._up(np.ascontiguousarray(xy, dtype=np.int32))
-        out = torch.empty(xs.numel() // 2, dtype=torch.int32, device=self.dev)
+        out = self._alloc(xs.numel() // 2, torch.int32)
         rc = self.e.fn["atan2_i32"](H._ptr(xs), H._ptr(out), out.numel(), None)
         torch.cuda.synchronize()
         return rc, out.cpu().numpy()
@@ -138,7 +150,7 @@ class GpuBackend:
     def dds(self, state, lanes, frames, layout):
         torch = self.torch
         ss = self._up(state)
-        out = torch.empty(lanes * frames * 2, dtype=torch.int32, device=self.dev)
+        out = self._alloc(lanes * frames * 2, torch.int32)
         rc = self.e.fn["dds_i32"](H._ptr(ss), H._ptr(out), lanes, frames, layout, None)
         torch.cuda.synchronize()
         state[...] = self._down(ss, np.uint32).reshape(state.shape)

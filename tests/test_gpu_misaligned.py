@@ -1,0 +1,21 @@
+"""f32 / i32 slices are 4-byte aligned in the reference, and a host may hand any such sub-slice to the boundary.  Replay
+the parity suites with every device buffer (input, output, state, coefficient planes) starting one element -- 4 or 8
+bytes -- into its allocation (IDSP_TEST_MISALIGN, read by tests/_backends.py): each kernel must either take a path
+without 16-byte vectors / LDS-DMA or be legal at that alignment, and give the same bits."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUITES = ["tests/test_gpu_parity.py", "tests/test_gpu_bylane.py", "tests/test_gpu_cic.py", "tests/test_gpu_normal_wdf.py",
+          "tests/test_fm_disc.py"]
+
+
+def test_parity_suites_on_buffers_without_16_byte_alignment(gpu):
+    env = dict(os.environ, IDSP_TEST_MISALIGN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", *SUITES, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
