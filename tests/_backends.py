@@ -93,7 +93,10 @@ class GpuBackend:
         return a.view(like_dtype) if a.dtype != like_dtype else a
 
     def stream(self, op, cfg, n, state, x, lanes, frames, layout, inplace=False):
+        import os
+
         torch = self.torch
+        inplace = inplace or bool(os.environ.get("IDSP_TEST_INPLACE"))  # `Inplace::inplace` for every stream call
         xs = self._up(x)
         ys = xs if inplace else self._alloc(xs.numel(), xs.dtype).reshape(xs.shape)
         if not inplace:
@@ -106,7 +109,10 @@ class GpuBackend:
         return rc, self._down(ys, x.dtype).reshape(np.shape(x))
 
     def bylane(self, op, coef, frac, n, state, x, lanes, frames, layout, inplace=False):
+        import os
+
         torch = self.torch
+        inplace = inplace or bool(os.environ.get("IDSP_TEST_INPLACE"))
         xs, cs, ss = self._up(x), self._up(coef), self._up(state)
         ys = xs if inplace else self._alloc(xs.numel(), xs.dtype).reshape(xs.shape)
         if not inplace:

@@ -14,8 +14,14 @@ SUITES = ["tests/test_gpu_parity.py", "tests/test_gpu_bylane.py", "tests/test_gp
           "tests/test_fm_disc.py"]
 
 
-def test_parity_suites_on_buffers_without_16_byte_alignment(gpu):
-    env = dict(os.environ, IDSP_TEST_MISALIGN="1")
+@pytest.mark.parametrize("mode", ["misaligned", "inplace", "both"])
+def test_parity_suites_on_buffers_without_16_byte_alignment(gpu, mode):
+    """mode "inplace": every stream / by-lane call runs as `Inplace::inplace` (y is x, dsp-process/src/process.rs:61-65)."""
+    env = dict(os.environ)
+    if mode in ("misaligned", "both"):
+        env["IDSP_TEST_MISALIGN"] = "1"
+    if mode in ("inplace", "both"):
+        env["IDSP_TEST_INPLACE"] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", *SUITES, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
