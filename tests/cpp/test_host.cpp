@@ -156,6 +156,18 @@ int main()
         for (size_t i = 6144; i < n; i++) si += o[(i * lanes) * 2], sq += o[(i * lanes) * 2 + 1];
         si /= (n - 6144) * amp, sq /= (n - 6144) * amp;
         EXPECT(std::fabs(si - 0.25 * std::cos(phi)) < 3e-3 && std::fabs(sq - 0.25 * std::sin(phi)) < 3e-3);
+        // the same pass with the polar read-out fused in: arg == atan2 of the Complex<i32> output, norm_sqr == re^2 + im^2
+        Lockin<2, 2> la({lp, lp}, {0, 0}, {step, step}), lq({lp, lp}, {0, 0}, {step, step});
+        DeviceBuffer<int32_t> ya(n * lanes), want(n * lanes);
+        DeviceBuffer<int64_t> yp(n * lanes);
+        la.process_view_arg(View<int32_t, FrameMajor>::from_flat(x, lanes), ViewMut<int32_t, FrameMajor>::from_flat(ya, lanes));
+        lq.process_view_norm_sqr(View<int32_t, FrameMajor>::from_flat(x, lanes), ViewMut<int64_t, FrameMajor>::from_flat(yp, lanes));
+        atan2(y, want);
+        EXPECT(ya.to_host() == want.to_host());
+        auto p = yp.to_host();
+        bool ok = true;
+        for (size_t i = 0; i < n * lanes; i++) ok = ok && p[i] == int64_t(o[2 * i]) * o[2 * i] + int64_t(o[2 * i + 1]) * o[2 * i + 1];
+        EXPECT(ok);
     }
     // `Biquad<f64>` DF1 vs DF2T (shape of src/iir/biquad.rs:672-682) and a same-rate EvenSymmetric FIR
     {
