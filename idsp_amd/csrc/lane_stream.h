@@ -263,7 +263,11 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
 // and its dwordx4 stores) are allowed to remain outstanding when tile i is
 // needed; start-up, drain and ragged tiles simply wait for everything.
 constexpr int kLdsT = 8;    // frames per tile
-constexpr int kLdsNB = 8;   // input tiles in the ring (64 KiB)
+// 7, not 8: the ring depth sets how far the DMA reads run ahead of the stores (NB * T rows).  With 8 tiles that was 64 rows =
+// 16 MiB at 65536 lanes, a power of two, and the read and the write stream then collide on the HBM channels unless the
+// caller happens to place y at a lucky offset from x (0.35 ms vs 0.40 ms, in place 0.39 ms); with 7 tiles every placement
+// and the in-place call run at 0.33-0.35 ms (tools/probe_xy_offset.py, profiles/r01_xy_offset_probe.txt).
+constexpr int kLdsNB = 7;   // input tiles in the ring (56 KiB)
 
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {

@@ -43,6 +43,8 @@ def measure(y):
 
 
 deltas = [0, 256, 1024, 4096] + [k << 14 for k in range(1, 65)] + [1 << 21, 1 << 22, 1 << 23, 1 << 24]
+if os.environ.get("IDSP_PROBE_QUICK"):
+    deltas = [0, 1 << 14, 1 << 15, 3 << 14, 1 << 17, 1 << 18, 1 << 21, 1 << 22, 1 << 24]
 for d in deltas:
     w = d // 4
     med, mn = measure(big[N + w:2 * N + w])
