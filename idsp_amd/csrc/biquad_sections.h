@@ -72,6 +72,7 @@ __device__ __forceinline__ int64_t sum5(const SecI32 &c, int32_t x0, int32_t x1,
 template <bool CLAMP>
 struct Df1I32 {
     static constexpr bool kClamp = CLAMP;
+    static constexpr int LDS_RING = CLAMP ? 8 : 7;  // lane_stream.h kLdsNB: measured per processor
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 4;  // x0 x1 y0 y1
@@ -92,6 +93,7 @@ struct Df1I32 {
 template <bool CLAMP>
 struct DitherI32 {
     static constexpr bool kClamp = CLAMP;
+    static constexpr int LDS_RING = CLAMP ? 8 : 7;  // lane_stream.h kLdsNB: measured per processor
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 5;  // x0 x1 y0 y1 e
@@ -176,6 +178,7 @@ struct Df1F32 {
 template <bool CLAMP>
 struct Df2tF32 {
     static constexpr bool kClamp = CLAMP;
+    static constexpr int LDS_RING = CLAMP ? 8 : 7;  // lane_stream.h kLdsNB: measured per processor
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 2;  // s0 s1
@@ -319,6 +322,16 @@ struct NormalF64 {
 };
 
 // ------------------------------------------------------------ processors
+// LDS-DMA ring depth of a one-section processor: the section's LDS_RING if it names one, else 8
+template <class Sec, class = void>
+struct SecRing {
+    static constexpr int value = 8;
+};
+template <class Sec>
+struct SecRing<Sec, std::void_t<decltype(Sec::LDS_RING)>> {
+    static constexpr int value = Sec::LDS_RING;
+};
+
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
 template <class Sec, int N>
 struct Chain {
@@ -328,6 +341,7 @@ struct Chain {
     static constexpr int LDS_WORDS = 0;
     static constexpr int IN_DIV = 1;
     static constexpr int COST = N * Sec::COST;
+    static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
 
@@ -461,6 +475,7 @@ struct ChainByLane {
     static constexpr int LDS_WORDS = 0;
     static constexpr int IN_DIV = 1;
     static constexpr int COST = N * Sec::COST;
+    static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
     static constexpr int CV = Sec::kClamp ? 8 : 5;
     using Params = ByLaneParams;
     uint32_t s[N][Sec::W];

@@ -263,11 +263,22 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
 // and its dwordx4 stores) are allowed to remain outstanding when tile i is
 // needed; start-up, drain and ragged tiles simply wait for everything.
 constexpr int kLdsT = 8;    // frames per tile
-// 7, not 8: the ring depth sets how far the DMA reads run ahead of the stores (NB * T rows).  With 8 tiles that was 64 rows =
-// 16 MiB at 65536 lanes, a power of two, and the read and the write stream then collide on the HBM channels unless the
-// caller happens to place y at a lucky offset from x (0.35 ms vs 0.40 ms, in place 0.39 ms); with 7 tiles every placement
-// and the in-place call run at 0.33-0.35 ms (tools/probe_xy_offset.py, profiles/r01_xy_offset_probe.txt).
-constexpr int kLdsNB = 7;   // input tiles in the ring (56 KiB)
+// Ring depth (input tiles in flight, 8 KiB each at 256 lanes): 8 unless the processor names another (P::LDS_RING).  It sets
+// how far the DMA reads run ahead of the stores.  Measured at C2 (65536 lanes, 256 KiB rows; tools/probe_xy_offset.py over
+// output placements y - x = 1 GiB + delta and in place), plain i32 DF1: 8 tiles 0.348-0.412 ms depending on delta (in
+// place 0.39), 9 tiles 0.347-0.393, 7 tiles 0.333-0.354 (in place 0.34), 6 tiles 0.343-0.363, 5 tiles 0.340-0.354: with 8
+// (and 9) the read and the write stream sit 16 (18) MiB apart and collide on the HBM channels unless y happens to sit at
+// a lucky offset from x.  The clamp / wide / multi-section processors are the other way round (8 tiles 0.35-0.40 ms by
+// placement, 7 or fewer a flat 0.41-0.46 ms), so only DF1 i32, dither and f32 DF2T without clamp take 7.
+constexpr int kLdsNB = 8;
+template <class P, class = void>
+struct LdsRingOf {
+    static constexpr int value = kLdsNB;
+};
+template <class P>
+struct LdsRingOf<P, std::void_t<decltype(P::LDS_RING)>> {
+    static constexpr int value = P::LDS_RING;
+};
 
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     using In = typename P::In;
     using Out = typename P::Out;
     static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4, "LDS path: one 4-byte input per lane and frame");
-    constexpr int T = kLdsT, NB = kLdsNB, OW = sizeof(Out) / 4, B = BatchOf<P>::value;
+    constexpr int T = kLdsT, NB = LdsRingOf<P>::value, OW = sizeof(Out) / 4, B = BatchOf<P>::value;
     constexpr int RPW = T / 4;  // rows per wave and tile
     constexpr int kYoung = RPW * OW + (NB - 1) * (RPW + RPW * OW);
     static_assert(kYoung <= 63 && T % 4 == 0 && T % B == 0, "vmcnt range / tile shape");
@@ -538,7 +549,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             if (P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                 reinterpret_cast<uintptr_t>(y) % 16 == 0 && !getenv("IDSP_NO_LDS_PATH")) {
                 constexpr size_t ow = sizeof(typename P::Out) / 4;
-                constexpr size_t bytes = (size_t(kLdsNB) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
+                constexpr size_t bytes = (size_t(LdsRingOf<P>::value) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
                 static bool attr_done = false;  // per instantiation
                 if (!attr_done) {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_lds<P>),

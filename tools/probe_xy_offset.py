@@ -16,10 +16,16 @@ lanes, frames = 65536, 4096
 N = lanes * frames
 cfg = _abi.BiquadI32()
 call("biquad_i32_from_sos", (C.c_double * 6)(*lowpass_sos(0.01)), 30, C.byref(cfg))
-cfgs = (_abi.BiquadI32 * 1)(cfg)
+OP = os.environ.get("IDSP_PROBE_OP", "biquad_i32_df1")  # or biquad_i32_df1_clamp / biquad_i32_wide_clamp (state words 4 / 6)
+if "clamp" in OP:
+    cfgs = (_abi.BiquadClampI32 * 1)()
+    cfgs[0].ba[:] = list(cfg.ba)
+    cfgs[0].frac, cfgs[0].u, cfgs[0].min, cfgs[0].max = 30, 3, -(1 << 30), 1 << 30
+else:
+    cfgs = (_abi.BiquadI32 * 1)(cfg)
 stream = torch.cuda.Stream(device=dev)
 sp = C.c_void_p(stream.cuda_stream)
-state = torch.zeros((4, lanes), dtype=torch.int32, device=dev)
+state = torch.zeros((6, lanes), dtype=torch.int32, device=dev)
 big = torch.empty(2 * N + (16 << 20), dtype=torch.int32, device=dev)
 x = big[:N]
 x.copy_(torch.randint(-(1 << 24), 1 << 24, (N,), dtype=torch.int32, device=dev))
@@ -27,7 +33,7 @@ x.copy_(torch.randint(-(1 << 24), 1 << 24, (N,), dtype=torch.int32, device=dev))
 
 def measure(y):
     def step():
-        call("biquad_i32_df1", C.cast(cfgs, C.c_void_p), 1, C.c_void_p(state.data_ptr()), C.c_void_p(x.data_ptr()),
+        call(OP, C.cast(cfgs, C.c_void_p), 1, C.c_void_p(state.data_ptr()), C.c_void_p(x.data_ptr()),
              C.c_void_p(y.data_ptr()), lanes, frames, 0, sp)
     for _ in range(60):
         step()
