@@ -225,6 +225,7 @@ FRONTEND = {
 UTILS = {
     "version": (_I, []),
     "last_error": (C.c_char_p, []),
+    "last_kernel": (C.c_char_p, []),
     "device_count": (_I, []),
     "device_set": (_I, [_I]),
     "device_alloc": (_I, [C.POINTER(_P), _SZ]),

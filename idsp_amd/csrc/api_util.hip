@@ -1,6 +1,8 @@
 // api_util.hip — library/device utilities, coefficient ingestion and the
 // built-in half-band tap sets of the C ABI (include/idsp_hip.h).  Host code
 // only; nothing here is on the per-sample path.
+#include <cxxabi.h>
+
 #include <cmath>
 #include <cstring>
 
@@ -22,6 +24,26 @@ int fail(int code, const char *fmt, ...)
     vsnprintf(last_error_buf(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+namespace {
+struct LastKernel {
+    const char *kernel = nullptr, *detail = nullptr;
+    char text[768] = {0};
+};
+LastKernel &last_kernel()
+{
+    static thread_local LastKernel k;
+    return k;
+}
+}  // namespace
+
+// two pointer stores per launch; the text is built only when idsp_last_kernel() is called
+void note_kernel(const char *kernel, const char *detail)
+{
+    LastKernel &k = last_kernel();
+    k.kernel = kernel;
+    k.detail = detail;
 }
 
 namespace {
@@ -74,6 +96,22 @@ extern "C" {
 int idsp_version(void) { return IDSP_ABI_VERSION; }
 
 const char *idsp_last_error(void) { return last_error_buf(); }
+
+const char *idsp_last_kernel(void)
+{
+    auto &k = last_kernel();
+    if (!k.kernel) return "";
+    if (k.detail) {
+        // `detail` is typeid(Processor).name(): demangle it for the reader
+        int status = 0;
+        char *dm = abi::__cxa_demangle(k.detail, nullptr, nullptr, &status);
+        snprintf(k.text, sizeof(k.text), "%s<%s>", k.kernel, status == 0 && dm ? dm : k.detail);
+        free(dm);
+    } else {
+        snprintf(k.text, sizeof(k.text), "%s", k.kernel);
+    }
+    return k.text;
+}
 
 int idsp_device_count(void)
 {

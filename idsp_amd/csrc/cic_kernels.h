@@ -457,6 +457,12 @@ __global__ __launch_bounds__(kBlock) void cic_int_lm_kernel(const idsp_cic cfg, 
     c.store(st, lanes, lane, m);
 }
 
+inline bool cic_no_lm_tiles()
+{
+    static const bool v = diag_env("IDSP_CIC_NO_LM_TILES") != nullptr;
+    return v;
+}
+
 inline int cfg_check(const idsp_cic *c)
 {
     if (!c) return fail(IDSP_EINVAL, "cfg is NULL");
@@ -488,7 +494,7 @@ int run_orders(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes,
     // LANE_MAJOR tile kernels: whole waves, at least one whole tile
     const bool lm_tiles = layout == IDSP_LANE_MAJOR && vpc > 0 && lanes % kBlock == 0 && frames >= size_t(kTileVecs / (vpc ? vpc : 1)) &&
                           reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
-                          (frames * R * sizeof(T)) % 16 == 0 && !getenv("IDSP_CIC_NO_LM_TILES");
+                          (frames * R * sizeof(T)) % 16 == 0 && !cic_no_lm_tiles();
 #define IDSP_CIC_LAUNCH(NN, VV)                                                                                       \
     do {                                                                                                              \
         if constexpr (VV > 0) {                                                                                       \

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "idsp_hip.h"
 
@@ -23,6 +24,22 @@ int fail(int code, const char *fmt, ...);
         if (e_ != hipSuccess)                                                           \
             return ::idsp::fail(IDSP_EHIP, "%s: %s", #expr, hipGetErrorString(e_));     \
     } while (0)
+
+// Kernel-selection switches exist for A/B measurements and for tests that force a
+// path a default run would not reach.  A production process must not change dispatch because of a stray
+// variable, so they are honoured only when IDSP_DIAG=1 is set as well; every caller caches the answer in a
+// function-local static (read once per process).
+inline const char *diag_env(const char *name)
+{
+    static const bool on = [] {
+        const char *e = getenv("IDSP_DIAG");
+        return e && atoi(e) != 0;
+    }();
+    return on ? getenv(name) : nullptr;
+}
+
+// Name of the kernel the most recent launch on this thread dispatched to (idsp_last_kernel()).
+void note_kernel(const char *kernel, const char *detail = nullptr);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

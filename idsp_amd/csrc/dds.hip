@@ -26,9 +26,9 @@ namespace {
 // Returns the wave count per 64 lanes, 0 = use the stream kernels.
 inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t frames, int layout, bool heavy_readout)
 {
-    static const bool off = getenv("IDSP_LOCKIN_NO_WAVES") != nullptr;
+    static const bool off = diag_env("IDSP_LOCKIN_NO_WAVES") != nullptr;
     static const int forced = [] {
-        const char *e = getenv("IDSP_LOCKIN_WAVES");
+        const char *e = diag_env("IDSP_LOCKIN_WAVES");
         return e ? atoi(e) : 0;
     }();
     if (off || frames == 0) return 0;

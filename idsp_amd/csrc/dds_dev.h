@@ -23,7 +23,7 @@ __device__ const uint32_t d_cossin_table[1 << kCossinDepth] = {
 inline size_t split_max_lanes()
 {
     static const size_t v = [] {
-        const char *e = getenv("IDSP_SPLIT_MAX_LANES");
+        const char *e = diag_env("IDSP_SPLIT_MAX_LANES");
         return e ? size_t(strtoull(e, nullptr, 10)) : size_t(40960);
     }();
     return v;

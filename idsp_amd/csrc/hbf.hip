@@ -227,10 +227,12 @@ __global__ __launch_bounds__(kThreads) void hbf_dec_kernel(const HbfArgs a, uint
             n >>= 1;
             const int M = a.m[s];
             const float *E = lds + a.buf_a[s], *O = lds + a.buf_b[s];
+#ifdef IDSP_DEBUG_ABLATE
             if (a.ablate & (1 << s)) {
                 lds_barrier();
                 continue;
             }
+#endif
             if (s + 1 < S) {
                 const int Mn = a.m[s + 1];
                 dec_stage_dispatch(M, E, O, n, a.taps[s], lds + a.buf_a[s + 1] + up4(Mn - 1),
@@ -528,7 +530,9 @@ int fill_args(const idsp_hbf_cascade_f32 *cfg, bool dec, HbfArgs &a, int &lds_wo
         }
     }
     a.st_off[cfg->stages] = so;
-    if (const char *e = getenv("IDSP_HBF_ABLATE")) a.ablate = atoi(e);
+#ifdef IDSP_DEBUG_ABLATE  // timing ablation: never in the shipped library (it changes results)
+    if (const char *e = diag_env("IDSP_HBF_ABLATE")) a.ablate = atoi(e);
+#endif
     a.stage_off = off;  // FRAME_MAJOR output staging: one chunk of outputs
     off += (dec ? kChunk / 2 : kChunk) + kSlack;
     lds_words = off;
@@ -563,7 +567,8 @@ int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state,
     // Fast path: the reference's own cascades run on the specialised one-wave-per-lane
     // kernels when every 16-byte access they make is aligned; anything else (custom taps,
     // odd shapes) takes the generic workgroup-per-lane kernel below.
-    const int ts = getenv("IDSP_HBF_GENERIC") ? -1 : builtin_tap_set(cfg, dec);
+    static const bool force_generic = diag_env("IDSP_HBF_GENERIC") != nullptr;
+    const int ts = force_generic ? -1 : builtin_tap_set(cfg, dec);
     const bool lm = layout == IDSP_LANE_MAJOR;
     const size_t R = size_t(1) << cfg->stages;
     const void *wide = dec ? static_cast<const void *>(x) : static_cast<const void *>(y);

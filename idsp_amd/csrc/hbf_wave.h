@@ -594,7 +594,7 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
         if constexpr (S >= 2) {
             if constexpr (DEC) {
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + 2 * (kCH / C::rate) * kBlkLanes) * sizeof(float);
-                static const bool use_block = !getenv("IDSP_HBF_NO_BLOCK_FM");
+                static const bool use_block = !diag_env("IDSP_HBF_NO_BLOCK_FM");
                 if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
                     static bool attr_done = false;
                     if (!attr_done) {
@@ -612,7 +612,7 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
             }
             else {
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + size_t(kBlkLanes) * kCH) * sizeof(float);
-                static const bool use_block = !getenv("IDSP_HBF_NO_BLOCK_FM");
+                static const bool use_block = !diag_env("IDSP_HBF_NO_BLOCK_FM");
                 if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
                     static bool attr_done = false;
                     if (!attr_done) {

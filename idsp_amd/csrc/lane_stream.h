@@ -40,8 +40,10 @@
 //   every SIMD a wave; `lanes` then counts virtual lanes.
 #pragma once
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
+#include <typeinfo>
 
 #include "common.h"
 
@@ -148,7 +150,7 @@ constexpr int kFmBlock = 256;  // 4 waves: one per SIMD of a CU, 1 KiB row segme
 template <class P, int U>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
 {
     using In = typename P::In;
     using Out = typename P::Out;
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
 #else
     constexpr bool kNT = P::COST <= 220;
 #endif
-    const size_t xl = lanes / P::IN_DIV;  // input row pitch (IN_DIV virtual lanes share an input lane)
+    // xl / yl: elements between consecutive frames of x / y (dense: lanes / IN_DIV and lanes — IN_DIV virtual
+    // lanes share an input lane)
     const In *xp = x + lane / P::IN_DIV;
     Out *yp = y + lane;
 
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
         size_t f = 0;
         for (; f + 2 * U <= frames; f += U) {
             const In *xn = xp + (f + U) * xl;
-            Out *yn = yp + f * lanes;
+            Out *yn = yp + f * yl;
             constexpr int B = BatchOf<P>::value;
             static_assert(U % B == 0, "window depth must be a multiple of the batch");
 #pragma unroll
@@ -200,13 +203,13 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
                         const int u = u0 + b;
                         const In v = ring[u];
                         ring[u] = nt_load<kNT>(xn + size_t(u) * xl);
-                        nt_store<kNT>(yn + size_t(u) * lanes, p.step(prm, v, pre[b]));
+                        nt_store<kNT>(yn + size_t(u) * yl, p.step(prm, v, pre[b]));
                     }
                 } else {
                     const int u = u0;
                     const In v = ring[u];
                     ring[u] = nt_load<kNT>(xn + size_t(u) * xl);
-                    nt_store<kNT>(yn + size_t(u) * lanes, p.step(prm, v));
+                    nt_store<kNT>(yn + size_t(u) * yl, p.step(prm, v));
                 }
             }
         }
@@ -217,14 +220,14 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
             if (fr < frames) {
                 const In v = ring[u];
                 if (fr + U < frames) ring[u] = nt_load<kNT>(xp + (fr + U) * xl);
-                nt_store<kNT>(yp + fr * lanes, step1(p, prm, v));
+                nt_store<kNT>(yp + fr * yl, step1(p, prm, v));
             }
         }
         f += U;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t fr = f + u;
-            if (fr < frames) nt_store<kNT>(yp + fr * lanes, step1(p, prm, ring[u]));
+            if (fr < frames) nt_store<kNT>(yp + fr * yl, step1(p, prm, ring[u]));
         }
     } else {
         constexpr int B = BatchOf<P>::value;
@@ -234,13 +237,13 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
                 typename P::Pre pre[B];
                 pre_all<P, B>(p, prm, pre);
 #pragma unroll
-                for (int b = 0; b < B; b++) nt_store<kNT>(yp + size_t(b) * lanes, p.step(prm, In{}, pre[b]));
-                yp += size_t(B) * lanes;
+                for (int b = 0; b < B; b++) nt_store<kNT>(yp + size_t(b) * yl, p.step(prm, In{}, pre[b]));
+                yp += size_t(B) * yl;
             }
         }
         for (; f < frames; f++) {
             nt_store<kNT>(yp, step1(p, prm, In{}));
-            yp += lanes;
+            yp += yl;
         }
     }
     p.store(prm, st, lanes, lane);
@@ -271,6 +274,8 @@ constexpr int kLdsT = 8;    // frames per tile
 // a lucky offset from x.  The clamp / wide / multi-section processors are the other way round (8 tiles 0.35-0.40 ms by
 // placement, 7 or fewer a flat 0.41-0.46 ms), so only DF1 i32, dither and f32 DF2T without clamp take 7.
 constexpr int kLdsNB = 8;
+// Largest grid of the LDS-DMA kernel; launches with more 256-lane blocks walk them persistently (0 = never).
+constexpr size_t kLdsGridCap = 512;
 template <class P, class = void>
 struct LdsRingOf {
     static constexpr int value = kLdsNB;
@@ -299,7 +304,7 @@ __device__ __forceinline__ void wait_vmcnt()
 template <class P>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
 {
     using In = typename P::In;
     using Out = typename P::Out;
@@ -316,8 +321,6 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     uint32_t *ptab = tout + 2 * T * kFmBlock * OW;     // [P::LDS_WORDS]
     const int tid = threadIdx.x, lid = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t lane0 = size_t(blockIdx.x) * kFmBlock;
-    const size_t lane = lane0 + tid;  // lanes % 256 == 0 (launcher)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem;
 
     P p;
@@ -325,6 +328,13 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
         P::fill_shared(ptab, tid, kFmBlock);  // published by the first tile barrier
         p.set_shared(ptab);
     }
+    // Persistent over lane blocks: workgroup w walks the 256-lane blocks w, w + grid, w + 2 grid, ... one after the
+    // other (state load, the whole frame walk, state store per block).  The launcher sizes the grid so that every CU
+    // holds the number of workgroups that was measured fastest instead of whatever lanes / 256 happens to be.
+    const size_t nblocks = lanes / kFmBlock;  // lanes % 256 == 0 (launcher)
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const size_t lane0 = blk * kFmBlock;
+    const size_t lane = lane0 + tid;
     p.load(prm, st, lanes, lane);
 
     const size_t ntiles = (frames + T - 1) / T;
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
             const int r = wave + 4 * j;
-            if (FULL || r < nr) glds16(x + (tile * T + r) * lanes + lane0 + lid * 4, lds_base + uint32_t((slot * T + r) * kFmBlock * 4));
+            if (FULL || r < nr) glds16(x + (tile * T + r) * xl + lane0 + lid * 4, lds_base + uint32_t((slot * T + r) * kFmBlock * 4));
         }
     };
     auto store = [&](size_t tile, auto full) {
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(o + (r * OW + h) * kFmBlock + lid * 4);
-                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(yw + ((tile * T + r) * lanes + lane0) * OW + h * kFmBlock + lid * 4));
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(yw + ((tile * T + r) * yl + lane0) * OW + h * kFmBlock + lid * 4));
                 }
             }
         }
@@ -404,6 +414,10 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     }
     for (; i < ntiles; i++) slow_iter();
     p.store(prm, st, lanes, lane);
+    // No barrier needed here: the next block's first lds_barrier() (after each wave's lgkmcnt wait) orders this
+    // block's last output-tile reads before the compute() that overwrites the tile, and its first DMA rows only
+    // touch input slots whose last readers passed the barrier after the final compute().
+    }
 }
 
 // ----------------------------------------------------------------- LANE_MAJOR
@@ -413,8 +427,9 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 template <class P>
 __global__ __launch_bounds__(kWave) void stream_lane_major(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
 {
+    // xl / yl: samples between the starts of consecutive lanes of x / y (dense: frames)
     using In = typename P::In;
     using Out = typename P::Out;
     // D = IN_DIV threads ("virtual lanes") share one lane: they read the same input sample and each
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 #pragma unroll
             for (int i = 0; i < NLD; i++) {
                 const size_t r = size_t(i) * RPI + lrow;
-                stage[i] = (r < nrows && size_t(lcol) < nw) ? xw[((lane0 + r) * frames + t0) * IW + lcol] : 0u;
+                stage[i] = (r < nrows && size_t(lcol) < nw) ? xw[((lane0 + r) * xl + t0) * IW + lcol] : 0u;
             }
         }
     };
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
         // row-contiguous stores: one instruction = up to 64 consecutive words of one lane
         const size_t nw = ncols * OWR;
         for (size_t r = 0; r < nrows; r++) {
-            if (size_t(lid) < nw) yw[((lane0 + r) * frames + t0) * OWR + lid] = tout[r][lid];
+            if (size_t(lid) < nw) yw[((lane0 + r) * yl + t0) * OWR + lid] = tout[r][lid];
         }
         lds_wave_sync();
     }
@@ -521,44 +536,75 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 // --------------------------------------------------------------------- launch
 // Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
 // latency, so go deep; with many resident waves keep the register budget low.
-// smallest launch (in waves) that takes the 256-thread LDS-DMA kernel (IDSP_LDS_MIN_WAVES overrides):
+// smallest launch (in waves) that takes the 256-thread LDS-DMA kernel (IDSP_DIAG=1 IDSP_LDS_MIN_WAVES overrides):
 // measured equal to the single-wave register kernel at 16384 lanes, 15-20 % ahead at 32768-49152,
 // slightly behind at 8192
+inline size_t diag_size(const char *name, size_t dflt)
+{
+    const char *e = diag_env(name);
+    return e ? size_t(strtoull(e, nullptr, 10)) : dflt;
+}
 inline size_t lds_min_waves()
 {
-    static const size_t v = getenv("IDSP_LDS_MIN_WAVES") ? size_t(atoll(getenv("IDSP_LDS_MIN_WAVES"))) : size_t(256);
+    static const size_t v = diag_size("IDSP_LDS_MIN_WAVES", 256);
     return v;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the ABI lets one
+// process switch devices (idsp_device_set), and the attribute is per device.
+template <class K>
+inline int ensure_dyn_lds(K kernel, size_t bytes)
+{
+    static std::atomic<uint64_t> done{0};  // one bit per device ordinal, per instantiation of this template
+    int dev = 0;
+    IDSP_HIP_TRY(hipGetDevice(&dev));
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return IDSP_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+    if (e != hipSuccess) return fail(IDSP_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (dev < 64) done.fetch_or(bit, std::memory_order_release);
+    return IDSP_OK;
+}
+
+// Row pitches of a call: elements between consecutive frames (FRAME_MAJOR) or between the starts of consecutive
+// lanes (LANE_MAJOR) of x and y; 0 = dense.  The `_pitch` entry points of the ABI pass them through.
+struct Pitch {
+    size_t x = 0, y = 0;
+};
+
 template <class P>
 int launch_stream(const typename P::Params &prm, void *state, const typename P::In *x,
-                  typename P::Out *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+                  typename P::Out *y, size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch = {})
 {
     if (lanes == 0) return IDSP_OK;
     uint32_t *st = static_cast<uint32_t *>(state);
     if (layout == IDSP_LANE_MAJOR) {
+        const size_t xl = pitch.x ? pitch.x : frames, yl = pitch.y ? pitch.y : frames;
         const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
-        hipLaunchKernelGGL((stream_lane_major<P>), dim3(grid), dim3(kWave), 0, s, prm, st, x, y, lanes, frames);
+        note_kernel("stream_lane_major", typeid(P).name());
+        hipLaunchKernelGGL((stream_lane_major<P>), dim3(grid), dim3(kWave), 0, s, prm, st, x, y, lanes, frames, xl, yl);
     } else {
+        const size_t xl = pitch.x ? pitch.x : lanes / P::IN_DIV, yl = pitch.y ? pitch.y : lanes;
         const size_t waves = (lanes + kWave - 1) / kWave;
         if constexpr (P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4) {
             // cheap per-sample arithmetic (the extra LDS hop and the two barriers per tile cost issue
-            // slots), <= 2 waves per SIMD, whole 256-lane blocks, 16-byte aligned rows: LDS-DMA path
-            static const int lds_cost_max = getenv("IDSP_LDS_COST") ? atoi(getenv("IDSP_LDS_COST")) : 120;
-            static const size_t lds_max_waves = getenv("IDSP_LDS_MAX_WAVES") ? size_t(atoll(getenv("IDSP_LDS_MAX_WAVES"))) : size_t(2048);
-            if (P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
-                reinterpret_cast<uintptr_t>(y) % 16 == 0 && !getenv("IDSP_NO_LDS_PATH")) {
-                constexpr size_t ow = sizeof(typename P::Out) / 4;
+            // slots), whole 256-lane blocks, 16-byte aligned rows: LDS-DMA path
+            static const int lds_cost_max = int(diag_size("IDSP_LDS_COST", 120));
+            static const size_t lds_max_waves = diag_size("IDSP_LDS_MAX_WAVES", size_t(1) << 40);
+            static const bool no_lds = diag_env("IDSP_NO_LDS_PATH") != nullptr;
+            constexpr size_t ow = sizeof(typename P::Out) / 4;
+            if (!no_lds && P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 &&
+                reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && (yl * ow) % 4 == 0) {
                 constexpr size_t bytes = (size_t(LdsRingOf<P>::value) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
-                static bool attr_done = false;  // per instantiation
-                if (!attr_done) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_lds<P>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
-                    if (e != hipSuccess) return fail(IDSP_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                    attr_done = true;
-                }
-                hipLaunchKernelGGL((stream_frame_major_lds<P>), dim3(unsigned(lanes / kFmBlock)), dim3(kFmBlock), bytes, s,
-                                   prm, st, x, y, lanes, frames);
+                if (int rc = ensure_dyn_lds(stream_frame_major_lds<P>, bytes)) return rc;
+                // Grid: one workgroup per 256-lane block while they are all resident at once (2 per CU by LDS);
+                // beyond that a persistent grid walks the blocks (IDSP_DIAG=1 IDSP_LDS_GRID overrides the cap).
+                static const size_t grid_cap = diag_size("IDSP_LDS_GRID", kLdsGridCap);
+                const size_t nblocks = lanes / kFmBlock;
+                const size_t grid = grid_cap && nblocks > grid_cap ? grid_cap : nblocks;
+                note_kernel("stream_frame_major_lds", typeid(P).name());
+                hipLaunchKernelGGL((stream_frame_major_lds<P>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s,
+                                   prm, st, x, y, lanes, frames, xl, yl);
                 return launch_status();
             }
         }
@@ -567,10 +613,11 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         const unsigned block = waves < 1024 ? unsigned(kWave) : unsigned(kFmBlock);
         const unsigned grid = unsigned((lanes + block - 1) / block);
         constexpr int kDeep = MaxU<P>::value, kShallow = kDeep < 8 ? kDeep : 8;
+        note_kernel("stream_frame_major", typeid(P).name());
         if (waves <= 2048)
-            hipLaunchKernelGGL((stream_frame_major<P, kDeep>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
+            hipLaunchKernelGGL((stream_frame_major<P, kDeep>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl);
         else
-            hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames);
+            hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl);
     }
     return launch_status();
 }

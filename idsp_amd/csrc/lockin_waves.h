@@ -226,12 +226,12 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
     using Out = typename LwOut<MODE>::type;
     uint32_t *st = static_cast<uint32_t *>(state);
     Out *y = static_cast<Out *>(yv);
-    static const bool no_dma = getenv("IDSP_LOCKIN_NO_DMA") != nullptr;
+    static const bool no_dma = diag_env("IDSP_LOCKIN_NO_DMA") != nullptr;
     // 16-frame batches halve the barriers per frame: 0.37 -> 0.35 ms (Complex<i32>), 0.61 -> 0.59 ms (arg) at 32768 lanes x 4096
     // frames, but 1.06 -> 1.19 ms (arg) at 65536 lanes, where the longer intervals cost more than the barriers
     // (IDSP_LOCKIN_B = 8 / 16 forces one)
     static const int forced_b = [] {
-        const char *e = getenv("IDSP_LOCKIN_B");
+        const char *e = diag_env("IDSP_LOCKIN_B");
         return e ? atoi(e) : 0;
     }();
     const bool b16 = forced_b == 16 || (forced_b != 8 && lanes <= kSplitMaxLanes);

@@ -84,6 +84,10 @@ typedef enum idsp_layout {
 int idsp_version(void);
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char *idsp_last_error(void);
+/* Diagnostic: thread-local name of the kernel (and processor instantiation) the most recent processing call
+ * of this thread dispatched to, e.g. "stream_frame_major_lds<idsp::bq::Chain<idsp::bq::Df1I32<false>, 1>>";
+ * "" before the first launch.  Multi-pass calls report their last pass. */
+const char *idsp_last_kernel(void);
 /* Number of visible HIP devices, or a negative idsp_status. */
 int idsp_device_count(void);
 /* Select the device used by subsequent calls of this thread. */

@@ -78,7 +78,7 @@ I32_OPS = [
     ("biquad_i32_wide", 6, False), ("biquad_i32_wide_clamp", 6, True),
 ]
 SHAPES = [(1, 1), (1, 100), (63, 23), (64, 24), (65, 47), (130, 48), (64, 49), (257, 64), (100, 65), (70, 130), (3, 1000),
-          (1028, 77), (4096, 50), (516, 9), (512, 300), (256, 1001)]
+          (1028, 77), (4096, 50), (516, 9), (512, 300), (256, 1001), (768, 41), (1024, 8), (256, 7), (2048, 121)]
 
 
 def run_both(bes, op, cfg, n, words, x, lanes, frames, layout, rng, is_float=False):
@@ -114,7 +114,7 @@ def run_both(bes, op, cfg, n, words, x, lanes, frames, layout, rng, is_float=Fal
 @pytest.mark.parametrize("layout", [FM, LM])
 def test_biquad_i32_parity(bes, op, words, clamp, layout):
     rng = np.random.default_rng(zlib.crc32(f"{op}-{layout}".encode()))
-    for (lanes, frames), n in zip(SHAPES, [1, 2, 1, 3, 4, 1, 5, 1, 9, 2, 1, 1, 2, 1, 1, 3]):
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 1, 3, 4, 1, 5, 1, 9, 2, 1, 1, 2, 1, 1, 3, 1, 2, 1, 1]):
         rows = random_i32_sections(rng, n, clamp)
         cfg = H.biquad_clamp_i32(rows) if clamp else H.biquad_i32(rows)
         x = adversarial_i32(rng, lanes * frames)
@@ -124,7 +124,7 @@ def test_biquad_i32_parity(bes, op, words, clamp, layout):
 @pytest.mark.parametrize("layout", [FM, LM])
 def test_cascade_i32_parity(bes, layout):
     rng = np.random.default_rng(11 + layout)
-    for (lanes, frames), n in zip(SHAPES, [1, 2, 3, 4, 5, 6, 7, 8, 1, 4, 8, 1, 2, 3, 2, 5]):
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 3, 4, 5, 6, 7, 8, 1, 4, 8, 1, 2, 3, 2, 5, 1, 8, 2, 3]):
         cfg = H.biquad_i32(random_i32_sections(rng, n, False))
         x = adversarial_i32(rng, lanes * frames)
         run_both(bes, "cascade_i32_df1", cfg, n, 2 + 2 * n, x, lanes, frames, layout, rng)
@@ -160,7 +160,7 @@ F32_OPS = [("biquad_f32_df1", 4, False), ("biquad_f32_df1_clamp", 4, True),
 @pytest.mark.parametrize("layout", [FM, LM])
 def test_biquad_f32_parity(bes, op, words, clamp, layout):
     rng = np.random.default_rng(zlib.crc32(f"{op}-{layout}-f".encode()))
-    for (lanes, frames), n in zip(SHAPES, [1, 2, 1, 3, 4, 1, 5, 1, 9, 2, 1, 1, 2, 1, 1, 3]):
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 1, 3, 4, 1, 5, 1, 9, 2, 1, 1, 2, 1, 1, 3, 1, 2, 1, 1]):
         rows = random_f32_sections(rng, n, clamp)
         cfg = H.biquad_clamp_f32(rows) if clamp else H.biquad_f32(rows)
         x = adversarial_f32(rng, lanes * frames)
@@ -170,7 +170,7 @@ def test_biquad_f32_parity(bes, op, words, clamp, layout):
 @pytest.mark.parametrize("layout", [FM, LM])
 def test_cascade_f32_parity(bes, layout):
     rng = np.random.default_rng(13 + layout)
-    for (lanes, frames), n in zip(SHAPES, [1, 2, 3, 4, 5, 6, 7, 8, 1, 4, 8, 1, 2, 3, 2, 5]):
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 3, 4, 5, 6, 7, 8, 1, 4, 8, 1, 2, 3, 2, 5, 1, 8, 2, 3]):
         cfg = H.biquad_f32(random_f32_sections(rng, n, False))
         x = adversarial_f32(rng, lanes * frames)
         run_both(bes, "cascade_f32_df1", cfg, n, 2 + 2 * n, x, lanes, frames, layout, rng, is_float=True)
@@ -196,7 +196,7 @@ def test_biquad_f64_parity(bes, op, words, clamp, layout):
     """`Biquad<f64>`: the same generic impls; held to 0 ULP (allowed: 1)."""
     ob, gb = bes
     rng = np.random.default_rng(zlib.crc32(f"{op}-{layout}-d".encode()))
-    for (lanes, frames), n in zip(SHAPES, [1, 2, 1, 3, 4, 1, 5, 1, 9, 2, 1, 1, 2, 1, 1, 3]):
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 1, 3, 4, 1, 5, 1, 9, 2, 1, 1, 2, 1, 1, 3, 1, 2, 1, 1]):
         rows = random_f32_sections(rng, n, clamp)  # f32-representable coefficients are valid f64 ones
         rows = [(r[0], r[1], r[2], r[3]) if clamp else r for r in rows]
         cfg = H.biquad_clamp_f64(rows) if clamp else H.biquad_f64(rows)
@@ -219,7 +219,7 @@ def test_biquad_f64_parity(bes, op, words, clamp, layout):
 def test_cascade_f64_parity(bes, layout):
     ob, gb = bes
     rng = np.random.default_rng(17 + layout)
-    for (lanes, frames), n in zip(SHAPES, [1, 2, 3, 4, 5, 6, 7, 8, 1, 4, 8, 1, 2, 3, 2, 5]):
+    for (lanes, frames), n in zip(SHAPES, [1, 2, 3, 4, 5, 6, 7, 8, 1, 4, 8, 1, 2, 3, 2, 5, 1, 8, 2, 3]):
         cfg = H.biquad_f64(random_f32_sections(rng, n, False))
         x = adversarial_f64(rng, lanes * frames)
         so, sg = np.zeros((4 + 4 * n, lanes), np.uint32), np.zeros((4 + 4 * n, lanes), np.uint32)

@@ -68,10 +68,10 @@ def p(t):
 
 
 def out_like(x):
-    """Output buffer of x's shape placed as bench.py places it: in one allocation with x's copy, 48 KiB past x's size
-    (the offset y - x moves a streaming kernel by up to 15 %; two torch allocations land anywhere).
-    Returns (x_in_arena, y)."""
-    if os.environ.get("IDSP_PERF_TORCH_PLACEMENT"):
+    """Output buffer of x's shape: a plain second allocation, like bench.py's.  IDSP_PERF_ARENA=1 carves x and y out of one
+    allocation with y 48 KiB past x's size instead (round 1's placement: the offset y - x moved a ring-of-8 streaming
+    kernel by up to 15 %).  Returns (x, y)."""
+    if not os.environ.get("IDSP_PERF_ARENA"):
         return x, torch.empty_like(x)
     n, pad = x.numel(), (48 << 10) // x.element_size()
     arena = torch.empty(2 * n + pad, dtype=x.dtype, device=x.device)
@@ -345,6 +345,12 @@ def main():
         biquad("biquad_f32_df2t", torch.float32, 2, 1 << 17, 4096, FM, 1, it, "C5/8")
         biquad("biquad_f32_df2t", torch.float32, 2, 1 << 20, 4096, FM, 1, max(3, it // 3), "C5")
         biquad("biquad_f32_df2t", torch.float32, 2, 1 << 20, 4096, LM, 1, max(3, it // 3), "C5")
+    if sel and "c5sweep" in sel:  # lane counts beyond one resident wave of workgroups (IDSP_DIAG=1 IDSP_LDS_GRID=... per process)
+        for lg in (16, 17, 18, 19, 20):
+            biquad("biquad_f32_df2t", torch.float32, 2, 1 << lg, 4096, FM, 1, max(3, it >> max(0, lg - 17)), "C5s")
+        for lg in (17, 20):
+            biquad("biquad_i32_df1", torch.int32, 4, 1 << lg, 4096, FM, 1, max(3, it >> max(0, lg - 17)), "C5s")
+            biquad("biquad_i32_df1_clamp", torch.int32, 4, 1 << lg, 4096, FM, 1, max(3, it >> max(0, lg - 17)), "C5s")
     if want("c3"):
         hbf("dec", 4, 16384, 4096, LM, it, "C3")
         hbf("dec", 4, 16384, 4096, FM, max(3, it // 3), "C3")
