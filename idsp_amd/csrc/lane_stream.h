@@ -301,7 +301,21 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <class P>
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// LPT ("lanes per thread") > 1: a workgroup owns 256 * LPT adjacent lanes; thread t runs the LPT independent
+// recurrences of lanes t, t + 256, ... and the tile sequence interleaves them: virtual tile v = row group v / LPT
+// (T frames) of sub-block v % LPT.  Tile size, ring bytes, barriers per sample and the vmcnt bookkeeping are those of
+// LPT = 1; what changes is that a launch of L lanes needs L / (256 LPT) workgroups — the launcher picks LPT so that
+// large launches still run as ~256 workgroups (one per CU) sweeping whole rows, the regime C2 is fast in.
+template <class P, int NB = LdsRingOf<P>::value, int LPT = 1>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
@@ -309,7 +323,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     using In = typename P::In;
     using Out = typename P::Out;
     static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4, "LDS path: one 4-byte input per lane and frame");
-    constexpr int T = kLdsT, NB = LdsRingOf<P>::value, OW = sizeof(Out) / 4, B = BatchOf<P>::value;
+    static_assert(LPT >= 1 && (LPT & (LPT - 1)) == 0, "LPT is a power of two");
+    constexpr int T = kLdsT, OW = sizeof(Out) / 4, B = BatchOf<P>::value;
     constexpr int RPW = T / 4;  // rows per wave and tile
     constexpr int kYoung = RPW * OW + (NB - 1) * (RPW + RPW * OW);
     static_assert(kYoung <= 63 && T % 4 == 0 && T % B == 0, "vmcnt range / tile shape");
@@ -323,35 +338,42 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem;
 
-    P p;
+    P p[LPT];
     if constexpr (P::LDS_WORDS > 0) {
         P::fill_shared(ptab, tid, kFmBlock);  // published by the first tile barrier
-        p.set_shared(ptab);
+#pragma unroll
+        for (int s = 0; s < LPT; s++) p[s].set_shared(ptab);
     }
-    // Persistent over lane blocks: workgroup w walks the 256-lane blocks w, w + grid, w + 2 grid, ... one after the
-    // other (state load, the whole frame walk, state store per block).  The launcher sizes the grid so that every CU
-    // holds the number of workgroups that was measured fastest instead of whatever lanes / 256 happens to be.
-    const size_t nblocks = lanes / kFmBlock;  // lanes % 256 == 0 (launcher)
+    // Persistent over lane blocks: workgroup w walks the (256 LPT)-lane blocks w, w + grid, w + 2 grid, ... one after
+    // the other (state load, the whole frame walk, state store per block).
+    constexpr size_t kBlockLanes = size_t(kFmBlock) * LPT;
+    const size_t nblocks = lanes / kBlockLanes;  // lanes % (256 LPT) == 0 (launcher)
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const size_t lane0 = blk * kFmBlock;
-    const size_t lane = lane0 + tid;
-    p.load(prm, st, lanes, lane);
+    const size_t lane0 = blk * kBlockLanes;
+#pragma unroll
+    for (int s = 0; s < LPT; s++) p[s].load(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
 
-    const size_t ntiles = (frames + T - 1) / T;
-    auto rows_of = [&](size_t tile) { return int(frames - tile * T < size_t(T) ? frames - tile * T : size_t(T)); };
-    auto issue = [&](size_t tile, auto full) {
+    const size_t ntiles = ((frames + T - 1) / T) * LPT;  // virtual tiles
+    const size_t nfull = (frames / T) * LPT;             // virtual tiles [0, nfull) have all T rows
+    auto rows_of = [&](size_t v) {
+        const size_t f0 = (v / LPT) * T;
+        return int(frames - f0 < size_t(T) ? frames - f0 : size_t(T));
+    };
+    auto issue = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const int slot = int(tile % NB), nr = FULL ? T : rows_of(tile);
+        const int slot = int(v % NB), nr = FULL ? T : rows_of(v);
+        const size_t f0 = (v / LPT) * T, l0 = lane0 + (v % LPT) * kFmBlock;
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
             const int r = wave + 4 * j;
-            if (FULL || r < nr) glds16(x + (tile * T + r) * xl + lane0 + lid * 4, lds_base + uint32_t((slot * T + r) * kFmBlock * 4));
+            if (FULL || r < nr) glds16(x + (f0 + r) * xl + l0 + lid * 4, lds_base + uint32_t((slot * T + r) * kFmBlock * 4));
         }
     };
-    auto store = [&](size_t tile, auto full) {
+    auto store = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const uint32_t *o = tout + (tile & 1) * T * kFmBlock * OW;
-        const int nr = FULL ? T : rows_of(tile);
+        const uint32_t *o = tout + (v & 1) * T * kFmBlock * OW;
+        const int nr = FULL ? T : rows_of(v);
+        const size_t f0 = (v / LPT) * T, l0 = lane0 + (v % LPT) * kFmBlock;
         uint32_t *yw = reinterpret_cast<uint32_t *>(y);
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
@@ -359,17 +381,18 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
             if (FULL || r < nr) {
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(o + (r * OW + h) * kFmBlock + lid * 4);
-                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(yw + ((tile * T + r) * yl + lane0) * OW + h * kFmBlock + lid * 4));
+                    const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (r * OW + h) * kFmBlock + lid * 4);
+                    __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(yw + ((f0 + r) * yl + l0) * OW + h * kFmBlock + lid * 4));
                 }
             }
         }
     };
-    auto compute = [&](size_t tile, auto full) {
+    auto compute = [&](size_t v, auto sub, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const uint32_t *in = tin + (tile % NB) * T * kFmBlock;
-        uint32_t *o = tout + (tile & 1) * T * kFmBlock * OW;
-        const int nr = FULL ? T : rows_of(tile);
+        P &q = p[decltype(sub)::value];  // static index: the LPT states stay in registers
+        const uint32_t *in = tin + (v % NB) * T * kFmBlock;
+        uint32_t *o = tout + (v & 1) * T * kFmBlock * OW;
+        const int nr = FULL ? T : rows_of(v);
 #pragma unroll
         for (int r0 = 0; r0 < T; r0 += B) {
             if (!FULL && r0 >= nr) break;
@@ -377,14 +400,14 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
                 typename P::Pre pre[B];
 #pragma unroll
                 for (int b = 0; b < B; b++)
-                    if (FULL || r0 + b < nr) pre[b] = p.pre(prm);
+                    if (FULL || r0 + b < nr) pre[b] = q.pre(prm);
 #pragma unroll
                 for (int b = 0; b < B; b++) {
                     const int r = r0 + b;
-                    if (FULL || r < nr) to_words<Out>(p.step(prm, __builtin_bit_cast(In, in[r * kFmBlock + tid]), pre[b]), o + (r * kFmBlock + tid) * OW);
+                    if (FULL || r < nr) to_words<Out>(q.step(prm, __builtin_bit_cast(In, in[r * kFmBlock + tid]), pre[b]), o + (r * kFmBlock + tid) * OW);
                 }
             } else {
-                to_words<Out>(p.step(prm, __builtin_bit_cast(In, in[r0 * kFmBlock + tid])), o + (r0 * kFmBlock + tid) * OW);
+                to_words<Out>(q.step(prm, __builtin_bit_cast(In, in[r0 * kFmBlock + tid])), o + (r0 * kFmBlock + tid) * OW);
             }
         }
     };
@@ -392,28 +415,36 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     using Full = std::true_type;
     using Ragged = std::false_type;
     for (size_t t = 0; t < size_t(NB) && t < ntiles; t++) issue(t, Ragged{});
-    size_t i = 0;
-    auto slow_iter = [&]() {  // start-up, drain and ragged tiles: wait for everything
-        wait_vmcnt<0>();
-        lds_barrier();
-        compute(i, Ragged{});
-        lds_barrier();
-        if (i + NB < ntiles) issue(i + NB, Ragged{});
-        store(i, Ragged{});
+    size_t i = 0;  // first virtual tile of the current group of LPT (sub-blocks 0 .. LPT-1 of one row group)
+    auto slow_group = [&]() {  // start-up, drain and ragged tiles: wait for everything
+        static_for<LPT>([&](auto sub) {
+            const size_t v = i + decltype(sub)::value;
+            wait_vmcnt<0>();
+            lds_barrier();
+            compute(v, sub, Ragged{});
+            lds_barrier();
+            if (v + NB < ntiles) issue(v + NB, Ragged{});
+            store(v, Ragged{});
+        });
     };
-    for (; i < ntiles && i < size_t(NB); i++) slow_iter();
+    constexpr size_t kStart = size_t((NB + LPT - 1) / LPT) * LPT;
+    for (; i < ntiles && i < kStart; i += LPT) slow_group();
     // steady state: all tiles involved are full, and every wave has issued exactly RPW loads
     // and RPW*OW stores per past tile, so kYoung younger operations may stay in flight
-    for (; i + NB + 1 < ntiles; i++) {
-        wait_vmcnt<kYoung>();
-        lds_barrier();  // all four waves' rows of tile i have landed
-        compute(i, Full{});
-        lds_barrier();  // out tile complete; ring slot i % NB is free again
-        issue(i + NB, Full{});
-        store(i, Full{});
+    for (; i + (LPT - 1) + NB < nfull; i += LPT) {
+        static_for<LPT>([&](auto sub) {
+            const size_t v = i + decltype(sub)::value;
+            wait_vmcnt<kYoung>();
+            lds_barrier();  // all four waves' rows of tile v have landed
+            compute(v, sub, Full{});
+            lds_barrier();  // out tile complete; ring slot v % NB is free again
+            issue(v + NB, Full{});
+            store(v, Full{});
+        });
     }
-    for (; i < ntiles; i++) slow_iter();
-    p.store(prm, st, lanes, lane);
+    for (; i < ntiles; i += LPT) slow_group();
+#pragma unroll
+    for (int s = 0; s < LPT; s++) p[s].store(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
     // No barrier needed here: the next block's first lds_barrier() (after each wave's lgkmcnt wait) orders this
     // block's last output-tile reads before the compute() that overwrites the tile, and its first DMA rows only
     // touch input slots whose last readers passed the barrier after the final compute().
