@@ -274,8 +274,18 @@ constexpr int kLdsT = 8;    // frames per tile
 // a lucky offset from x.  The clamp / wide / multi-section processors are the other way round (8 tiles 0.35-0.40 ms by
 // placement, 7 or fewer a flat 0.41-0.46 ms), so only DF1 i32, dither and f32 DF2T without clamp take 7.
 constexpr int kLdsNB = 8;
-// Largest grid of the LDS-DMA kernel; launches with more 256-lane blocks walk them persistently (0 = never).
-constexpr size_t kLdsGridCap = 512;
+// Largest non-persistent grid of the LDS-DMA kernel; launches with more workgroups walk their lane blocks persistently.
+constexpr size_t kLdsGridCap = 384;
+// Largest lanes-per-thread factor the LDS-DMA kernel is instantiated with for a processor (P::LDS_LPT_MAX; 1 = only
+// the one-lane-per-thread form).  Each step doubles the processor's state registers.
+template <class P, class = void>
+struct LdsLptMaxOf {
+    static constexpr int value = 1;
+};
+template <class P>
+struct LdsLptMaxOf<P, std::void_t<decltype(P::LDS_LPT_MAX)>> {
+    static constexpr int value = P::LDS_LPT_MAX;
+};
 template <class P, class = void>
 struct LdsRingOf {
     static constexpr int value = kLdsNB;
@@ -310,11 +320,14 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// LPT ("lanes per thread") > 1: a workgroup owns 256 * LPT adjacent lanes; thread t runs the LPT independent
-// recurrences of lanes t, t + 256, ... and the tile sequence interleaves them: virtual tile v = row group v / LPT
-// (T frames) of sub-block v % LPT.  Tile size, ring bytes, barriers per sample and the vmcnt bookkeeping are those of
-// LPT = 1; what changes is that a launch of L lanes needs L / (256 LPT) workgroups — the launcher picks LPT so that
-// large launches still run as ~256 workgroups (one per CU) sweeping whole rows, the regime C2 is fast in.
+// LPT ("lanes per thread") > 1: a workgroup owns 256 * LPT adjacent lanes and thread t runs the LPT independent
+// recurrences of lanes t, t + 256, ...  A tile is still TS one-KiB row segments (8 KiB; 16 KiB for LPT = 16) —
+// frames [v R, v R + R) x all LPT sub-blocks, R = TS / LPT — so ring bytes, barriers per sample and the vmcnt
+// bookkeeping are those of LPT = 1, and every workgroup sweeps whole (LPT KiB) row pieces in address order.  What
+// changes is that a launch of L lanes needs only L / (256 LPT) workgroups: the launcher picks LPT so that launches
+// of 2^17 .. 2^18 lanes still run as 256 workgroups, one per CU — measured (tools/exp_c5.hip,
+// profiles/r02_exp_c5_*.jsonl, i32 DF1 x 4096 frames): 131072 lanes 0.65 (512 workgroups) / 0.70 (256 persistent
+// workgroups, two column panels) -> 0.76-0.77 with LPT 2; 262144 lanes 0.66 -> 0.72 with LPT 4.
 template <class P, int NB = LdsRingOf<P>::value, int LPT = 1>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
@@ -324,16 +337,18 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     using Out = typename P::Out;
     static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4, "LDS path: one 4-byte input per lane and frame");
     static_assert(LPT >= 1 && (LPT & (LPT - 1)) == 0, "LPT is a power of two");
-    constexpr int T = kLdsT, OW = sizeof(Out) / 4, B = BatchOf<P>::value;
-    constexpr int RPW = T / 4;  // rows per wave and tile
+    constexpr int OW = sizeof(Out) / 4, B = BatchOf<P>::value;
+    constexpr int TS = LPT > kLdsT ? LPT : kLdsT;  // 1 KiB row segments per tile
+    constexpr int R = TS / LPT;                    // frames per tile
+    constexpr int RPW = TS / 4;                    // segments per wave and tile
     constexpr int kYoung = RPW * OW + (NB - 1) * (RPW + RPW * OW);
-    static_assert(kYoung <= 63 && T % 4 == 0 && T % B == 0, "vmcnt range / tile shape");
+    static_assert(kYoung <= 63 && TS % 4 == 0 && (LPT > 1 ? B == 1 : R % B == 0), "vmcnt range / tile shape");
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *tin = smem;                              // [NB][T][256]
-    uint32_t *tout = smem + NB * T * kFmBlock;         // [2][T][256 * OW]
-    uint32_t *ptab = tout + 2 * T * kFmBlock * OW;     // [P::LDS_WORDS]
+    uint32_t *tin = smem;                               // [NB][TS][256]
+    uint32_t *tout = smem + NB * TS * kFmBlock;         // [2][TS][256 * OW]
+    uint32_t *ptab = tout + 2 * TS * kFmBlock * OW;     // [P::LDS_WORDS]
     const int tid = threadIdx.x, lid = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem;
@@ -348,101 +363,97 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     // the other (state load, the whole frame walk, state store per block).
     constexpr size_t kBlockLanes = size_t(kFmBlock) * LPT;
     const size_t nblocks = lanes / kBlockLanes;  // lanes % (256 LPT) == 0 (launcher)
+    // (a workgroup that owns ADJACENT blocks instead — blocks [w rounds, (w + 1) rounds) — was measured slower: 0.58 vs
+    // 0.68 of peak at 2^20 lanes, profiles/r02_exp_c5_matrix6.jsonl: the panel order keeps the concurrently active
+    // columns in one contiguous 256 KiB piece of every row)
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const size_t lane0 = blk * kBlockLanes;
 #pragma unroll
     for (int s = 0; s < LPT; s++) p[s].load(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
 
-    const size_t ntiles = ((frames + T - 1) / T) * LPT;  // virtual tiles
-    const size_t nfull = (frames / T) * LPT;             // virtual tiles [0, nfull) have all T rows
-    auto rows_of = [&](size_t v) {
-        const size_t f0 = (v / LPT) * T;
-        return int(frames - f0 < size_t(T) ? frames - f0 : size_t(T));
-    };
+    const size_t ntiles = (frames + R - 1) / R;
+    const size_t nfull = frames / R;  // tiles [0, nfull) have all their rows
+    // segment g of a tile = frame g / LPT of the tile, sub-block g % LPT; a ragged tile holds nseg(v) segments
+    auto nseg = [&](size_t v) { return int((frames - v * R < size_t(R) ? frames - v * R : size_t(R)) * LPT); };
     auto issue = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const int slot = int(v % NB), nr = FULL ? T : rows_of(v);
-        const size_t f0 = (v / LPT) * T, l0 = lane0 + (v % LPT) * kFmBlock;
+        const int slot = int(v % NB), ns = FULL ? TS : nseg(v);
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
-            const int r = wave + 4 * j;
-            if (FULL || r < nr) glds16(x + (f0 + r) * xl + l0 + lid * 4, lds_base + uint32_t((slot * T + r) * kFmBlock * 4));
+            const int g = wave + 4 * j;
+            if (FULL || g < ns)
+                glds16(x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid * 4, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
         }
     };
     auto store = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const uint32_t *o = tout + (v & 1) * T * kFmBlock * OW;
-        const int nr = FULL ? T : rows_of(v);
-        const size_t f0 = (v / LPT) * T, l0 = lane0 + (v % LPT) * kFmBlock;
+        const uint32_t *o = tout + (v & 1) * TS * kFmBlock * OW;
+        const int ns = FULL ? TS : nseg(v);
         uint32_t *yw = reinterpret_cast<uint32_t *>(y);
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
-            const int r = wave + 4 * j;
-            if (FULL || r < nr) {
+            const int g = wave + 4 * j;
+            if (FULL || g < ns) {
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
-                    const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (r * OW + h) * kFmBlock + lid * 4);
-                    __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(yw + ((f0 + r) * yl + l0) * OW + h * kFmBlock + lid * 4));
+                    const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid * 4);
+                    __builtin_nontemporal_store(
+                        v4, reinterpret_cast<u32x4 *>(yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid * 4));
                 }
             }
         }
     };
-    auto compute = [&](size_t v, auto sub, auto full) {
+    auto compute = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        P &q = p[decltype(sub)::value];  // static index: the LPT states stay in registers
-        const uint32_t *in = tin + (v % NB) * T * kFmBlock;
-        uint32_t *o = tout + (v & 1) * T * kFmBlock * OW;
-        const int nr = FULL ? T : rows_of(v);
+        const uint32_t *in = tin + (v % NB) * TS * kFmBlock;
+        uint32_t *o = tout + (v & 1) * TS * kFmBlock * OW;
+        const int ns = FULL ? TS : nseg(v);
+        if constexpr (B > 1) {  // LPT == 1: segments are consecutive frames of one lane
 #pragma unroll
-        for (int r0 = 0; r0 < T; r0 += B) {
-            if (!FULL && r0 >= nr) break;
-            if constexpr (B > 1) {
+            for (int r0 = 0; r0 < TS; r0 += B) {
+                if (!FULL && r0 >= ns) break;
                 typename P::Pre pre[B];
 #pragma unroll
                 for (int b = 0; b < B; b++)
-                    if (FULL || r0 + b < nr) pre[b] = q.pre(prm);
+                    if (FULL || r0 + b < ns) pre[b] = p[0].pre(prm);
 #pragma unroll
                 for (int b = 0; b < B; b++) {
                     const int r = r0 + b;
-                    if (FULL || r < nr) to_words<Out>(q.step(prm, __builtin_bit_cast(In, in[r * kFmBlock + tid]), pre[b]), o + (r * kFmBlock + tid) * OW);
+                    if (FULL || r < ns) to_words<Out>(p[0].step(prm, __builtin_bit_cast(In, in[r * kFmBlock + tid]), pre[b]), o + (r * kFmBlock + tid) * OW);
                 }
-            } else {
-                to_words<Out>(q.step(prm, __builtin_bit_cast(In, in[r0 * kFmBlock + tid])), o + (r0 * kFmBlock + tid) * OW);
             }
+        } else {
+            static_for<TS>([&](auto gg) {
+                constexpr int g = decltype(gg)::value;  // static: the LPT states stay in registers
+                if (FULL || g < ns) to_words<Out>(p[g % LPT].step(prm, __builtin_bit_cast(In, in[g * kFmBlock + tid])), o + (g * kFmBlock + tid) * OW);
+            });
         }
     };
 
     using Full = std::true_type;
     using Ragged = std::false_type;
     for (size_t t = 0; t < size_t(NB) && t < ntiles; t++) issue(t, Ragged{});
-    size_t i = 0;  // first virtual tile of the current group of LPT (sub-blocks 0 .. LPT-1 of one row group)
-    auto slow_group = [&]() {  // start-up, drain and ragged tiles: wait for everything
-        static_for<LPT>([&](auto sub) {
-            const size_t v = i + decltype(sub)::value;
-            wait_vmcnt<0>();
-            lds_barrier();
-            compute(v, sub, Ragged{});
-            lds_barrier();
-            if (v + NB < ntiles) issue(v + NB, Ragged{});
-            store(v, Ragged{});
-        });
+    size_t i = 0;
+    auto slow_iter = [&]() {  // start-up, drain and ragged tiles: wait for everything
+        wait_vmcnt<0>();
+        lds_barrier();
+        compute(i, Ragged{});
+        lds_barrier();
+        if (i + NB < ntiles) issue(i + NB, Ragged{});
+        store(i, Ragged{});
     };
-    constexpr size_t kStart = size_t((NB + LPT - 1) / LPT) * LPT;
-    for (; i < ntiles && i < kStart; i += LPT) slow_group();
+    for (; i < ntiles && i < size_t(NB); i++) slow_iter();
     // steady state: all tiles involved are full, and every wave has issued exactly RPW loads
     // and RPW*OW stores per past tile, so kYoung younger operations may stay in flight
-    for (; i + (LPT - 1) + NB < nfull; i += LPT) {
-        static_for<LPT>([&](auto sub) {
-            const size_t v = i + decltype(sub)::value;
-            wait_vmcnt<kYoung>();
-            lds_barrier();  // all four waves' rows of tile v have landed
-            compute(v, sub, Full{});
-            lds_barrier();  // out tile complete; ring slot v % NB is free again
-            issue(v + NB, Full{});
-            store(v, Full{});
-        });
+    for (; i + NB < nfull; i++) {
+        wait_vmcnt<kYoung>();
+        lds_barrier();  // all four waves' segments of tile i have landed
+        compute(i, Full{});
+        lds_barrier();  // out tile complete; ring slot i % NB is free again
+        issue(i + NB, Full{});
+        store(i, Full{});
     }
-    for (; i < ntiles; i += LPT) slow_group();
+    for (; i < ntiles; i++) slow_iter();
 #pragma unroll
     for (int s = 0; s < LPT; s++) p[s].store(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
     // No barrier needed here: the next block's first lds_barrier() (after each wave's lgkmcnt wait) orders this
@@ -626,16 +637,56 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             constexpr size_t ow = sizeof(typename P::Out) / 4;
             if (!no_lds && P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 &&
                 reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && (yl * ow) % 4 == 0) {
-                constexpr size_t bytes = (size_t(LdsRingOf<P>::value) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
-                if (int rc = ensure_dyn_lds(stream_frame_major_lds<P>, bytes)) return rc;
-                // Grid: one workgroup per 256-lane block while they are all resident at once (2 per CU by LDS);
-                // beyond that a persistent grid walks the blocks (IDSP_DIAG=1 IDSP_LDS_GRID overrides the cap).
-                static const size_t grid_cap = diag_size("IDSP_LDS_GRID", kLdsGridCap);
+                // Lanes per thread and grid (profiles/r02_exp_c5_*.jsonl).  Fastest regime: ~256 workgroups, one per CU,
+                // each sweeping whole row pieces -> 2 or 4 lanes per thread when that gives 224..320 workgroups (the
+                // processor must have the form, P::LDS_LPT_MAX, and the lanes must divide).  Launches beyond that run
+                // one lane per thread on a persistent grid of <= 256 workgroups that walks the lane blocks in column
+                // panels of equal rounds (2^20 lanes: 0.68 of peak against 0.64 with 4096 workgroups, 0.615 on the
+                // register-window kernel, 0.49-0.59 with 2 / 4 lanes per thread on a persistent grid).
+                // IDSP_DIAG=1 IDSP_LDS_LPT / IDSP_LDS_GRID override both.
+                static const size_t forced_lpt = diag_size("IDSP_LDS_LPT", 0);
+                static const size_t forced_grid = diag_size("IDSP_LDS_GRID", ~size_t(0));
                 const size_t nblocks = lanes / kFmBlock;
-                const size_t grid = grid_cap && nblocks > grid_cap ? grid_cap : nblocks;
-                note_kernel("stream_frame_major_lds", typeid(P).name());
-                hipLaunchKernelGGL((stream_frame_major_lds<P>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s,
-                                   prm, st, x, y, lanes, frames, xl, yl);
+                constexpr int kMaxLpt = LdsLptMaxOf<P>::value;
+                int lpt = 1;
+                if (forced_lpt) {
+                    lpt = int(forced_lpt) > kMaxLpt ? kMaxLpt : int(forced_lpt);
+                    while (lpt > 1 && nblocks % size_t(lpt) != 0) lpt >>= 1;
+                } else {
+                    for (int c = kMaxLpt; c > 1; c >>= 1)
+                        if (nblocks % size_t(c) == 0 && nblocks / size_t(c) >= 224 && nblocks / size_t(c) <= 320) {
+                            lpt = c;
+                            break;
+                        }
+                }
+                const size_t wgs = nblocks / size_t(lpt);
+                size_t grid = wgs;
+                if (forced_grid != ~size_t(0)) {
+                    if (forced_grid && wgs > forced_grid) grid = forced_grid;
+                } else if (wgs > kLdsGridCap) {
+                    const size_t rounds = (wgs + 255) / 256;
+                    grid = (wgs + rounds - 1) / rounds;
+                }
+                int rc = IDSP_OK;
+                auto go = [&](auto lpt_tag) {
+                    constexpr int L = decltype(lpt_tag)::value;
+                    constexpr int NB = LdsRingOf<P>::value;
+                    constexpr size_t ts = L > kLdsT ? L : kLdsT;
+                    constexpr size_t bytes = (size_t(NB) * ts * kFmBlock + 2 * ts * kFmBlock * ow + P::LDS_WORDS) * 4;
+                    if ((rc = ensure_dyn_lds(stream_frame_major_lds<P, NB, L>, bytes))) return;
+                    note_kernel(L == 1 ? "stream_frame_major_lds" : L == 2 ? "stream_frame_major_lds[2 lanes/thread]" : "stream_frame_major_lds[4 lanes/thread]",
+                                typeid(P).name());
+                    hipLaunchKernelGGL((stream_frame_major_lds<P, NB, L>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s,
+                                       prm, st, x, y, lanes, frames, xl, yl);
+                };
+                if constexpr (kMaxLpt >= 4) {
+                    if (lpt == 4) go(std::integral_constant<int, 4>{});
+                }
+                if constexpr (kMaxLpt >= 2) {
+                    if (lpt == 2) go(std::integral_constant<int, 2>{});
+                }
+                if (lpt == 1) go(std::integral_constant<int, 1>{});
+                if (rc) return rc;
                 return launch_status();
             }
         }

@@ -317,3 +317,125 @@ def test_cic_decimator_into_hbf_16384_lanes(eng):
     assert eng.cfgcall("cic_dec_i64", cfg, std, up, down, lanes, 64, FM) == 0
     torch.cuda.synchronize()
     assert torch.equal(down[-1], dc[0] * (R ** 6))
+
+
+def _subset(lanes, step):
+    return np.unique(np.concatenate([np.arange(0, lanes, step), [0, 1, 255, 256, lanes - 257, lanes - 1]]))
+
+
+C2_VARIANTS = [
+    # op, state words, dtype, clamp record?  (the processors DESIGN section 5 quotes C2-shape throughput for)
+    ("biquad_i32_df1_clamp", 4, np.int32, True),
+    ("biquad_i32_dither", 5, np.int32, False),
+    ("biquad_i32_dither_clamp", 5, np.int32, True),
+    ("biquad_i32_wide", 6, np.int32, False),
+    ("biquad_i32_wide_clamp", 6, np.int32, True),
+    ("biquad_f32_df1", 4, np.float32, False),
+    ("biquad_f32_df1_clamp", 4, np.float32, True),
+    ("biquad_f32_df2t_clamp", 2, np.float32, True),
+]
+
+
+@pytest.mark.parametrize("op,words,dtype,clamp", C2_VARIANTS, ids=[v[0] for v in C2_VARIANTS])
+def test_c2_shape_variants_on_default_dispatch(eng, op, words, dtype, clamp):
+    """65536 lanes x 4096 frames, FRAME_MAJOR, default dispatch (= the LDS-DMA kernel, asserted): every clamp / dither /
+    wide / f32 variant against the oracle on a lane subset, outputs and written-back state; clamp limits chosen so
+    that they bite (the lowpass output of +-2^24 inputs exceeds +-2^22)."""
+    lanes, frames = 65536, 4096
+    o = H.oracle()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    if dtype == np.int32:
+        q = lowpass_i32()[0]
+        cfg = H.biquad_clamp_i32([(list(q.ba), 30, 1234, -(1 << 22), (1 << 22) + 5)]) if clamp else H.biquad_i32([(list(q.ba), 30)])
+        x = torch.randint(-(1 << 24), 1 << 24, (frames, lanes), dtype=torch.int32, device=DEV, generator=g)
+    else:
+        q = _abi.BiquadF32()
+        assert o.fn["biquad_f32_from_sos_f64"]((C.c_double * 6)(*o.lowpass_sos(0.01)), C.byref(q)) == 0
+        cfg = H.biquad_clamp_f32([(list(q.ba), 0.01, -0.05, 0.04)]) if clamp else H.biquad_f32([list(q.ba)])
+        x = torch.randn((frames, lanes), dtype=torch.float32, device=DEV, generator=g)
+    y = torch.empty_like(x)
+    st = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)
+    assert eng.stream(op, cfg, 1, st, x, y, lanes, frames, FM) == 0
+    torch.cuda.synchronize()
+    assert eng.fn["last_kernel"]().decode().startswith("stream_frame_major_lds<"), eng.fn["last_kernel"]()
+    idx = _subset(lanes, 509)
+    tidx = torch.from_numpy(idx).to(DEV)
+    xs = np.ascontiguousarray(x[:, tidx].cpu().numpy())
+    ys = np.empty_like(xs)
+    ss = np.zeros((words, idx.size), np.uint32)
+    assert o.stream(op, cfg, 1, ss, xs, ys, idx.size, frames, FM) == 0
+    got = y[:, tidx].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ys.view(np.uint32))
+    assert np.array_equal(st[:, tidx].cpu().numpy().view(np.uint32), ss)
+    if clamp and dtype == np.int32:
+        assert (got == (1 << 22) + 5).any() and (got == -(1 << 22)).any(), "the clamp must be active in this test"
+    # in place at full width gives the same bits
+    st2 = torch.zeros_like(st)
+    assert eng.stream(op, cfg, 1, st2, x, x, lanes, frames, FM) == 0
+    assert torch.equal(x.view(torch.int32), y.view(torch.int32)) and torch.equal(st, st2)
+
+
+@pytest.mark.parametrize("lanes,want", [(131072, "stream_frame_major_lds[2 lanes/thread]<"), (262144, "stream_frame_major_lds[4 lanes/thread]<"),
+                                        (327680, "stream_frame_major_lds<")])
+def test_large_lane_counts_on_default_dispatch(eng, lanes, want):
+    """Beyond 65536 lanes the LDS-DMA kernel runs 2 or 4 lanes per thread, or one lane per thread on a persistent grid
+    (C5 shards at 8 / 4 GPUs; 327680 lanes = 1280 blocks -> 5 rounds of 256 workgroups): i32 DF1 and f32 DF2T against
+    the oracle on a lane subset, ragged frame count (odd: the 4-lane form packs 2 frames per tile), chunked == whole."""
+    frames = 1003
+    o = H.oracle()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(22)
+    q = _abi.BiquadF32()
+    assert o.fn["biquad_f32_from_sos_f64"]((C.c_double * 6)(*o.lowpass_sos(0.01)), C.byref(q)) == 0
+    cases = [("biquad_i32_df1", lowpass_i32(), 4, torch.randint(-(1 << 24), 1 << 24, (frames, lanes), dtype=torch.int32, device=DEV, generator=g)),
+             ("biquad_f32_df2t", (_abi.BiquadF32 * 1)(q), 2, torch.randn((frames, lanes), dtype=torch.float32, device=DEV, generator=g))]
+    for op, cfg, words, x in cases:
+        y = torch.empty_like(x)
+        st = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)
+        assert eng.stream(op, cfg, 1, st, x, y, lanes, frames, FM) == 0
+        torch.cuda.synchronize()
+        assert eng.fn["last_kernel"]().decode().startswith(want), eng.fn["last_kernel"]()
+        idx = _subset(lanes, 1021)
+        tidx = torch.from_numpy(idx).to(DEV)
+        xs = np.ascontiguousarray(x[:, tidx].cpu().numpy())
+        ys = np.empty_like(xs)
+        ss = np.zeros((words, idx.size), np.uint32)
+        assert o.stream(op, cfg, 1, ss, xs, ys, idx.size, frames, FM) == 0
+        assert np.array_equal(y[:, tidx].cpu().numpy().view(np.uint32), ys.view(np.uint32)), op
+        assert np.array_equal(st[:, tidx].cpu().numpy().view(np.uint32), ss), op
+        y2 = torch.empty_like(x)
+        st2 = torch.zeros_like(st)
+        for a, b in ((0, 1), (1, 502), (502, frames)):
+            assert eng.stream(op, cfg, 1, st2, x[a:b], y2[a:b], lanes, b - a, FM) == 0
+        assert torch.equal(y.view(torch.int32), y2.view(torch.int32)) and torch.equal(st, st2), op
+
+
+def test_c1_single_lane_one_million_samples(eng):
+    """BASELINE.json configs[0] ("C1"): ONE lane, 2^20 samples, i32 DF1, seed 1 — the reference's plain
+    `SplitProcess::block` / `SplitInplace::inplace` plumbing (dsp-process/src/process.rs:122-127,137-141) with no lane
+    parallelism at all.  HIP == oracle bit for bit, out of place, in place and in ragged chunks; both layouts (they
+    coincide for one lane)."""
+    frames = 1 << 20
+    o = H.oracle()
+    cfg = lowpass_i32()
+    x = np.random.default_rng(1).integers(-(1 << 24), 1 << 24, frames, dtype=np.int32)
+    want = np.empty_like(x)
+    sw = np.zeros((4, 1), np.uint32)
+    assert o.stream("biquad_i32_df1", cfg, 1, sw, x, want, 1, frames, FM) == 0
+    xd = torch.from_numpy(x).to(DEV)
+    for layout in (FM, LM):
+        y = torch.empty_like(xd)
+        st = torch.zeros((4, 1), dtype=torch.int32, device=DEV)
+        assert eng.stream("biquad_i32_df1", cfg, 1, st, xd, y, 1, frames, layout) == 0
+        assert np.array_equal(y.cpu().numpy(), want) and np.array_equal(st.cpu().numpy().view(np.uint32), sw)
+    xi = xd.clone()
+    st = torch.zeros((4, 1), dtype=torch.int32, device=DEV)
+    assert eng.stream("biquad_i32_df1", cfg, 1, st, xi, xi, 1, frames, FM) == 0
+    assert np.array_equal(xi.cpu().numpy(), want)
+    y = torch.empty_like(xd)
+    st = torch.zeros((4, 1), dtype=torch.int32, device=DEV)
+    cuts = [0, 1, 63, 64, 4097, 500000, frames]
+    for a, b in zip(cuts, cuts[1:]):
+        assert eng.stream("biquad_i32_df1", cfg, 1, st, xd[a:b], y[a:b], 1, b - a, LM) == 0
+    assert np.array_equal(y.cpu().numpy(), want) and np.array_equal(st.cpu().numpy().view(np.uint32), sw)

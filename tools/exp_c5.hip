@@ -19,13 +19,15 @@ void note_kernel(const char *, const char *) {}
 
 using namespace idsp;
 using P = bq::Chain<bq::Df1I32<false>, 1>;
+static int g_adj = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int NB, int LPT = 1>
-float run(const P::Params &prm, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, size_t pitch, unsigned grid, int iters)
+float run(const P::Params &prm, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, size_t pitch, unsigned grid, int iters, int adj = 0)
 {
-    constexpr size_t bytes = (size_t(NB) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock) * 4;
+    constexpr size_t kSeg = (LPT > kLdsT) ? LPT : kLdsT;
+    constexpr size_t bytes = (size_t(NB) * kSeg * kFmBlock + 2 * kSeg * kFmBlock) * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_lds<P, NB, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
@@ -53,6 +55,7 @@ int main(int argc, char **argv)
     const bool inplace = argc > 6 && atoi(argv[6]);
     const size_t yoff = argc > 7 ? atoll(argv[7]) : 0;
     const int lpt = argc > 8 ? atoi(argv[8]) : 1;
+    g_adj = argc > 9 ? atoi(argv[9]) : 0;
     if (!pitch) pitch = lanes;
     if (!grid) grid = unsigned(lanes / kFmBlock / lpt);
     const size_t n = pitch * frames;
@@ -87,10 +90,15 @@ int main(int argc, char **argv)
         case 6: ms = run<6>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
         case 7: ms = run<7>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
         case 8: ms = run<8>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
+        case 9: ms = run<9>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
+        case 10: ms = run<10>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
+        case 11: ms = run<11>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
+        case 12: ms = run<12>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
+        case 14: ms = run<14>(prm, st, x, y, lanes, frames, pitch, grid, 20); break;
         default: printf("NB 3..8\n"); return 1;
     }
     const double gbs = double(lanes) * frames * 8 / (ms * 1e-3) / 1e9;
-    printf("{\"lanes\": %zu, \"frames\": %zu, \"pitch\": %zu, \"grid\": %u, \"nb\": %d, \"inplace\": %d, \"yoff\": %zu, \"lpt\": %d, \"ms\": %.4f, \"GB/s\": %.0f, \"frac\": %.3f}\n",
-           lanes, frames, pitch, grid, nb, int(inplace), yoff, lpt, ms, gbs, gbs / 8000);
+    printf("{\"lanes\": %zu, \"frames\": %zu, \"pitch\": %zu, \"grid\": %u, \"nb\": %d, \"inplace\": %d, \"yoff\": %zu, \"lpt\": %d, \"adj\": %d, \"ms\": %.4f, \"GB/s\": %.0f, \"frac\": %.3f}\n",
+           lanes, frames, pitch, grid, nb, int(inplace), yoff, lpt, g_adj, ms, gbs, gbs / 8000);
     return 0;
 }
