@@ -377,10 +377,10 @@ def test_c2_shape_variants_on_default_dispatch(eng, op, words, dtype, clamp):
 
 
 @pytest.mark.parametrize("lanes,want", [(131072, "stream_frame_major_lds[2 lanes/thread]<"), (262144, "stream_frame_major_lds[4 lanes/thread]<"),
-                                        (327680, "stream_frame_major_lds<")])
+                                        (393216, "stream_frame_major_lds<")])
 def test_large_lane_counts_on_default_dispatch(eng, lanes, want):
     """Beyond 65536 lanes the LDS-DMA kernel runs 2 or 4 lanes per thread, or one lane per thread on a persistent grid
-    (C5 shards at 8 / 4 GPUs; 327680 lanes = 1280 blocks -> 5 rounds of 256 workgroups): i32 DF1 and f32 DF2T against
+    (C5 shards at 8 / 4 GPUs; 393216 lanes = 1536 blocks -> 6 rounds of 256 workgroups): i32 DF1 and f32 DF2T against
     the oracle on a lane subset, ragged frame count (odd: the 4-lane form packs 2 frames per tile), chunked == whole."""
     frames = 1003
     o = H.oracle()
