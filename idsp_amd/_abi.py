@@ -180,6 +180,16 @@ PROCESSING = {
     "fm_disc_i32": _CFG_SIG,
 }
 
+# `<entry>_pitch` twins (product only: explicit x / y row pitches after the x and y pointers)
+def _pitched(sig):
+    sig = list(sig)
+    i = len(sig) - 6  # ..., x, y, lanes, frames, layout, stream
+    return sig[:i + 1] + [_SZ] + [sig[i + 1]] + [_SZ] + sig[i + 2:]
+
+
+PITCHED = {name + "_pitch": _pitched(sig) for name, sig in PROCESSING.items()
+           if name.startswith(("biquad_", "cascade_"))}
+
 # host-side helpers present in both libraries (same signature)
 HELPERS = {
     "biquad_i32_from_sos": (_I, [_P, _I, _P]),
@@ -234,12 +244,28 @@ UTILS = {
     "device_h2d": (_I, [_P, _P, _SZ, _P]),
     "device_d2h": (_I, [_P, _P, _SZ, _P]),
     "stream_sync": (_I, [_P]),
+    # single-process lane split over several devices
+    "multi_create": (_I, [_P, _I, C.POINTER(_P)]),
+    "multi_destroy": (_I, [_P]),
+    "multi_size": (_I, [_P]),
+    "multi_device": (_I, [_P, _I]),
+    "multi_stream": (_P, [_P, _I]),
+    "multi_shard": (_I, [_P, _SZ, _I, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "multi_for_each": (_I, [_P, _SZ, _P, _P]),
+    "multi_sync": (_I, [_P]),
+    "multi_alloc": (_I, [_P, _SZ, _SZ, C.POINTER(_P)]),
+    "multi_free": (_I, [_P, C.POINTER(_P)]),
+    "multi_copy": (_I, [_P, _SZ, _SZ, C.POINTER(_P), _P, _I]),
+    "multi_biquad_i32_df1": (_I, [_P, _P, _SZ, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, _SZ, _I]),
+    "multi_biquad_f32_df2t": (_I, [_P, _P, _SZ, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _SZ, _SZ, _I]),
 }
+
+SHARD_FN = C.CFUNCTYPE(_I, _P, _I, _SZ, _SZ, _P)  # idsp_shard_fn
 
 
 def exported_names() -> list:
     """Every symbol include/idsp_hip.h declares (without the ``idsp_`` prefix)."""
-    return sorted(list(PROCESSING) + list(HELPERS) + list(UTILS) + list(FRONTEND))
+    return sorted(list(PROCESSING) + list(PITCHED) + list(HELPERS) + list(UTILS) + list(FRONTEND))
 
 
 def bind(lib: C.CDLL, prefix: str, *, with_stream: bool, utils: bool):
@@ -256,6 +282,11 @@ def bind(lib: C.CDLL, prefix: str, *, with_stream: bool, utils: bool):
         fn.argtypes = list(args)
         out[name] = fn
     if utils:
+        for name, sig in PITCHED.items():
+            fn = getattr(lib, prefix + name)
+            fn.restype = _I
+            fn.argtypes = list(sig)
+            out[name] = fn
         for name, (res, args) in list(UTILS.items()) + list(FRONTEND.items()):
             fn = getattr(lib, prefix + name)
             fn.restype = res

@@ -10,6 +10,11 @@ using namespace idsp::bq;
                                            size_t lanes, size_t frames, int layout, void *stream)             \
     {                                                                                                         \
         return entry_bylane<sec>(coef, 0, n, state, x, y, lanes, frames, layout, stream);                     \
+    }                                                                                                         \
+    int idsp_biquad_##tn##_##name##_bylane_pitch(const ty *coef, size_t n, void *state, const ty *x, size_t x_pitch, ty *y, \
+                                                 size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream)     \
+    {                                                                                                         \
+        return entry_bylane<sec>(coef, 0, n, state, x, y, lanes, frames, layout, stream, Pitch{x_pitch, y_pitch}); \
     }
 
 extern "C" {

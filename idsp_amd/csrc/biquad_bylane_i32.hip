@@ -10,6 +10,11 @@ using namespace idsp::bq;
                                         int32_t *y, size_t lanes, size_t frames, int layout, void *stream)      \
     {                                                                                                           \
         return entry_bylane<sec>(coef, frac, n, state, x, y, lanes, frames, layout, stream);                    \
+    }                                                                                                           \
+    int idsp_biquad_i32_##name##_bylane_pitch(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, size_t x_pitch, \
+                                              int32_t *y, size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream)      \
+    {                                                                                                           \
+        return entry_bylane<sec>(coef, frac, n, state, x, y, lanes, frames, layout, stream, Pitch{x_pitch, y_pitch}); \
     }
 
 extern "C" {

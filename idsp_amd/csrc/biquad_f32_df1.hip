@@ -18,4 +18,8 @@ int idsp_biquad_f32_df1_clamp(const idsp_biquad_clamp_f32 *cfg, size_t n, void *
     return entry_f32<Df1F32<true>, idsp_biquad_clamp_f32, FillClampF32>(cfg, n, state, x, y, lanes, frames, layout, stream);
 }
 
+// explicit row pitches (include/idsp_hip.h, "_pitch" entries)
+IDSP_PITCH_TWIN(idsp_biquad_f32_df1, idsp_biquad_f32, float, entry_f32, Df1F32<false>, idsp_biquad_f32, FillF32)
+IDSP_PITCH_TWIN(idsp_biquad_f32_df1_clamp, idsp_biquad_clamp_f32, float, entry_f32, Df1F32<true>, idsp_biquad_clamp_f32, FillClampF32)
+
 }  // extern "C"

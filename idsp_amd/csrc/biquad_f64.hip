@@ -38,4 +38,18 @@ int idsp_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, cons
     return run_cascade<double>(FillF64{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 
+// explicit row pitches (include/idsp_hip.h, "_pitch" entries)
+IDSP_PITCH_TWIN(idsp_biquad_f64_df1, idsp_biquad_f64, double, entry_f64, Df1F64<false>, idsp_biquad_f64, FillF64)
+IDSP_PITCH_TWIN(idsp_biquad_f64_df1_clamp, idsp_biquad_clamp_f64, double, entry_f64, Df1F64<true>, idsp_biquad_clamp_f64, FillClampF64)
+IDSP_PITCH_TWIN(idsp_biquad_f64_df2t, idsp_biquad_f64, double, entry_f64, Df2tF64<false>, idsp_biquad_f64, FillF64)
+IDSP_PITCH_TWIN(idsp_biquad_f64_df2t_clamp, idsp_biquad_clamp_f64, double, entry_f64, Df2tF64<true>, idsp_biquad_clamp_f64, FillClampF64)
+
+int idsp_cascade_f64_df1_pitch(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, size_t x_pitch, double *y,
+                               size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream)
+{
+    int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    return run_cascade<double>(FillF64{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream), Pitch{x_pitch, y_pitch});
+}
+
 }  // extern "C"

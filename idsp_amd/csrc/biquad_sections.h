@@ -511,42 +511,63 @@ struct ChainByLane {
 };
 
 // ------------------------------------------------------------ host dispatch
+// Row pitches of the `_pitch` entry points (include/idsp_hip.h): elements between the starts of consecutive lanes
+// (LANE_MAJOR) or consecutive frames (FRAME_MAJOR); 0 = dense.  A pitch must cover a row, and an in-place call must
+// use the same pitch on both sides.
+inline int check_pitch(const void *x, const void *y, size_t lanes, size_t frames, int layout, Pitch pitch)
+{
+    const size_t row = layout == IDSP_LANE_MAJOR ? frames : lanes;
+    if ((pitch.x && pitch.x < row) || (pitch.y && pitch.y < row))
+        return fail(IDSP_EINVAL, "pitch (%zu, %zu) shorter than a row of %zu elements", pitch.x, pitch.y, row);
+    if (x == y && (pitch.x ? pitch.x : row) != (pitch.y ? pitch.y : row))
+        return fail(IDSP_EINVAL, "in-place call with different x and y pitches (%zu, %zu)", pitch.x, pitch.y);
+    return IDSP_OK;
+}
+
+template <class T>
+int copy_through(const T *x, T *y, size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch)
+{
+    if (x == y) return IDSP_OK;
+    const size_t row = layout == IDSP_LANE_MAJOR ? frames : lanes, rows = layout == IDSP_LANE_MAJOR ? lanes : frames;
+    const size_t xp = pitch.x ? pitch.x : row, yp = pitch.y ? pitch.y : row;
+    IDSP_HIP_TRY(hipMemcpy2DAsync(y, yp * sizeof(T), x, xp * sizeof(T), row * sizeof(T), rows, hipMemcpyDeviceToDevice, s));
+    return IDSP_OK;
+}
+
 template <class Sec, int N, class CfgFill>
 int run_chain_n(CfgFill fill, size_t first, void *state, const typename Sec::T *x, typename Sec::T *y,
-                size_t lanes, size_t frames, int layout, hipStream_t s)
+                size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch = {})
 {
     typename Chain<Sec, N>::Params prm;
     for (int k = 0; k < N; k++) fill(prm.sec[k], first + k);
     uint32_t *st = static_cast<uint32_t *>(state) + first * Sec::W * lanes;
-    return launch_stream<Chain<Sec, N>>(prm, st, x, y, lanes, frames, layout, s);
+    return launch_stream<Chain<Sec, N>>(prm, st, x, y, lanes, frames, layout, s, pitch);
 }
 
 // n sections in passes of <= kMaxChain: the first pass reads x, later passes
 // run in place on y — literally the reference's slice composition.
 template <class Sec, class CfgFill>
 int run_chain(CfgFill fill, size_t n, void *state, const typename Sec::T *x, typename Sec::T *y,
-              size_t lanes, size_t frames, int layout, hipStream_t s)
+              size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch = {})
 {
     using T = typename Sec::T;
     if (lanes == 0 || frames == 0) return IDSP_OK;
-    if (n == 0) {  // empty slice: y.copy_from_slice(x), compose.rs:63-65
-        if (x != y) IDSP_HIP_TRY(hipMemcpyAsync(y, x, lanes * frames * sizeof(T), hipMemcpyDeviceToDevice, s));
-        return IDSP_OK;
-    }
+    if (n == 0) return copy_through<T>(x, y, lanes, frames, layout, s, pitch);  // empty slice: y.copy_from_slice(x), compose.rs:63-65
     size_t done = 0;
     const T *src = x;
     while (done < n) {
         const size_t m = n - done < size_t(kMaxChain) ? n - done : size_t(kMaxChain);
         int rc;
         switch (m) {
-            case 1: rc = run_chain_n<Sec, 1>(fill, done, state, src, y, lanes, frames, layout, s); break;
-            case 2: rc = run_chain_n<Sec, 2>(fill, done, state, src, y, lanes, frames, layout, s); break;
-            case 3: rc = run_chain_n<Sec, 3>(fill, done, state, src, y, lanes, frames, layout, s); break;
-            default: rc = run_chain_n<Sec, 4>(fill, done, state, src, y, lanes, frames, layout, s); break;
+            case 1: rc = run_chain_n<Sec, 1>(fill, done, state, src, y, lanes, frames, layout, s, pitch); break;
+            case 2: rc = run_chain_n<Sec, 2>(fill, done, state, src, y, lanes, frames, layout, s, pitch); break;
+            case 3: rc = run_chain_n<Sec, 3>(fill, done, state, src, y, lanes, frames, layout, s, pitch); break;
+            default: rc = run_chain_n<Sec, 4>(fill, done, state, src, y, lanes, frames, layout, s, pitch); break;
         }
         if (rc) return rc;
         done += m;
         src = y;
+        pitch.x = pitch.y;  // later passes run in place on y
     }
     return IDSP_OK;
 }
@@ -563,14 +584,11 @@ constexpr int kMaxChainByLane = 2;  // coefficient registers come on top of the 
 // n per-lane sections in passes of <= kMaxChainByLane (stage-major like run_chain)
 template <class Sec>
 int run_chain_bylane(const void *coef, int frac, size_t n, void *state, const typename Sec::T *x, typename Sec::T *y,
-                     size_t lanes, size_t frames, int layout, hipStream_t s)
+                     size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch = {})
 {
     using T = typename Sec::T;
     if (lanes == 0 || frames == 0) return IDSP_OK;
-    if (n == 0) {
-        if (x != y) IDSP_HIP_TRY(hipMemcpyAsync(y, x, lanes * frames * sizeof(T), hipMemcpyDeviceToDevice, s));
-        return IDSP_OK;
-    }
+    if (n == 0) return copy_through<T>(x, y, lanes, frames, layout, s, pitch);
     constexpr int CV = ChainByLane<Sec, 1>::CV;
     size_t done = 0;
     const T *src = x;
@@ -578,48 +596,51 @@ int run_chain_bylane(const void *coef, int frac, size_t n, void *state, const ty
         const size_t m = n - done < size_t(kMaxChainByLane) ? n - done : size_t(kMaxChainByLane);
         ByLaneParams prm{static_cast<const T *>(coef) + done * CV * lanes, frac};
         uint32_t *st = static_cast<uint32_t *>(state) + done * Sec::W * lanes;
-        const int rc = m == 1 ? launch_stream<ChainByLane<Sec, 1>>(prm, st, src, y, lanes, frames, layout, s)
-                              : launch_stream<ChainByLane<Sec, 2>>(prm, st, src, y, lanes, frames, layout, s);
+        const int rc = m == 1 ? launch_stream<ChainByLane<Sec, 1>>(prm, st, src, y, lanes, frames, layout, s, pitch)
+                              : launch_stream<ChainByLane<Sec, 2>>(prm, st, src, y, lanes, frames, layout, s, pitch);
         if (rc) return rc;
         done += m;
         src = y;
+        pitch.x = pitch.y;
     }
     return IDSP_OK;
 }
 
 template <class Sec>
 int entry_bylane(const void *coef, int frac, size_t n, void *state, const typename Sec::T *x, typename Sec::T *y,
-                 size_t lanes, size_t frames, int layout, void *stream)
+                 size_t lanes, size_t frames, int layout, void *stream, Pitch pitch = {})
 {
     int rc = check_stream_args(coef, n, state, x, y, lanes, frames, layout);
     if (rc) return rc;
+    if ((rc = check_pitch(x, y, lanes, frames, layout, pitch))) return rc;
     if (std::is_same<typename Sec::T, int32_t>::value && (rc = check_frac(frac, 0))) return rc;
-    return run_chain_bylane<Sec>(coef, frac, n, state, x, y, lanes, frames, layout, as_stream(stream));
+    return run_chain_bylane<Sec>(coef, frac, n, state, x, y, lanes, frames, layout, as_stream(stream), pitch);
 }
 
 template <class T, int N, class CfgFill>
-int run_cascade_n(CfgFill fill, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+int run_cascade_n(CfgFill fill, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch)
 {
     typename CascadeDf1<T, N>::Params prm;
     for (int k = 0; k < N; k++) fill(prm.sec[k], size_t(k));
-    return launch_stream<CascadeDf1<T, N>>(prm, state, x, y, lanes, frames, layout, s);
+    return launch_stream<CascadeDf1<T, N>>(prm, state, x, y, lanes, frames, layout, s, pitch);
 }
 
 template <class T, class CfgFill>
 int run_cascade(CfgFill fill, size_t n, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout,
-                hipStream_t s)
+                hipStream_t s, Pitch pitch = {})
 {
+    if (int rc = check_pitch(x, y, lanes, frames, layout, pitch)) return rc;
     if (n < 1 || n > size_t(kMaxCascade)) return fail(IDSP_EINVAL, "cascade sections n = %zu not in 1..%d", n, kMaxCascade);
     if (lanes == 0 || frames == 0) return IDSP_OK;
     switch (n) {
-        case 1: return run_cascade_n<T, 1>(fill, state, x, y, lanes, frames, layout, s);
-        case 2: return run_cascade_n<T, 2>(fill, state, x, y, lanes, frames, layout, s);
-        case 3: return run_cascade_n<T, 3>(fill, state, x, y, lanes, frames, layout, s);
-        case 4: return run_cascade_n<T, 4>(fill, state, x, y, lanes, frames, layout, s);
-        case 5: return run_cascade_n<T, 5>(fill, state, x, y, lanes, frames, layout, s);
-        case 6: return run_cascade_n<T, 6>(fill, state, x, y, lanes, frames, layout, s);
-        case 7: return run_cascade_n<T, 7>(fill, state, x, y, lanes, frames, layout, s);
-        default: return run_cascade_n<T, 8>(fill, state, x, y, lanes, frames, layout, s);
+        case 1: return run_cascade_n<T, 1>(fill, state, x, y, lanes, frames, layout, s, pitch);
+        case 2: return run_cascade_n<T, 2>(fill, state, x, y, lanes, frames, layout, s, pitch);
+        case 3: return run_cascade_n<T, 3>(fill, state, x, y, lanes, frames, layout, s, pitch);
+        case 4: return run_cascade_n<T, 4>(fill, state, x, y, lanes, frames, layout, s, pitch);
+        case 5: return run_cascade_n<T, 5>(fill, state, x, y, lanes, frames, layout, s, pitch);
+        case 6: return run_cascade_n<T, 6>(fill, state, x, y, lanes, frames, layout, s, pitch);
+        case 7: return run_cascade_n<T, 7>(fill, state, x, y, lanes, frames, layout, s, pitch);
+        default: return run_cascade_n<T, 8>(fill, state, x, y, lanes, frames, layout, s, pitch);
     }
 }
 
@@ -689,32 +710,43 @@ struct FillClampF64 {
 
 template <class Sec, class Cfg, class Fill>
 int entry_i32(const Cfg *cfg, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
-              int layout, void *stream)
+              int layout, void *stream, Pitch pitch = {})
 {
     int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
     if (rc) return rc;
+    if ((rc = check_pitch(x, y, lanes, frames, layout, pitch))) return rc;
     for (size_t k = 0; k < n; k++)
         if ((rc = check_frac(cfg[k].frac, k))) return rc;
-    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream), pitch);
 }
 
 template <class Sec, class Cfg, class Fill>
 int entry_f64(const Cfg *cfg, size_t n, void *state, const double *x, double *y, size_t lanes, size_t frames,
-              int layout, void *stream)
+              int layout, void *stream, Pitch pitch = {})
 {
     int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
     if (rc) return rc;
-    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+    if ((rc = check_pitch(x, y, lanes, frames, layout, pitch))) return rc;
+    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream), pitch);
 }
 
 template <class Sec, class Cfg, class Fill>
 int entry_f32(const Cfg *cfg, size_t n, void *state, const float *x, float *y, size_t lanes, size_t frames,
-              int layout, void *stream)
+              int layout, void *stream, Pitch pitch = {})
 {
     int rc = check_stream_args(cfg, n, state, x, y, lanes, frames, layout);
     if (rc) return rc;
-    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream));
+    if ((rc = check_pitch(x, y, lanes, frames, layout, pitch))) return rc;
+    return run_chain<Sec>(Fill{cfg}, n, state, x, y, lanes, frames, layout, as_stream(stream), pitch);
 }
 
 }  // namespace bq
 }  // namespace idsp
+
+// `<entry>_pitch` twin of a shared-coefficient entry point (include/idsp_hip.h): same call with explicit row pitches.
+#define IDSP_PITCH_TWIN(name, Cfg, T, ENTRY, ...)                                                                      \
+    int name##_pitch(const Cfg *cfg, size_t n, void *state, const T *x, size_t x_pitch, T *y, size_t y_pitch,          \
+                     size_t lanes, size_t frames, int layout, void *stream)                                            \
+    {                                                                                                                  \
+        return ENTRY<__VA_ARGS__>(cfg, n, state, x, y, lanes, frames, layout, stream, ::idsp::Pitch{x_pitch, y_pitch}); \
+    }

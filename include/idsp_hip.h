@@ -296,6 +296,87 @@ int idsp_biquad_f64_df2t_clamp_bylane(const double *coef, size_t n, void *state,
         const double *x, double *y, size_t lanes, size_t frames, int layout, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* explicit row pitches: `<entry>_pitch`                                    */
+/* ------------------------------------------------------------------------ */
+/*
+ * Every biquad / cascade / by-lane entry above has a `_pitch` twin that takes the distance between rows of x and
+ * of y explicitly (like a BLAS leading dimension), in ELEMENTS:
+ *   IDSP_LANE_MAJOR   pitch = elements between the starts of consecutive lanes  (dense: frames) — the reference's
+ *                     `View::<_, LaneMajor>::lane(i) = flat[i * frames ..]` (dsp-process/src/view.rs:181-195) with the
+ *                     lanes padded apart; element (f, l) at l * pitch + f;
+ *   IDSP_FRAME_MAJOR  pitch = elements between the starts of consecutive frames (dense: lanes): a block of `lanes`
+ *                     adjacent lanes of a wider `[[T; L]; frames]` tensor; element (f, l) at f * pitch + l.
+ * 0 means dense.  A pitch shorter than a row is IDSP_EINVAL; an in-place call (y == x) needs x_pitch == y_pitch.
+ * Why it exists: power-of-two LANE_MAJOR pitches (frames = 4096 -> 16 KiB) alias on the HBM channels and cost
+ * 10-15 % (profiles/r01_lm_pitch_probe.jsonl); a caller that owns its buffers can pad each lane by a few cache
+ * lines.  The FRAME_MAJOR form lets a caller process a lane block of a larger tensor without a re-layout pass
+ * (this is also how a FRAME_MAJOR host tensor is split over several devices).  `pitch == dense` is bit-identical to
+ * the plain entry.
+ */
+int idsp_biquad_i32_df1_pitch(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, size_t x_pitch, int32_t *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_df1_clamp_pitch(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x, size_t x_pitch, int32_t *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_dither_pitch(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, size_t x_pitch, int32_t *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_dither_clamp_pitch(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x, size_t x_pitch, int32_t *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_wide_pitch(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, size_t x_pitch, int32_t *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_wide_clamp_pitch(const idsp_biquad_clamp_i32 *cfg, size_t n, void *state, const int32_t *x, size_t x_pitch, int32_t *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_cascade_i32_df1_pitch(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x, size_t x_pitch, int32_t *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df1_pitch(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df1_clamp_pitch(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df2t_pitch(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df2t_clamp_pitch(const idsp_biquad_clamp_f32 *cfg, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_cascade_f32_df1_pitch(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df1_pitch(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df1_clamp_pitch(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df2t_pitch(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df2t_clamp_pitch(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_cascade_f64_df1_pitch(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_df1_bylane_pitch(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, size_t x_pitch,
+        int32_t *y, size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_df1_clamp_bylane_pitch(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, size_t x_pitch,
+        int32_t *y, size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_dither_bylane_pitch(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, size_t x_pitch,
+        int32_t *y, size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_dither_clamp_bylane_pitch(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, size_t x_pitch,
+        int32_t *y, size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_wide_bylane_pitch(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, size_t x_pitch,
+        int32_t *y, size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_i32_wide_clamp_bylane_pitch(const int32_t *coef, int frac, size_t n, void *state, const int32_t *x, size_t x_pitch,
+        int32_t *y, size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df1_bylane_pitch(const float *coef, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df1_clamp_bylane_pitch(const float *coef, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df2t_bylane_pitch(const float *coef, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f32_df2t_clamp_bylane_pitch(const float *coef, size_t n, void *state, const float *x, size_t x_pitch, float *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df1_bylane_pitch(const double *coef, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df1_clamp_bylane_pitch(const double *coef, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df2t_bylane_pitch(const double *coef, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+int idsp_biquad_f64_df2t_clamp_bylane_pitch(const double *coef, size_t n, void *state, const double *x, size_t x_pitch, double *y, size_t y_pitch,
+        size_t lanes, size_t frames, int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* iir::normal::Normal and iir::wdf::Wdf lanes                               */
 /* ------------------------------------------------------------------------ */
 
@@ -639,6 +720,55 @@ typedef struct idsp_fm_disc {
 #define IDSP_FM_DISC_STATE_WORDS 7
 int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int32_t *y,
                      size_t lanes, size_t frames, int layout, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* lane split over several devices in ONE process: idsp_multi_*             */
+/* ------------------------------------------------------------------------ */
+/*
+ * Lanes never interact (`Lanes::process` indexes state[i], x[i] only, dsp-process/src/compose.rs:468-476), so G
+ * devices take G contiguous lane blocks — device g gets lanes [g*L/G, (g+1)*L/G) — and there is NO data-path
+ * exchange between them.  An idsp_multi holds a device list and one non-blocking stream per device; it is host-side
+ * bookkeeping for hosts that drive all GPUs from one process (the Rust shim, a C program).  One process per GPU
+ * (torch.distributed / MPI, each calling the plain entry points on its own lane block) is equivalent and is what
+ * bench.py uses.  Per-device buffers hold that device's lane block only: LANE_MAJOR shards are contiguous pieces of
+ * the host tensor, FRAME_MAJOR shards are `[[T; L/G]; frames]` tensors of their own (or lane blocks of a wider
+ * tensor through the `_pitch` entries).
+ */
+typedef struct idsp_multi idsp_multi;
+
+/* `devices` = n_devices device ordinals (a device may appear more than once: its lane blocks then share the
+ * device); devices == NULL and n_devices <= 0 = every visible device. */
+int idsp_multi_create(const int *devices, int n_devices, idsp_multi **out);
+int idsp_multi_destroy(idsp_multi *m);
+/* Number of lane blocks G; device ordinal and stream (hipStream_t) of block `index`. */
+int idsp_multi_size(const idsp_multi *m);
+int idsp_multi_device(const idsp_multi *m, int index);
+void *idsp_multi_stream(const idsp_multi *m, int index);
+/* Lane block [*lane_lo, *lane_hi) of block `index` for a job of `lanes` lanes. */
+int idsp_multi_shard(const idsp_multi *m, size_t lanes, int index, size_t *lane_lo, size_t *lane_hi);
+
+/* Generic driver: for every block, make its device current and call fn(user, index, lane_lo, lane_hi, stream) —
+ * fn issues whatever entry points it likes on that stream for that lane block.  A negative return stops the loop
+ * and is returned.  The caller's current device is restored. */
+typedef int (*idsp_shard_fn)(void *user, int index, size_t lane_lo, size_t lane_hi, void *stream);
+int idsp_multi_for_each(idsp_multi *m, size_t lanes, idsp_shard_fn fn, void *user);
+/* Wait for every block's stream (the "barrier" of a single-process run). */
+int idsp_multi_sync(idsp_multi *m);
+
+/* Per-block device buffers of (block lanes) * bytes_per_lane bytes, zero-filled: ptrs[G] out. */
+int idsp_multi_alloc(idsp_multi *m, size_t lanes, size_t bytes_per_lane, void **ptrs);
+int idsp_multi_free(idsp_multi *m, void **ptrs);
+/* Scatter (to_device != 0) / gather a host array of `lanes` records of bytes_per_lane bytes, lane-contiguous (a
+ * LANE_MAJOR tensor, or one state / coefficient plane), to / from the per-block buffers; asynchronous on the
+ * block streams (pinned host memory overlaps). */
+int idsp_multi_copy(idsp_multi *m, size_t lanes, size_t bytes_per_lane, void *const *dev_ptrs, void *host, int to_device);
+
+/* The two headline operators over the split: state[g], x[g], y[g] are block g's device buffers; `lanes` is the
+ * TOTAL lane count.  Asynchronous; idsp_multi_sync() waits. */
+int idsp_multi_biquad_i32_df1(idsp_multi *m, const idsp_biquad_i32 *cfg, size_t n, void *const *state,
+                              const int32_t *const *x, int32_t *const *y, size_t lanes, size_t frames, int layout);
+int idsp_multi_biquad_f32_df2t(idsp_multi *m, const idsp_biquad_f32 *cfg, size_t n, void *const *state,
+                               const float *const *x, float *const *y, size_t lanes, size_t frames, int layout);
 
 #ifdef __cplusplus
 }
