@@ -81,7 +81,7 @@ def test_rust_prototypes_agree_with_the_ctypes_prototypes():
 
 def test_safe_crate_only_uses_declared_items():
     sys_src = open(SYS).read()
-    declared = set(re.findall(r"pub (?:fn|struct|const) (\w+)", sys_src))
+    declared = set(re.findall(r"pub (?:fn|struct|const|type) (\w+)", sys_src))
     safe_src = open(SAFE).read()
     used = set(re.findall(r"\bsys::(\w+)", safe_src)) - {"idsp_"}  # "sys::idsp_*" appears in a doc comment
     # entry points handed to the kernel macros as bare identifiers (`sys::$entry`), and any other idsp_ symbol named
