@@ -72,7 +72,8 @@ __device__ __forceinline__ int64_t sum5(const SecI32 &c, int32_t x0, int32_t x1,
 template <bool CLAMP>
 struct Df1I32 {
     static constexpr bool kClamp = CLAMP;
-    static constexpr int LDS_RING = CLAMP ? 8 : 7;  // lane_stream.h kLdsNB: measured per processor
+    static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements (plain: 5, 6, 7 within 1.5 %)
+    static constexpr bool LDS_RUN = false;
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 4;  // x0 x1 y0 y1
@@ -93,7 +94,8 @@ struct Df1I32 {
 template <bool CLAMP>
 struct DitherI32 {
     static constexpr bool kClamp = CLAMP;
-    static constexpr int LDS_RING = CLAMP ? 8 : 7;  // lane_stream.h kLdsNB: measured per processor
+    static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements
+    static constexpr bool LDS_RUN = false;
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 5;  // x0 x1 y0 y1 e
@@ -120,6 +122,8 @@ template <bool CLAMP>
 struct WideI32 {
     static constexpr bool kClamp = CLAMP;
     using T = int32_t;
+    static constexpr int LDS_RING = CLAMP ? 4 : 5;   // tools/tune_lds.hip: best worst-case over four output placements
+    static constexpr bool LDS_RUN = !CLAMP;
     using Sec = SecI32;
     static constexpr int W = 6;  // x0 x1 y0.lo y0.hi y1.lo y1.hi
     static constexpr int COST = 100;
@@ -154,6 +158,8 @@ struct WideI32 {
 template <bool CLAMP>
 struct Df1F32 {
     static constexpr bool kClamp = CLAMP;
+    static constexpr int LDS_RING = CLAMP ? 4 : 5;   // tools/tune_lds.hip: best worst-case over four output placements
+    static constexpr bool LDS_RUN = false;
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 4;
@@ -178,7 +184,8 @@ struct Df1F32 {
 template <bool CLAMP>
 struct Df2tF32 {
     static constexpr bool kClamp = CLAMP;
-    static constexpr int LDS_RING = CLAMP ? 8 : 7;  // lane_stream.h kLdsNB: measured per processor
+    static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements
+    static constexpr bool LDS_RUN = false;
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 2;  // s0 s1
@@ -255,6 +262,8 @@ struct Df2tF64 {
 // {x0, x1, y0, y1}: y1' = (b0 x0 + b1 x1 + b2 x2 + re y1 + (-im) y0).as_(), y0' = (im y1 + re y0).as_().
 struct NormalI32 {
     using T = int32_t;
+    static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
+    static constexpr bool LDS_RUN = true;
     using Sec = SecI32;
     static constexpr bool kClamp = false;
     static constexpr int W = 4;
@@ -278,6 +287,8 @@ struct NormalI32 {
 };
 struct NormalF32 {
     using T = float;
+    static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
+    static constexpr bool LDS_RUN = true;
     using Sec = SecF32;
     static constexpr bool kClamp = false;
     static constexpr int W = 4;
@@ -332,6 +343,15 @@ struct SecRing<Sec, std::void_t<decltype(Sec::LDS_RING)>> {
     static constexpr int value = Sec::LDS_RING;
 };
 
+template <class Sec, class = void>
+struct SecRun {
+    static constexpr bool value = false;
+};
+template <class Sec>
+struct SecRun<Sec, std::void_t<decltype(Sec::LDS_RUN)>> {
+    static constexpr bool value = Sec::LDS_RUN;
+};
+
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
 template <class Sec, int N>
 struct Chain {
@@ -342,6 +362,7 @@ struct Chain {
     static constexpr int IN_DIV = 1;
     static constexpr int COST = N * Sec::COST;
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
+    static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     static constexpr int LDS_LPT_MAX = N == 1 ? 4 : 1;  // lane_stream.h: 2 / 4 lanes per thread on launches beyond 112k / 224k lanes
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
@@ -477,6 +498,7 @@ struct ChainByLane {
     static constexpr int IN_DIV = 1;
     static constexpr int COST = N * Sec::COST;
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
+    static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     static constexpr int LDS_LPT_MAX = N == 1 ? 4 : 1;
     static constexpr int CV = Sec::kClamp ? 8 : 5;
     using Params = ByLaneParams;

@@ -83,6 +83,56 @@ struct Casc {
     }
 };
 
+// History roll of a FULL chunk as one flat copy.  After a chunk, every stream's last H samples become the history in
+// front of the next chunk (src/hbf.rs:182-183,224 `copy_within`).  Done stage by stage with `lid < H` predicates that
+// was ~120 wave instructions per 1024-sample chunk (8 predicated reads, 8 predicated writes, their exec-mask
+// bookkeeping) out of ~570 — on a kernel that is instruction-issue bound.  The histories of all
+// streams are one list of `roll_total` words (118 for /16); thread t moves words t, t + 64, ... and knows their
+// source / destination LDS offsets from before the chunk loop: 2 reads, 2 writes, one predicate.
+template <class C>
+struct Roll {
+    static constexpr int total()
+    {
+        int t = 0;
+        for (int s = 0; s < C::stages; s++) t += C::sizeB(0) ? 3 * C::M(s) - 2 : 2 * C::M(s) - 1;
+        return t;
+    }
+    static constexpr int per_thread = (total() + kW - 1) / kW;
+    int src[per_thread], dst[per_thread];
+
+    __device__ __forceinline__ void plan(int lid)
+    {
+        constexpr bool DEC = C::sizeB(0) != 0;
+#pragma unroll
+        for (int k = 0; k < per_thread; k++) {
+            const int j = lid + k * kW;
+            int base = 0, d = 0, sft = 0;
+            static_for<0, C::stages>([&](auto s) {
+                constexpr int s_ = decltype(s)::value;
+                constexpr int M = C::M(s_), He = DEC ? M - 1 : 2 * M - 1, Ho = DEC ? 2 * M - 1 : 0;
+                if (j >= base && j < base + He) d = C::offA(s_) + pad4(He) + (j - base), sft = C::n(s_);
+                base += He;
+                if (Ho && j >= base && j < base + Ho) d = C::offB(s_) + pad4(Ho) + (j - base), sft = C::n(s_);
+                base += Ho;
+            });
+            dst[k] = d;
+            src[k] = d + sft;
+        }
+    }
+    __device__ __forceinline__ void run(float *lds, int lid) const
+    {
+        float t[per_thread];
+#pragma unroll
+        for (int k = 0; k < per_thread; k++)
+            if ((k + 1) * kW <= total() || lid + k * kW < total()) t[k] = lds[src[k]];
+        lds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < per_thread; k++)
+            if ((k + 1) * kW <= total() || lid + k * kW < total()) lds[dst[k]] = t[k];
+        lds_wave_sync();
+    }
+};
+
 // Σ_k (w[lo + 2M-1-k] + w[lo + k]) * tap_k, sequential from -0.0 (src/hbf.rs:60-66)
 template <class C, int s>
 __device__ __forceinline__ float window_sum(const float *w, int lo)
@@ -158,14 +208,25 @@ __device__ __forceinline__ void dec_stage(float *lds, int n_rt, float *yg, size_
 }
 
 template <class C, bool FULL>
-__device__ __forceinline__ void dec_chunk(float *lds, int nin, float *yg, size_t ystride, int lid)
+__device__ __forceinline__ void dec_chunk(float *lds, int nin, float *yg, size_t ystride, int lid, const Roll<C> &roll)
 {
+#ifdef IDSP_EXP_HBF_NOSTAGES  // timing experiment only (tools/exp_hbf.sh): memory traffic without the arithmetic
+    if (lid == 0 && FULL) yg[0] = lds[C::offA(0) + 8];
+    return;
+#endif
     static_for<0, C::stages>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
+#ifdef IDSP_EXP_HBF_SKIP
+        if constexpr (((IDSP_EXP_HBF_SKIP) >> s_) & 1) return;
+#endif
         dec_stage<C, s_, FULL>(lds, nin >> (s_ + 1), yg, ystride, lid);
         lds_wave_sync();
     });
-    // roll the histories: word j <- word n_s + j (src/hbf.rs:182-183)
+    if constexpr (FULL) {
+        roll.run(lds, lid);
+        return;
+    }
+    // ragged last chunk: roll the histories stage by stage, word j <- word n_s + j (src/hbf.rs:182-183)
     float ke[C::stages], ko[C::stages];
     static_for<0, C::stages>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
@@ -215,11 +276,17 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
         if (lid < Ho) lds[C::offB(s_) + pad4(Ho) + lid] = __uint_as_float(st[size_t(so + He + lid) * lanes + lane]);
     });
 
+    Roll<C> roll;
+    roll.plan(lid);
     constexpr int CHF = kCH / R;     // output frames per chunk
     constexpr int kPre = kCH / 4 / kW;  // 16-byte pieces per thread and chunk
     constexpr int M0 = C::M(0);
     float *E0n = lds + C::offA(0) + up4(M0 - 1), *O0n = lds + C::offB(0) + up4(2 * M0 - 1);
-    v4f pre[kPre];
+    // Two chunks in flight (register double buffer, statically indexed: the chunk loop is unrolled by two): with 16-18
+    // waves per CU one 4 KiB chunk per wave left only 64-72 KiB per CU in flight and the loads alone (arithmetic removed,
+    // tools/exp_hbf.sh) ran at 0.72 of the HBM peak.  Whole chunks take an unpredicated path: the per-piece `q < n`
+    // tests with their exec-mask bookkeeping were ~50 of the ~500 instructions per chunk of an issue-bound kernel.
+    v4f pre[2][kPre];
     auto piece = [&](size_t f0, int q) -> const v4f * {
         if constexpr (LM) {
             return reinterpret_cast<const v4f *>(x + (lane * frames + f0) * size_t(R)) + q;
@@ -228,37 +295,66 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
             return reinterpret_cast<const v4f *>(x + ((f0 + size_t(q / PPF)) * lanes + lane) * size_t(R)) + (q % PPF);
         }
     };
-    auto fetch = [&](size_t f0) {
-        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
-#pragma unroll
-        for (int i = 0; i < kPre; i++) {
-            const int q = lid + i * kW;
-            // contiguous 1 KiB per wave instruction in LANE_MAJOR: streamed once -> nontemporal;
-            // FRAME_MAJOR pieces are 64-byte fragments that rely on L2 to merge neighbours
-            if (q < nf * R / 4) pre[i] = LM ? __builtin_nontemporal_load(piece(f0, q)) : *piece(f0, q);
-        }
+    // contiguous 1 KiB per wave instruction in LANE_MAJOR: streamed once -> nontemporal;
+    // FRAME_MAJOR pieces are 64-byte fragments that rely on L2 to merge neighbours
+    auto load = [&](size_t f0, int q) -> v4f {
+#ifdef IDSP_EXP_HBF_NOLOAD  // timing experiment only: the arithmetic without the input stream
+        return v4f{float(q), 1.f, 2.f, 3.f};
+#else
+        return LM ? __builtin_nontemporal_load(piece(f0, q)) : *piece(f0, q);
+#endif
     };
-    fetch(0);
-    for (size_t f0 = 0; f0 < frames; f0 += CHF) {
-        const int nf = frames - f0 < size_t(CHF) ? int(frames - f0) : CHF;
-        const int nin = nf * R;
-        // stage-0 input: pairs [even, odd] split into the two streams
+    auto fetch = [&](auto slot, size_t f0) {
+        constexpr int SL = decltype(slot)::value;
+        if (f0 >= frames) return;
+        if (frames - f0 >= size_t(CHF)) {
 #pragma unroll
-        for (int i = 0; i < kPre; i++) {
-            const int q = lid + i * kW;
-            if (q < nin / 4) {
-                *reinterpret_cast<v2f *>(E0n + 2 * q) = v2f{pre[i].x, pre[i].z};
-                *reinterpret_cast<v2f *>(O0n + 2 * q) = v2f{pre[i].y, pre[i].w};
+            for (int i = 0; i < kPre; i++) pre[SL][i] = load(f0, lid + i * kW);
+        } else {
+            const int nf = int(frames - f0);
+#pragma unroll
+            for (int i = 0; i < kPre; i++) {
+                const int q = lid + i * kW;
+                if (q < nf * R / 4) pre[SL][i] = load(f0, q);
             }
         }
-        if (f0 + CHF < frames) fetch(f0 + CHF);  // next chunk in flight during the arithmetic
-        lds_wave_sync();
+    };
+    auto chunk = [&](auto slot, size_t f0) {
+        constexpr int SL = decltype(slot)::value;
         float *yg = LM ? y + lane * frames + f0 : y + f0 * lanes + lane;
         const size_t ystride = LM ? 1 : lanes;
-        if (nf == CHF)
-            dec_chunk<C, true>(lds, nin, yg, ystride, lid);
-        else
-            dec_chunk<C, false>(lds, nin, yg, ystride, lid);
+        // stage-0 input: pairs [even, odd] split into the two streams
+        if (frames - f0 >= size_t(CHF)) {
+#pragma unroll
+            for (int i = 0; i < kPre; i++) {
+                const int q = lid + i * kW;
+                *reinterpret_cast<v2f *>(E0n + 2 * q) = v2f{pre[SL][i].x, pre[SL][i].z};
+                *reinterpret_cast<v2f *>(O0n + 2 * q) = v2f{pre[SL][i].y, pre[SL][i].w};
+            }
+            fetch(slot, f0 + 2 * size_t(CHF));  // two chunks ahead, into the slot just emptied
+            lds_wave_sync();
+            dec_chunk<C, true>(lds, kCH, yg, ystride, lid, roll);
+        } else {
+            const int nin = int(frames - f0) * R;
+#pragma unroll
+            for (int i = 0; i < kPre; i++) {
+                const int q = lid + i * kW;
+                if (q < nin / 4) {
+                    *reinterpret_cast<v2f *>(E0n + 2 * q) = v2f{pre[SL][i].x, pre[SL][i].z};
+                    *reinterpret_cast<v2f *>(O0n + 2 * q) = v2f{pre[SL][i].y, pre[SL][i].w};
+                }
+            }
+            lds_wave_sync();
+            dec_chunk<C, false>(lds, nin, yg, ystride, lid, roll);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    fetch(S0{}, 0);
+    fetch(S1{}, size_t(CHF));
+    for (size_t f0 = 0; f0 < frames; f0 += 2 * size_t(CHF)) {
+        chunk(S0{}, f0);
+        if (f0 + CHF < frames) chunk(S1{}, f0 + CHF);
     }
 
     static_for<0, S>([&](auto s) {
@@ -302,6 +398,8 @@ __global__ __launch_bounds__(kBlkLanes *kW) void hbf_dec_block_fm(uint32_t *st, 
         if (lid < Ho) lds[C::offB(s_) + pad4(Ho) + lid] = __uint_as_float(st[size_t(so + He + lid) * lanes + lane]);
     });
 
+    Roll<C> roll;
+    roll.plan(lid);
     // Cooperative input: a frame of the workgroup's 16 lanes is 16 * R * 4 contiguous bytes; thread t of the
     // workgroup moves 16-byte vector v = t % VPF of frame t / VPF (+ FPI per instruction), so every wave
     // instruction reads whole contiguous runs, and drops it into the owning lane's stage-0 streams.
@@ -345,9 +443,9 @@ __global__ __launch_bounds__(kBlkLanes *kW) void hbf_dec_block_fm(uint32_t *st, 
         lds_barrier();  // every lane's chunk is in place
         float *ot = otile + slot * CHF * kBlkLanes;
         if (nf == CHF)
-            dec_chunk<C, true>(lds, nin, ot + wave, size_t(kBlkLanes), lid);
+            dec_chunk<C, true>(lds, nin, ot + wave, size_t(kBlkLanes), lid, roll);
         else
-            dec_chunk<C, false>(lds, nin, ot + wave, size_t(kBlkLanes), lid);
+            dec_chunk<C, false>(lds, nin, ot + wave, size_t(kBlkLanes), lid, roll);
         lds_barrier();  // outputs staged, and nobody still reads the stage-0 streams
         // 16 threads write one frame's 64 bytes; the other tile is free until the next chunk's barrier
         for (int t = threadIdx.x; t < nf * kBlkLanes; t += NT)
@@ -430,13 +528,17 @@ __device__ __forceinline__ void int_stage(float *lds, int n_rt, float *y, size_t
 
 template <class C, bool FULL, bool LM>
 __device__ __forceinline__ void int_chunk(float *lds, int nf, float *y, size_t lanes, size_t frames, size_t lane,
-                                          size_t f0, int lid)
+                                          size_t f0, int lid, const Roll<C> &roll)
 {
     static_for<0, C::stages>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
         int_stage<C, s_, FULL, LM>(lds, nf << s_, y, lanes, frames, lane, f0, lid);
         lds_wave_sync();
     });
+    if constexpr (FULL) {
+        roll.run(lds, lid);
+        return;
+    }
     float kx[C::stages];
     static_for<0, C::stages>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
@@ -470,6 +572,8 @@ __global__ __launch_bounds__(kW) void hbf_int_wave(uint32_t *st, const float *x,
         if (lid < H) lds[C::offA(s_) + pad4(H) + lid] = __uint_as_float(st[size_t(C::state_off(s_) + lid) * lanes + lane]);
     });
 
+    Roll<C> roll;
+    roll.plan(lid);
     constexpr int CHF = kCH / R;  // input frames per chunk (<= 512)
     constexpr int kPre = (CHF + kW - 1) / kW;
     float *X0n = lds + C::offA(0) + up4(2 * C::M(0) - 1);
@@ -495,9 +599,9 @@ __global__ __launch_bounds__(kW) void hbf_int_wave(uint32_t *st, const float *x,
         if (f0 + CHF < frames) fetch(f0 + CHF);
         lds_wave_sync();
         if (nf == CHF)
-            int_chunk<C, true, LM>(lds, nf, y, lanes, frames, lane, f0, lid);
+            int_chunk<C, true, LM>(lds, nf, y, lanes, frames, lane, f0, lid, roll);
         else
-            int_chunk<C, false, LM>(lds, nf, y, lanes, frames, lane, f0, lid);
+            int_chunk<C, false, LM>(lds, nf, y, lanes, frames, lane, f0, lid, roll);
     }
 
     static_for<0, S>([&](auto s) {
@@ -532,6 +636,8 @@ __global__ __launch_bounds__(kBlkLanes *kW) void hbf_int_block_fm(uint32_t *st, 
         if (lid < H) lds[C::offA(s_) + pad4(H) + lid] = __uint_as_float(st[size_t(C::state_off(s_) + lid) * lanes + lane]);
     });
 
+    Roll<C> roll;
+    roll.plan(lid);
     constexpr int kPre = (CHF + kW - 1) / kW;
     float *X0n = lds + C::offA(0) + up4(2 * C::M(0) - 1);
     float pre[kPre];
@@ -564,9 +670,9 @@ __global__ __launch_bounds__(kBlkLanes *kW) void hbf_int_block_fm(uint32_t *st, 
         lds_wave_sync();
         // LANE_MAJOR addressing onto the staging row: y' + (0 * frames + 0) * R + o
         if (nf == CHF)
-            int_chunk<C, true, true>(lds, nf, stage + wave * kCH, 1, 0, 0, 0, lid);
+            int_chunk<C, true, true>(lds, nf, stage + wave * kCH, 1, 0, 0, 0, lid, roll);
         else
-            int_chunk<C, false, true>(lds, nf, stage + wave * kCH, 1, 0, 0, 0, lid);
+            int_chunk<C, false, true>(lds, nf, stage + wave * kCH, 1, 0, 0, 0, lid, roll);
         lds_barrier();  // every lane's chunk is staged
         for (int fr = tf; fr < nf; fr += FPI) dst[(f0 + size_t(fr)) * fpitch] = *reinterpret_cast<const v4f *>(src + fr * R);
         lds_barrier();  // staging rows free again

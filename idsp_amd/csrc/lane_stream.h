@@ -294,6 +294,16 @@ template <class P>
 struct LdsRingOf<P, std::void_t<decltype(P::LDS_RING)>> {
     static constexpr int value = P::LDS_RING;
 };
+// Addressing form of the LDS-DMA kernel per processor (see the kernel): indexed unless the processor asks for the running
+// form (P::LDS_RUN).  Ring depth and form per section type come from tools/tune_lds.hip (profiles/r02_tune_lds.jsonl).
+template <class P, class = void>
+struct LdsRunOf {
+    static constexpr bool value = false;
+};
+template <class P>
+struct LdsRunOf<P, std::void_t<decltype(P::LDS_RUN)>> {
+    static constexpr bool value = P::LDS_RUN;
+};
 
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {
@@ -328,7 +338,7 @@ __device__ __forceinline__ void static_for(F &&f)
 // of 2^17 .. 2^18 lanes still run as 256 workgroups, one per CU — measured (tools/exp_c5.hip,
 // profiles/r02_exp_c5_*.jsonl, i32 DF1 x 4096 frames): 131072 lanes 0.65 (512 workgroups) / 0.70 (256 persistent
 // workgroups, two column panels) -> 0.76-0.77 with LPT 2; 262144 lanes 0.66 -> 0.72 with LPT 4.
-template <class P, int NB = LdsRingOf<P>::value, int LPT = 1>
+template <class P, int NB = LdsRingOf<P>::value, int LPT = 1, bool RUN = LdsRunOf<P>::value>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
@@ -370,20 +380,40 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const size_t lane0 = blk * kBlockLanes;
 #pragma unroll
     for (int s = 0; s < LPT; s++) p[s].load(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
+    // The state loads must have landed HERE, in a way the compiler's wait-count pass sees: it cannot see the DMA
+    // requests of glds16(), and if it first needs a state register inside the steady-state loop it protects that use
+    // with `s_waitcnt vmcnt(0)` on every iteration — which drains the whole prefetch ring each tile (0.52 instead of
+    // 0.34 ms at C2 when a refactoring moved the first use).  vmcnt(0), expcnt / lgkmcnt untouched:
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 
     const size_t ntiles = (frames + R - 1) / R;
     const size_t nfull = frames / R;  // tiles [0, nfull) have all their rows
     // segment g of a tile = frame g / LPT of the tile, sub-block g % LPT; a ragged tile holds nseg(v) segments
     auto nseg = [&](size_t v) { return int((frames - v * R < size_t(R) ? frames - v * R : size_t(R)) * LPT); };
+    // Two forms of the per-tile addressing, chosen per processor (P::LDS_RUN) by measurement — these kernels sit on a
+    // timing edge where the scalar instructions between the barriers decide how the DMA requests and the stores
+    // interleave (profiles/r02_exp_c2_clamp*.jsonl, tools/exp_c2_clamp.sh: C2 shape, four placements of y):
+    //   RUN = false  ring slot = tile % NB, addresses from the tile index: plain DF1 / dither / f32 DF2T at ring 7
+    //                run 0.796-0.805 of peak this way and 0.71-0.77 the other way;
+    //   RUN = true   running ring slot, x / y pointers advanced per tile: the clamp forms (two more dependent
+    //                operations per sample) run 0.77-0.78 at ring 5 this way in every placement, against 0.67-0.68
+    //                (ring 5-7) or 0.67 / 0.75 by placement (ring 8) the other way.
+    const size_t xstep = size_t(R) * xl, ystep = size_t(R) * yl * OW;
+    const In *xq = x + lane0 + lid * 4;                                       // RUN: tile about to be requested
+    uint32_t *yq = reinterpret_cast<uint32_t *>(y) + lane0 * OW + lid * 4;    // RUN: tile about to be stored
+    int slot_run = 0;                                                         // RUN: i % NB
     auto issue = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const int slot = int(v % NB), ns = FULL ? TS : nseg(v);
+        const int slot = RUN ? slot_run : int(v % NB), ns = FULL ? TS : nseg(v);
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
             const int g = wave + 4 * j;
-            if (FULL || g < ns)
-                glds16(x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid * 4, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
+            if (FULL || g < ns) {
+                const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * kFmBlock : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid * 4;
+                glds16(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
+            }
         }
+        if constexpr (RUN) xq += xstep;
     };
     auto store = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
@@ -397,15 +427,20 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
                     const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid * 4);
-                    __builtin_nontemporal_store(
-                        v4, reinterpret_cast<u32x4 *>(yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid * 4));
+                    uint32_t *dst = RUN ? yq + (size_t(g / LPT) * yl + (g % LPT) * kFmBlock) * OW + h * kFmBlock
+                                        : yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid * 4;
+                    __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst));
                 }
             }
+        }
+        if constexpr (RUN) {
+            yq += ystep;
+            slot_run = slot_run + 1 == NB ? 0 : slot_run + 1;  // the tile is done: its slot went to tile v + NB in issue()
         }
     };
     auto compute = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const uint32_t *in = tin + (v % NB) * TS * kFmBlock;
+        const uint32_t *in = tin + (RUN ? slot_run : int(v % NB)) * TS * kFmBlock;
         uint32_t *o = tout + (v & 1) * TS * kFmBlock * OW;
         const int ns = FULL ? TS : nseg(v);
         if constexpr (B > 1) {  // LPT == 1: segments are consecutive frames of one lane
@@ -432,7 +467,11 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 
     using Full = std::true_type;
     using Ragged = std::false_type;
-    for (size_t t = 0; t < size_t(NB) && t < ntiles; t++) issue(t, Ragged{});
+    for (size_t t = 0; t < size_t(NB) && t < ntiles; t++) {
+        slot_run = int(t);
+        issue(t, Ragged{});
+    }
+    slot_run = 0;
     size_t i = 0;
     auto slow_iter = [&]() {  // start-up, drain and ragged tiles: wait for everything
         wait_vmcnt<0>();
@@ -668,24 +707,37 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     grid = (wgs + rounds - 1) / rounds;
                 }
                 int rc = IDSP_OK;
-                auto go = [&](auto lpt_tag) {
+                // Ring depth: the processor's tuned depth for single-pass launches; persistent launches (large lane
+                // counts, row pitch >= 1.5 MiB) keep 7 tiles and the indexed form for every processor — depths 3-5 lose
+                // 15-20 % there (profiles/r02_exp_c5_matrix7.jsonl: 0.56 vs 0.68 at 2^20 lanes).
+                const bool persistent = grid < wgs;
+                auto go = [&](auto lpt_tag, auto deep) {
                     constexpr int L = decltype(lpt_tag)::value;
-                    constexpr int NB = LdsRingOf<P>::value;
+                    constexpr bool DEEP = decltype(deep)::value;
+                    constexpr int NB = DEEP ? 7 : LdsRingOf<P>::value;
+                    constexpr bool RUN = DEEP ? false : LdsRunOf<P>::value;
                     constexpr size_t ts = L > kLdsT ? L : kLdsT;
                     constexpr size_t bytes = (size_t(NB) * ts * kFmBlock + 2 * ts * kFmBlock * ow + P::LDS_WORDS) * 4;
-                    if ((rc = ensure_dyn_lds(stream_frame_major_lds<P, NB, L>, bytes))) return;
+                    if ((rc = ensure_dyn_lds(stream_frame_major_lds<P, NB, L, RUN>, bytes))) return;
                     note_kernel(L == 1 ? "stream_frame_major_lds" : L == 2 ? "stream_frame_major_lds[2 lanes/thread]" : "stream_frame_major_lds[4 lanes/thread]",
                                 typeid(P).name());
-                    hipLaunchKernelGGL((stream_frame_major_lds<P, NB, L>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s,
+                    hipLaunchKernelGGL((stream_frame_major_lds<P, NB, L, RUN>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s,
                                        prm, st, x, y, lanes, frames, xl, yl);
                 };
+                using Yes = std::true_type;
+                using No = std::false_type;
                 if constexpr (kMaxLpt >= 4) {
-                    if (lpt == 4) go(std::integral_constant<int, 4>{});
+                    if (lpt == 4) go(std::integral_constant<int, 4>{}, No{});
                 }
                 if constexpr (kMaxLpt >= 2) {
-                    if (lpt == 2) go(std::integral_constant<int, 2>{});
+                    if (lpt == 2) go(std::integral_constant<int, 2>{}, No{});
                 }
-                if (lpt == 1) go(std::integral_constant<int, 1>{});
+                if (lpt == 1) {
+                    if (persistent && LdsRingOf<P>::value != 7)
+                        go(std::integral_constant<int, 1>{}, Yes{});
+                    else
+                        go(std::integral_constant<int, 1>{}, No{});
+                }
                 if (rc) return rc;
                 return launch_status();
             }

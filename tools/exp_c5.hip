@@ -18,7 +18,14 @@ void note_kernel(const char *, const char *) {}
 }  // namespace idsp
 
 using namespace idsp;
+#ifndef EXP_RUN
+#define EXP_RUN false
+#endif
+#ifdef EXP_CLAMP
+using P = bq::Chain<bq::Df1I32<true>, 1>;
+#else
 using P = bq::Chain<bq::Df1I32<false>, 1>;
+#endif
 static int g_adj = 0;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -28,14 +35,14 @@ float run(const P::Params &prm, uint32_t *st, const int32_t *x, int32_t *y, size
 {
     constexpr size_t kSeg = (LPT > kLdsT) ? LPT : kLdsT;
     constexpr size_t bytes = (size_t(NB) * kSeg * kFmBlock + 2 * kSeg * kFmBlock) * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_lds<P, NB, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_lds<P, NB, LPT, EXP_RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
     std::vector<float> ts;
     for (int i = 0; i < iters + 40; i++) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, LPT>), dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, pitch, pitch);
+        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, LPT, EXP_RUN>), dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, pitch, pitch);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;
@@ -53,7 +60,7 @@ int main(int argc, char **argv)
     unsigned grid = argc > 4 ? atoi(argv[4]) : 0;
     const int nb = argc > 5 ? atoi(argv[5]) : 7;
     const bool inplace = argc > 6 && atoi(argv[6]);
-    const size_t yoff = argc > 7 ? atoll(argv[7]) : 0;
+    const size_t yoff = argc > 7 ? size_t(atoll(argv[7])) : 0;
     const int lpt = argc > 8 ? atoi(argv[8]) : 1;
     g_adj = argc > 9 ? atoi(argv[9]) : 0;
     if (!pitch) pitch = lanes;
@@ -61,13 +68,15 @@ int main(int argc, char **argv)
     const size_t n = pitch * frames;
     int32_t *x, *y;
     uint32_t *st;
-    CK(hipMalloc(&x, n * 4 + (inplace ? 0 : n * 4 + yoff + 4096)));
+    const bool separate = yoff == size_t(-1);  // y from its own hipMalloc (what two framework allocations look like)
+    CK(hipMalloc(&x, n * 4 + (inplace || separate ? 0 : n * 4 + yoff + 4096)));
     y = inplace ? x : reinterpret_cast<int32_t *>(reinterpret_cast<char *>(x) + n * 4 + yoff);
+    if (separate) CK(hipMalloc(&y, n * 4));
     CK(hipMalloc(&st, lanes * 16));
     CK(hipMemset(x, 1, n * 4));
     CK(hipMemset(st, 0, lanes * 16));
     P::Params prm{};
-    prm.sec[0] = {{1 << 20, 1 << 21, 1 << 20, 1 << 30, -(1 << 29)}, 30, 0, 0, 0};
+    prm.sec[0] = {{1 << 20, 1 << 21, 1 << 20, 1 << 30, -(1 << 29)}, 30, 3, -(1 << 30), 1 << 30};
     float ms = 0;
     if (lpt > 1) {
         if (nb != 7 && nb != 5) { printf("LPT > 1: NB 5 or 7\n"); return 1; }
