@@ -25,12 +25,12 @@ all: $(LIB) $(ORACLE)
 lib: $(LIB)
 oracle: $(ORACLE)
 
-# The SLP vectoriser packs two independent i64 MACs into <2 x i64> operations, which the back end
-# lowers to generic 64-bit multiplies (v_mul_lo_u32 / v_mad_u64_u32 chains) instead of
-# v_mad_i64_i32 — seen to come and go with unrelated edits.  It stays on only for the half-band
-# FIR files, where it produces the packed f32 adds/multiplies.
+# No SLP vectorisation anywhere.  (i) It packs two independent i64 MACs into <2 x i64> operations, which the back end
+# lowers to generic 64-bit multiplies (v_mul_lo_u32 / v_mad_u64_u32 chains) instead of v_mad_i64_i32 — seen to come and
+# go with unrelated edits.  (ii) In the half-band FIR files it produces v_pk_add_f32 / v_pk_mul_f32; round 1 kept it on
+# there for that, but packed f32 VALU is no faster than two scalar operations on gfx950 and costs register shuffles:
+# every half-band kernel measured 1-4 % faster without it (x4 interpolator 10 %; profiles/r02_exp_hbf_slp.txt).
 NOSLP_FLAGS := -fno-slp-vectorize
-$(CSRC)/hbf%.o: NOSLP_FLAGS :=
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) $(NOSLP_FLAGS) -c $< -o $@
