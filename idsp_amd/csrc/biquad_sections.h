@@ -363,7 +363,6 @@ struct Chain {
     static constexpr int COST = N * Sec::COST;
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
-    static constexpr int LDS_LPT_MAX = N == 1 ? 4 : 1;  // lane_stream.h: 2 / 4 lanes per thread on launches beyond 112k / 224k lanes
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
 
@@ -499,7 +498,6 @@ struct ChainByLane {
     static constexpr int COST = N * Sec::COST;
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
-    static constexpr int LDS_LPT_MAX = N == 1 ? 4 : 1;
     static constexpr int CV = Sec::kClamp ? 8 : 5;
     using Params = ByLaneParams;
     uint32_t s[N][Sec::W];

@@ -333,11 +333,13 @@ __device__ __forceinline__ void static_for(F &&f)
 // LPT ("lanes per thread") > 1: a workgroup owns 256 * LPT adjacent lanes and thread t runs the LPT independent
 // recurrences of lanes t, t + 256, ...  A tile is still TS one-KiB row segments (8 KiB; 16 KiB for LPT = 16) —
 // frames [v R, v R + R) x all LPT sub-blocks, R = TS / LPT — so ring bytes, barriers per sample and the vmcnt
-// bookkeeping are those of LPT = 1, and every workgroup sweeps whole (LPT KiB) row pieces in address order.  What
-// changes is that a launch of L lanes needs only L / (256 LPT) workgroups: the launcher picks LPT so that launches
-// of 2^17 .. 2^18 lanes still run as 256 workgroups, one per CU — measured (tools/exp_c5.hip,
-// profiles/r02_exp_c5_*.jsonl, i32 DF1 x 4096 frames): 131072 lanes 0.65 (512 workgroups) / 0.70 (256 persistent
-// workgroups, two column panels) -> 0.76-0.77 with LPT 2; 262144 lanes 0.66 -> 0.72 with LPT 4.
+// bookkeeping are those of LPT = 1, and every workgroup sweeps whole (LPT KiB) row pieces in address order, so that a
+// launch of L lanes needs only L / (256 LPT) workgroups.  MEASURED AND NOT USED BY DEFAULT (no processor declares
+// LDS_LPT_MAX > 1): with the output right behind the input in one allocation the form runs 131072 lanes at 0.76-0.78
+// of the HBM peak and 262144 at 0.72 (one lane per thread on a persistent grid: 0.70 / 0.67), but over nine placements
+// of the output buffer it ranges 0.61-0.78 / 0.62-0.77 (mean 0.68 / 0.67) where the persistent one-lane form ranges
+// 0.69-0.75 / 0.65-0.69 (mean 0.72 / 0.68) — profiles/r02_exp_c5_place.jsonl, tools/exp_c5_place.hip.  The template
+// parameter stays for those tools and for IDSP_DIAG=1 IDSP_LDS_LPT experiments on processors that opt in.
 template <class P, int NB = LdsRingOf<P>::value, int LPT = 1, bool RUN = LdsRunOf<P>::value>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
@@ -676,13 +678,12 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             constexpr size_t ow = sizeof(typename P::Out) / 4;
             if (!no_lds && P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 &&
                 reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && (yl * ow) % 4 == 0) {
-                // Lanes per thread and grid (profiles/r02_exp_c5_*.jsonl).  Fastest regime: ~256 workgroups, one per CU,
-                // each sweeping whole row pieces -> 2 or 4 lanes per thread when that gives 224..320 workgroups (the
-                // processor must have the form, P::LDS_LPT_MAX, and the lanes must divide).  Launches beyond that run
-                // one lane per thread on a persistent grid of <= 256 workgroups that walks the lane blocks in column
-                // panels of equal rounds (2^20 lanes: 0.68 of peak against 0.64 with 4096 workgroups, 0.615 on the
-                // register-window kernel, 0.49-0.59 with 2 / 4 lanes per thread on a persistent grid).
-                // IDSP_DIAG=1 IDSP_LDS_LPT / IDSP_LDS_GRID override both.
+                // Grid (profiles/r02_exp_c5_*.jsonl).  Up to 384 workgroups: one per 256-lane block.  Beyond: a persistent
+                // grid of <= 256 workgroups (one per CU) that walks the lane blocks in column panels of equal rounds —
+                // 2^20 lanes: 0.68 of peak (0.61-0.75 by output placement) against 0.66 with 4096 workgroups and 0.615
+                // on the register-window kernel; 131072 lanes: 0.72 against 0.65 with 512 workgroups.  Two or four
+                // lanes per thread (whole-row sweeps by 256 workgroups) are available to processors that declare
+                // P::LDS_LPT_MAX; none does (see the kernel).  IDSP_DIAG=1 IDSP_LDS_LPT / IDSP_LDS_GRID override both.
                 static const size_t forced_lpt = diag_size("IDSP_LDS_LPT", 0);
                 static const size_t forced_grid = diag_size("IDSP_LDS_GRID", ~size_t(0));
                 const size_t nblocks = lanes / kFmBlock;

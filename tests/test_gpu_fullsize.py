@@ -376,12 +376,11 @@ def test_c2_shape_variants_on_default_dispatch(eng, op, words, dtype, clamp):
     assert torch.equal(x.view(torch.int32), y.view(torch.int32)) and torch.equal(st, st2)
 
 
-@pytest.mark.parametrize("lanes,want", [(131072, "stream_frame_major_lds[2 lanes/thread]<"), (262144, "stream_frame_major_lds[4 lanes/thread]<"),
-                                        (393216, "stream_frame_major_lds<")])
+@pytest.mark.parametrize("lanes,want", [(131072, "stream_frame_major_lds<"), (262144, "stream_frame_major_lds<"), (327680, "stream_frame_major_lds<")])
 def test_large_lane_counts_on_default_dispatch(eng, lanes, want):
-    """Beyond 65536 lanes the LDS-DMA kernel runs 2 or 4 lanes per thread, or one lane per thread on a persistent grid
-    (C5 shards at 8 / 4 GPUs; 393216 lanes = 1536 blocks -> 6 rounds of 256 workgroups): i32 DF1 and f32 DF2T against
-    the oracle on a lane subset, ragged frame count (odd: the 4-lane form packs 2 frames per tile), chunked == whole."""
+    """Beyond 98304 lanes the LDS-DMA kernel runs on a persistent grid of <= 256 workgroups that walks the 256-lane blocks
+    in column panels (C5 shards at 8 / 4 GPUs: 2 / 4 rounds; 327680 lanes = 1280 blocks -> 5 rounds): i32 DF1 and f32
+    DF2T against the oracle on a lane subset, ragged frame count, chunked == whole."""
     frames = 1003
     o = H.oracle()
     g = torch.Generator(device=DEV)

@@ -16,7 +16,7 @@ SUITES = ["tests/test_gpu_parity.py", "tests/test_gpu_bylane.py", "tests/test_gp
           "tests/test_fm_disc.py"]
 
 
-@pytest.mark.parametrize("mode", ["misaligned", "inplace", "both", "lds", "lds-persistent", "lds-lpt2", "lds-lpt4"])
+@pytest.mark.parametrize("mode", ["misaligned", "inplace", "both", "lds", "lds-persistent"])
 def test_parity_suites_on_buffers_without_16_byte_alignment(gpu, mode):
     """mode "inplace": every stream / by-lane call runs as `Inplace::inplace` (y is x, dsp-process/src/process.rs:61-65)."""
     env = dict(os.environ)
@@ -28,10 +28,7 @@ def test_parity_suites_on_buffers_without_16_byte_alignment(gpu, mode):
         # every FrameMajor case with whole 256-lane blocks (SHAPES holds ragged-frame ones) on the LDS-DMA kernel whatever
         # the processor's cost or the launch size: clamp / f32 DF1 / ByLane / Normal functors meet the oracle there;
         # "lds-persistent": a grid of 3 workgroups walks the 256-lane blocks (uneven shares, several blocks per workgroup)
-        # "lds-lpt2" / "lds-lpt4": 2 / 4 lanes per thread wherever the processor has that form and the lanes divide
         env.update(IDSP_DIAG="1", IDSP_LDS_MIN_WAVES="0", IDSP_LDS_COST="100000", IDSP_LDS_GRID="3" if mode == "lds-persistent" else "0")
-        if mode.startswith("lds-lpt"):
-            env.update(IDSP_LDS_LPT=mode[-1], IDSP_LDS_GRID="2")
     r = subprocess.run([sys.executable, "-m", "pytest", *SUITES, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
