@@ -497,6 +497,7 @@ int run_orders(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes,
                           (frames * R * sizeof(T)) % 16 == 0 && !cic_no_lm_tiles();
 #define IDSP_CIC_LAUNCH(NN, VV)                                                                                       \
     do {                                                                                                              \
+        note_kernel(DEC ? "cic_dec_kernel" : "cic_int_kernel");                                                                                                              \
         if constexpr (VV > 0) {                                                                                       \
             if (lm_tiles) {                                                                                           \
                 if constexpr (DEC)                                                                                    \

@@ -422,6 +422,7 @@ int idsp_cossin_i32(const int32_t *phase, int32_t *out, size_t n, void *stream)
     const bool vec = (reinterpret_cast<uintptr_t>(phase) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
     size_t blocks = (n / (vec ? 2 : 1) + 255) / 256 + 1;
     if (blocks > 8192) blocks = 8192;
+    note_kernel("cossin_kernel");
     hipLaunchKernelGGL(cossin_kernel, dim3(unsigned(blocks)), dim3(256), 0, as_stream(stream), phase,
                        reinterpret_cast<Cplx *>(out), n, vec);
     return launch_status();
@@ -434,6 +435,7 @@ int idsp_atan2_i32(const int32_t *xy, int32_t *out, size_t n, void *stream)
     const bool vec = (reinterpret_cast<uintptr_t>(xy) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
     size_t blocks = (n / (vec ? 4 : 1) + 255) / 256 + 1;
     if (blocks > 8192) blocks = 8192;
+    note_kernel("atan2_kernel");
     hipLaunchKernelGGL(atan2_kernel, dim3(unsigned(blocks)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const Cplx *>(xy), out, n, vec);
     return launch_status();

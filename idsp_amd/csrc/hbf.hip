@@ -583,6 +583,7 @@ int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state,
     const size_t bytes = size_t(lds_words) * sizeof(float);
     if (bytes > 64 * 1024)
         IDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    note_kernel(dec ? "hbf_dec_kernel (generic taps)" : "hbf_int_kernel (generic taps)");
     hipLaunchKernelGGL(kernel, dim3(unsigned(layout == IDSP_LANE_MAJOR ? lanes : 8 * ((lanes + 7) / 8))), dim3(kThreads), bytes, as_stream(stream), a,
                        static_cast<uint32_t *>(state), x, y, lanes, frames, layout == IDSP_LANE_MAJOR ? 1 : 0);
     return launch_status();
@@ -626,6 +627,7 @@ int idsp_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const flo
     a.odd = (cfg->kind == IDSP_FIR_ODD_SYMMETRIC || cfg->kind == IDSP_FIR_ODD_ANTISYMMETRIC) ? 1 : 0;
     a.sym = (cfg->kind == IDSP_FIR_ODD_SYMMETRIC || cfg->kind == IDSP_FIR_EVEN_SYMMETRIC) ? 1 : 0;
     for (int k = 0; k < IDSP_HBF_MAX_TAPS; k++) a.taps[k] = k < cfg->m ? cfg->taps[k] : 0.f;
+    note_kernel("fir_sym_kernel");
     hipLaunchKernelGGL(fir_sym_kernel, dim3(unsigned(layout == IDSP_LANE_MAJOR ? lanes : 8 * ((lanes + 7) / 8))), dim3(kThreads), 0, as_stream(stream), a,
                        static_cast<uint32_t *>(state), x, y, lanes, frames, layout == IDSP_LANE_MAJOR ? 1 : 0);
     return launch_status();

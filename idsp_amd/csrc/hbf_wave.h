@@ -24,6 +24,7 @@
 #pragma once
 
 #include <type_traits>
+#include <typeinfo>
 #include <utility>
 
 #include "common.h"
@@ -286,7 +287,11 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
     // waves per CU one 4 KiB chunk per wave left only 64-72 KiB per CU in flight and the loads alone (arithmetic removed,
     // tools/exp_hbf.sh) ran at 0.72 of the HBM peak.  Whole chunks take an unpredicated path: the per-piece `q < n`
     // tests with their exec-mask bookkeeping were ~50 of the ~500 instructions per chunk of an issue-bound kernel.
-    v4f pre[2][kPre];
+    // FRAME_MAJOR (this kernel is the fallback there; the 4-lane workgroups of hbf_dec_block_fm are the default) keeps one
+    // chunk in flight: its loads are 64-byte fragments that rely on L2 to merge neighbouring lanes, and twice as many of
+    // them in flight ran 1.72 instead of 1.4 ms at C3.
+    constexpr int kAhead = LM ? 2 : 1;
+    v4f pre[kAhead][kPre];
     auto piece = [&](size_t f0, int q) -> const v4f * {
         if constexpr (LM) {
             return reinterpret_cast<const v4f *>(x + (lane * frames + f0) * size_t(R)) + q;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
                 *reinterpret_cast<v2f *>(E0n + 2 * q) = v2f{pre[SL][i].x, pre[SL][i].z};
                 *reinterpret_cast<v2f *>(O0n + 2 * q) = v2f{pre[SL][i].y, pre[SL][i].w};
             }
-            fetch(slot, f0 + 2 * size_t(CHF));  // two chunks ahead, into the slot just emptied
+            fetch(slot, f0 + kAhead * size_t(CHF));  // kAhead chunks ahead, into the slot just emptied
             lds_wave_sync();
             dec_chunk<C, true>(lds, kCH, yg, ystride, lid, roll);
         } else {
@@ -351,10 +356,14 @@ __global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x,
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     fetch(S0{}, 0);
-    fetch(S1{}, size_t(CHF));
-    for (size_t f0 = 0; f0 < frames; f0 += 2 * size_t(CHF)) {
-        chunk(S0{}, f0);
-        if (f0 + CHF < frames) chunk(S1{}, f0 + CHF);
+    if constexpr (kAhead == 2) {
+        fetch(S1{}, size_t(CHF));
+        for (size_t f0 = 0; f0 < frames; f0 += 2 * size_t(CHF)) {
+            chunk(S0{}, f0);
+            if (f0 + CHF < frames) chunk(S1{}, f0 + CHF);
+        }
+    } else {
+        for (size_t f0 = 0; f0 < frames; f0 += size_t(CHF)) chunk(S0{}, f0);
     }
 
     static_for<0, S>([&](auto s) {
@@ -692,6 +701,7 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
     using C = Casc<TS, S, DEC>;
     const dim3 grid{unsigned(lm ? lanes : 8 * ((lanes + 7) / 8))}, block{unsigned(kW)};
     if (lm) {
+        note_kernel(DEC ? "hbf_dec_wave[LaneMajor]" : "hbf_int_wave[LaneMajor]", typeid(C).name());
         if constexpr (DEC)
             hipLaunchKernelGGL((hbf_dec_wave<C, true>), grid, block, 0, stream, st, x, y, lanes, frames);
         else
@@ -702,36 +712,28 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + 2 * (kCH / C::rate) * kBlkLanes) * sizeof(float);
                 static const bool use_block = !diag_env("IDSP_HBF_NO_BLOCK_FM");
                 if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
-                    static bool attr_done = false;
-                    if (!attr_done) {
-                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(hbf_dec_block_fm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                int(bytes)) != hipSuccess)
-                            return 1;
-                        attr_done = true;
-                    }
+                    if (ensure_dyn_lds(hbf_dec_block_fm<C>, bytes)) return 1;  // once per device (common.h)
                     const size_t ngroups = lanes / kBlkLanes;
+                    note_kernel("hbf_dec_block_fm", typeid(C).name());
                     hipLaunchKernelGGL((hbf_dec_block_fm<C>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(kBlkLanes * kW), bytes, stream,
                                        st, x, y, lanes, frames);
                     return 0;
                 }
+                note_kernel("hbf_dec_wave[FrameMajor]", typeid(C).name());
                 hipLaunchKernelGGL((hbf_dec_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
             }
             else {
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + size_t(kBlkLanes) * kCH) * sizeof(float);
                 static const bool use_block = !diag_env("IDSP_HBF_NO_BLOCK_FM");
                 if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
-                    static bool attr_done = false;
-                    if (!attr_done) {
-                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(hbf_int_block_fm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                int(bytes)) != hipSuccess)
-                            return 1;
-                        attr_done = true;
-                    }
+                    if (ensure_dyn_lds(hbf_int_block_fm<C>, bytes)) return 1;  // once per device (common.h)
                     const size_t ngroups = lanes / kBlkLanes;
+                    note_kernel("hbf_int_block_fm", typeid(C).name());
                     hipLaunchKernelGGL((hbf_int_block_fm<C>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(kBlkLanes * kW), bytes, stream,
                                        st, x, y, lanes, frames);
                     return 0;
                 }
+                note_kernel("hbf_int_wave[FrameMajor]", typeid(C).name());
                 hipLaunchKernelGGL((hbf_int_wave<C, false>), grid, block, 0, stream, st, x, y, lanes, frames);
             }
         } else {

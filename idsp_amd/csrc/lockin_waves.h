@@ -212,6 +212,7 @@ int launch_lockin_waves_in(const LpParams &p, uint32_t *st, const int32_t *x, ty
                            size_t frames, int waves, hipStream_t s)
 {
     const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
+    note_kernel(waves == 6 ? "lockin_waves_kernel[6 waves per 64 lanes]" : "lockin_waves_kernel[4 waves per 64 lanes]");
     if (waves == 6)
         hipLaunchKernelGGL((lockin_waves_kernel<N, K, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
     else
