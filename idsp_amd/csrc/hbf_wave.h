@@ -37,7 +37,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kW = 64;      // threads per workgroup = one wave
-constexpr int kCH = 1024;   // high-rate samples per chunk
+#ifndef IDSP_HBF_CH
+#define IDSP_HBF_CH 1024
+#endif
+constexpr int kCH = IDSP_HBF_CH;   // high-rate samples per chunk (C3 LaneMajor: 512 -> 1.06 ms, 1024 -> 0.906, 2048 -> 0.904 at half the occupancy: tools/exp_hbf.sh)
 constexpr int kSlack = 8;   // words readable past the last valid sample of a stream
 
 constexpr int pad4(int h) { return (4 - h % 4) % 4; }
