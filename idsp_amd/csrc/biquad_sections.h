@@ -361,7 +361,7 @@ struct Chain {
     static constexpr int LDS_WORDS = 0;
     static constexpr int IN_DIV = 1;
     static constexpr int COST = N * Sec::COST;
-    static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
+    static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 4;  // N >= 2: tools/tune_lds.hip (worst placement 0.75-0.77 against 0.68 at 8 tiles for N = 2)
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
@@ -400,6 +400,7 @@ struct CascadeDf1 {
     static constexpr int IN_DIV = 1;
     static constexpr bool kFloat = std::is_floating_point<T>::value;
     static constexpr int COST = N * (std::is_same<T, float>::value ? 24 : (kFloat ? 60 : 50));
+    static constexpr int LDS_RING = 4;  // tools/tune_lds.hip: worst placement 0.76-0.78 (N = 2) against 0.67-0.68 at 8 tiles
     using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32,
                                            typename std::conditional<kFloat, SecF64, SecI32>::type>::type;
     using Params = ChainParams<SecT, N>;
@@ -496,7 +497,7 @@ struct ChainByLane {
     static constexpr int LDS_WORDS = 0;
     static constexpr int IN_DIV = 1;
     static constexpr int COST = N * Sec::COST;
-    static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 8;
+    static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 4;  // N >= 2: tools/tune_lds.hip (worst placement 0.75-0.77 against 0.68 at 8 tiles for N = 2)
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     static constexpr int CV = Sec::kClamp ? 8 : 5;
     using Params = ByLaneParams;

@@ -82,16 +82,23 @@ void sweep(const char *name, const typename P::Params &prm, const Bufs &b)
     combo<P, 8, true>(name, prm, b);
 }
 
+template <class SecP, int N>
+bq::ChainParams<SecP, N> params_n()
+{
+    bq::ChainParams<SecP, N> p{};
+    for (int k = 0; k < N; k++) {
+        if constexpr (std::is_same<SecP, bq::SecI32>::value) {
+            p.sec[k] = {{1 << 20, 1 << 21, 1 << 20, 1 << 30, -(1 << 29)}, 30, 3, -(1 << 30), 1 << 30};
+        } else {
+            p.sec[k] = {{0.001f, 0.002f, 0.001f, 1.9f, -0.91f}, 0.01f, -10.f, 10.f};
+        }
+    }
+    return p;
+}
 template <class Sec>
 bq::ChainParams<typename Sec::Sec, 1> params()
 {
-    bq::ChainParams<typename Sec::Sec, 1> p{};
-    if constexpr (std::is_same<typename Sec::T, int32_t>::value) {
-        p.sec[0] = {{1 << 20, 1 << 21, 1 << 20, 1 << 30, -(1 << 29)}, 30, 3, -(1 << 30), 1 << 30};
-    } else {
-        p.sec[0] = {{0.001f, 0.002f, 0.001f, 1.9f, -0.91f}, 0.01f, -10.f, 10.f};
-    }
-    return p;
+    return params_n<typename Sec::Sec, 1>();
 }
 
 int main(int argc, char **argv)
@@ -103,9 +110,9 @@ int main(int argc, char **argv)
     b.yadj = b.x + n;
     b.y48 = b.x + n + 49152;
     CK(hipMalloc(&b.yown, n));
-    CK(hipMalloc(&b.st, kLanes * 64));
+    CK(hipMalloc(&b.st, kLanes * 256));
     CK(hipMemset(b.x, 1, n));
-    CK(hipMemset(b.st, 0, kLanes * 64));
+    CK(hipMemset(b.st, 0, kLanes * 256));
     int k = 0;
 #define SWEEP(SEC) if (only < 0 || only == k) sweep<bq::Chain<bq::SEC, 1>>(#SEC, params<bq::SEC>(), b); k++;
     SWEEP(Df1I32<false>)
@@ -120,5 +127,15 @@ int main(int argc, char **argv)
     SWEEP(Df2tF32<true>)
     SWEEP(NormalI32)
     SWEEP(NormalF32)
+#define SWEEPN(SEC, N) if (only < 0 || only == k) sweep<bq::Chain<bq::SEC, N>>(#SEC " x" #N, params_n<bq::SEC::Sec, N>(), b); k++;
+    SWEEPN(Df1I32<false>, 2)
+    SWEEPN(Df1F32<false>, 2)
+    SWEEPN(Df1F32<false>, 4)
+    SWEEPN(Df2tF32<false>, 2)
+    SWEEPN(Df2tF32<false>, 4)
+#define SWEEPC(T, SECP, N) if (only < 0 || only == k) sweep<bq::CascadeDf1<T, N>>("CascadeDf1<" #T "> x" #N, params_n<bq::SECP, N>(), b); k++;
+    SWEEPC(int32_t, SecI32, 2)
+    SWEEPC(float, SecF32, 2)
+    SWEEPC(float, SecF32, 4)
     return 0;
 }
