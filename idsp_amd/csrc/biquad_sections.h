@@ -74,6 +74,7 @@ struct Df1I32 {
     static constexpr bool kClamp = CLAMP;
     static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements (plain: 5, 6, 7 within 1.5 %)
     static constexpr bool LDS_RUN = false;
+    static constexpr int LDS_MAX_N = 3;     // serial sections up to which the LDS-DMA kernel beats the register window
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 4;  // x0 x1 y0 y1
@@ -96,6 +97,7 @@ struct DitherI32 {
     static constexpr bool kClamp = CLAMP;
     static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = false;
+    static constexpr int LDS_MAX_N = 2;     // serial sections up to which the LDS-DMA kernel beats the register window
     using T = int32_t;
     using Sec = SecI32;
     static constexpr int W = 5;  // x0 x1 y0 y1 e
@@ -124,6 +126,7 @@ struct WideI32 {
     using T = int32_t;
     static constexpr int LDS_RING = CLAMP ? 4 : 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = !CLAMP;
+    static constexpr int LDS_MAX_N = 2;     // serial sections up to which the LDS-DMA kernel beats the register window
     using Sec = SecI32;
     static constexpr int W = 6;  // x0 x1 y0.lo y0.hi y1.lo y1.hi
     static constexpr int COST = 100;
@@ -160,6 +163,7 @@ struct Df1F32 {
     static constexpr bool kClamp = CLAMP;
     static constexpr int LDS_RING = CLAMP ? 4 : 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = false;
+    static constexpr int LDS_MAX_N = 2;     // serial sections up to which the LDS-DMA kernel beats the register window
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 4;
@@ -186,6 +190,7 @@ struct Df2tF32 {
     static constexpr bool kClamp = CLAMP;
     static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = false;
+    static constexpr int LDS_MAX_N = 2;     // serial sections up to which the LDS-DMA kernel beats the register window
     using T = float;
     using Sec = SecF32;
     static constexpr int W = 2;  // s0 s1
@@ -264,6 +269,7 @@ struct NormalI32 {
     using T = int32_t;
     static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = true;
+    static constexpr int LDS_MAX_N = 2;     // serial sections up to which the LDS-DMA kernel beats the register window
     using Sec = SecI32;
     static constexpr bool kClamp = false;
     static constexpr int W = 4;
@@ -289,6 +295,7 @@ struct NormalF32 {
     using T = float;
     static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = true;
+    static constexpr int LDS_MAX_N = 2;     // serial sections up to which the LDS-DMA kernel beats the register window
     using Sec = SecF32;
     static constexpr bool kClamp = false;
     static constexpr int W = 4;
@@ -352,6 +359,19 @@ struct SecRun<Sec, std::void_t<decltype(Sec::LDS_RUN)>> {
     static constexpr bool value = Sec::LDS_RUN;
 };
 
+// Section count up to which a chain of this section type runs faster on the LDS-DMA kernel than on the register-window
+// kernel at the C2 shape, both at their worst output placement (tools/tune_lds.hip): i32 DF1 x3 0.77 vs 0.62, x4 0.61 vs
+// 0.68; wide x2 0.73 vs 0.65; f32 DF1 / DF2T x2 0.75-0.77 vs 0.60-0.69, x3 0.70 vs 0.71, x4 0.54-0.57 vs 0.57-0.62;
+// Normal x2 0.77-0.81 vs 0.66-0.70, x4 0.51 vs 0.53.
+template <class Sec, class = void>
+struct SecLdsMaxN {
+    static constexpr int value = 0;  // f64 sections: 8-byte samples never take the LDS-DMA kernel
+};
+template <class Sec>
+struct SecLdsMaxN<Sec, std::void_t<decltype(Sec::LDS_MAX_N)>> {
+    static constexpr int value = Sec::LDS_MAX_N;
+};
+
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
 template <class Sec, int N>
 struct Chain {
@@ -363,6 +383,7 @@ struct Chain {
     static constexpr int COST = N * Sec::COST;
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 4;  // N >= 2: tools/tune_lds.hip (worst placement 0.75-0.77 against 0.68 at 8 tiles for N = 2)
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
+    static constexpr bool LDS_ELIGIBLE = N <= SecLdsMaxN<Sec>::value;
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
 
@@ -401,6 +422,9 @@ struct CascadeDf1 {
     static constexpr bool kFloat = std::is_floating_point<T>::value;
     static constexpr int COST = N * (std::is_same<T, float>::value ? 24 : (kFloat ? 60 : 50));
     static constexpr int LDS_RING = 4;  // tools/tune_lds.hip: worst placement 0.76-0.78 (N = 2) against 0.67-0.68 at 8 tiles
+    // LDS-DMA kernel against register window at the C2 shape: i32 x3 0.78 vs 0.59, x4 0.69 vs 0.65, x8 0.42 vs 0.50;
+    // f32 x2 0.76 vs 0.70, x4 0.59 vs 0.62
+    static constexpr bool LDS_ELIGIBLE = std::is_same<T, int32_t>::value ? N <= 4 : (std::is_same<T, float>::value && N <= 2);
     using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32,
                                            typename std::conditional<kFloat, SecF64, SecI32>::type>::type;
     using Params = ChainParams<SecT, N>;
@@ -499,6 +523,7 @@ struct ChainByLane {
     static constexpr int COST = N * Sec::COST;
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 4;  // N >= 2: tools/tune_lds.hip (worst placement 0.75-0.77 against 0.68 at 8 tiles for N = 2)
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
+    static constexpr bool LDS_ELIGIBLE = N <= SecLdsMaxN<Sec>::value;
     static constexpr int CV = Sec::kClamp ? 8 : 5;
     using Params = ByLaneParams;
     uint32_t s[N][Sec::W];

@@ -276,6 +276,15 @@ constexpr int kLdsT = 8;    // frames per tile
 constexpr int kLdsNB = 8;
 // Largest non-persistent grid of the LDS-DMA kernel; launches with more workgroups walk their lane blocks persistently.
 constexpr size_t kLdsGridCap = 384;
+// LDS-DMA path or register-window kernel (launch_stream): P::LDS_ELIGIBLE if the processor declares it, else COST <= 120.
+template <class P, class = void>
+struct LdsEligibleOf {
+    static constexpr bool value = P::COST <= 120;
+};
+template <class P>
+struct LdsEligibleOf<P, std::void_t<decltype(P::LDS_ELIGIBLE)>> {
+    static constexpr bool value = P::LDS_ELIGIBLE;
+};
 // Largest lanes-per-thread factor the LDS-DMA kernel is instantiated with for a processor (P::LDS_LPT_MAX; 1 = only
 // the one-lane-per-thread form).  Each step doubles the processor's state registers.
 template <class P, class = void>
@@ -656,11 +665,16 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         if constexpr (P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4) {
             // cheap per-sample arithmetic (the extra LDS hop and the two barriers per tile cost issue
             // slots), whole 256-lane blocks, 16-byte aligned rows: LDS-DMA path
+            // Which processors take the LDS-DMA path: P::LDS_ELIGIBLE where the processor says so (measured per section type
+            // and section count against the register-window kernel, tools/tune_lds.hip, profiles/r02_tune_lds_heavy*.jsonl),
+            // else the cost estimate; IDSP_DIAG=1 IDSP_LDS_COST=n replaces both by `COST <= n`.
+            static const bool cost_forced = diag_env("IDSP_LDS_COST") != nullptr;
             static const int lds_cost_max = int(diag_size("IDSP_LDS_COST", 120));
+            const bool eligible = cost_forced ? P::COST <= lds_cost_max : LdsEligibleOf<P>::value;
             static const size_t lds_max_waves = diag_size("IDSP_LDS_MAX_WAVES", size_t(1) << 40);
             static const bool no_lds = diag_env("IDSP_NO_LDS_PATH") != nullptr;
             constexpr size_t ow = sizeof(typename P::Out) / 4;
-            if (!no_lds && P::COST <= lds_cost_max && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 &&
+            if (!no_lds && eligible && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 &&
                 reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && (yl * ow) % 4 == 0) {
                 // Grid (profiles/r02_exp_c5_*.jsonl).  Up to 384 workgroups: one per 256-lane block.  Beyond: a persistent
                 // grid of <= 256 workgroups (one per CU) that walks the lane blocks in column panels of equal rounds —

@@ -46,6 +46,28 @@ float run1(const typename P::Params &prm, uint32_t *st, const typename P::In *x,
     return ts[ts.size() / 2];
 }
 
+// the register-window kernel the launcher uses for processors above the LDS cost limit (same four placements)
+template <class P>
+float run_regwin(const typename P::Params &prm, uint32_t *st, const typename P::In *x, typename P::Out *y)
+{
+    constexpr int U = MaxU<P>::value;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    std::vector<float> ts;
+    for (int i = 0; i < 50; i++) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((stream_frame_major<P, U>), dim3(kLanes / kFmBlock), dim3(kFmBlock), 0, 0, prm, st, x, y, kLanes, kFrames, kLanes, kLanes);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (i >= 30) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
 struct Bufs {
     char *x, *yadj, *yown, *y48;
     uint32_t *st;
@@ -70,6 +92,18 @@ void combo(const char *name, const typename P::Params &prm, const Bufs &b)
 template <class P>
 void sweep(const char *name, const typename P::Params &prm, const Bufs &b)
 {
+    {
+        using In = typename P::In;
+        using Out = typename P::Out;
+        const float t0 = run_regwin<P>(prm, b.st, reinterpret_cast<const In *>(b.x), reinterpret_cast<Out *>(b.yadj));
+        const float t1 = run_regwin<P>(prm, b.st, reinterpret_cast<const In *>(b.x), reinterpret_cast<Out *>(b.yown));
+        const float t2 = run_regwin<P>(prm, b.st, reinterpret_cast<const In *>(b.x), reinterpret_cast<Out *>(b.y48));
+        const float t3 = run_regwin<P>(prm, b.st, reinterpret_cast<const In *>(b.x), reinterpret_cast<Out *>(b.x));
+        const double gb = double(kLanes) * kFrames * 8 / 1e9;
+        const float worst = std::max(std::max(t0, t1), std::max(t2, t3)), best = std::min(std::min(t0, t1), std::min(t2, t3));
+        printf("{\"proc\": \"%s\", \"nb\": 0, \"run\": -1, \"kernel\": \"register window\", \"ms\": [%.4f, %.4f, %.4f, %.4f], \"worst_frac\": %.3f, \"best_frac\": %.3f}\n", name,
+               t0, t1, t2, t3, gb / (worst * 1e-3) / 8000, gb / (best * 1e-3) / 8000);
+    }
     combo<P, 4, false>(name, prm, b);
     combo<P, 5, false>(name, prm, b);
     combo<P, 6, false>(name, prm, b);
@@ -137,5 +171,17 @@ int main(int argc, char **argv)
     SWEEPC(int32_t, SecI32, 2)
     SWEEPC(float, SecF32, 2)
     SWEEPC(float, SecF32, 4)
+    SWEEPN(Df1I32<false>, 3)
+    SWEEPN(Df1I32<false>, 4)
+    SWEEPN(Df1I32<true>, 2)
+    SWEEPN(WideI32<false>, 2)
+    SWEEPC(int32_t, SecI32, 3)
+    SWEEPC(int32_t, SecI32, 4)
+    SWEEPC(int32_t, SecI32, 8)
+    SWEEPN(NormalI32, 2)
+    SWEEPN(DitherI32<false>, 2)
+    SWEEPN(Df1F32<false>, 3)
+    SWEEPN(NormalF32, 2)
+    SWEEPN(NormalF32, 4)
     return 0;
 }
