@@ -78,15 +78,17 @@ __device__ __forceinline__ void lds_wave_sync()
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the ABI lets one
 // process switch devices (idsp_device_set), and the attribute is per device.
-template <class K>
-inline int ensure_dyn_lds(K kernel, size_t bytes)
+// The kernel is a template ARGUMENT (not a function parameter) so that the flag below is one per kernel: kernels of
+// different processors often share one function type, and a flag per type would let the second of them skip the call.
+template <auto Kernel>
+inline int ensure_dyn_lds(size_t bytes)
 {
-    static std::atomic<uint64_t> done{0};  // one bit per device ordinal, per instantiation of this template
+    static std::atomic<uint64_t> done{0};  // one bit per device ordinal, per kernel
     int dev = 0;
     IDSP_HIP_TRY(hipGetDevice(&dev));
     const uint64_t bit = uint64_t(1) << (dev & 63);
     if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return IDSP_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
     if (e != hipSuccess) return fail(IDSP_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (dev < 64) done.fetch_or(bit, std::memory_order_release);
     return IDSP_OK;

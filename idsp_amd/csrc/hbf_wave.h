@@ -715,7 +715,7 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + 2 * (kCH / C::rate) * kBlkLanes) * sizeof(float);
                 static const bool use_block = !diag_env("IDSP_HBF_NO_BLOCK_FM");
                 if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
-                    if (ensure_dyn_lds(hbf_dec_block_fm<C>, bytes)) return 1;  // once per device (common.h)
+                    if (ensure_dyn_lds<&hbf_dec_block_fm<C>>(bytes)) return 1;  // once per device (common.h)
                     const size_t ngroups = lanes / kBlkLanes;
                     note_kernel("hbf_dec_block_fm", typeid(C).name());
                     hipLaunchKernelGGL((hbf_dec_block_fm<C>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(kBlkLanes * kW), bytes, stream,
@@ -729,7 +729,7 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + size_t(kBlkLanes) * kCH) * sizeof(float);
                 static const bool use_block = !diag_env("IDSP_HBF_NO_BLOCK_FM");
                 if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
-                    if (ensure_dyn_lds(hbf_int_block_fm<C>, bytes)) return 1;  // once per device (common.h)
+                    if (ensure_dyn_lds<&hbf_int_block_fm<C>>(bytes)) return 1;  // once per device (common.h)
                     const size_t ngroups = lanes / kBlkLanes;
                     note_kernel("hbf_int_block_fm", typeid(C).name());
                     hipLaunchKernelGGL((hbf_int_block_fm<C>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(kBlkLanes * kW), bytes, stream,

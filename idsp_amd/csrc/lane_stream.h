@@ -717,7 +717,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     constexpr bool RUN = DEEP ? false : LdsRunOf<P>::value;
                     constexpr size_t ts = L > kLdsT ? L : kLdsT;
                     constexpr size_t bytes = (size_t(NB) * ts * kFmBlock + 2 * ts * kFmBlock * ow + P::LDS_WORDS) * 4;
-                    if ((rc = ensure_dyn_lds(stream_frame_major_lds<P, NB, L, RUN>, bytes))) return;
+                    if ((rc = ensure_dyn_lds<&stream_frame_major_lds<P, NB, L, RUN>>(bytes))) return;
                     note_kernel(L == 1 ? "stream_frame_major_lds" : L == 2 ? "stream_frame_major_lds[2 lanes/thread]" : "stream_frame_major_lds[4 lanes/thread]",
                                 typeid(P).name());
                     hipLaunchKernelGGL((stream_frame_major_lds<P, NB, L, RUN>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s,
