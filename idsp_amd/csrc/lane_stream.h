@@ -625,6 +625,172 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
     if (active) p.store(prm, st, lanes, vlane);
 }
 
+// ------------------------------------------- LANE_MAJOR, 16-byte pieces (staged)
+// The kernel above moves a lane's row as 4-byte pieces (one 256-byte run of ONE lane per instruction): 64 loads, 64
+// stores and 256 LDS accesses per 64 x 64 tile, all on the issue path of a single wave, and it asks HBM for 256-byte
+// runs per lane.  This form moves 512-byte runs per lane with 16 bytes per thread in both directions:
+//   * a tile is 64 lanes x kLmRun bytes (TF = 128 / W frames of W words, PCS = 32 pieces per lane); load instruction j
+//     of a tile fetches the runs of the G = 2 lanes j and j + 32 — 32 threads per run — into VGPRs, and the whole tile
+//     is handed to one 32 KiB LDS slot with linear ds_write_b128 (thread t's piece of instruction j at 1024 j + 16 t, so
+//     lane l sits in slot row (l % PCS) G + l / PCS).  WHICH piece of the run a thread fetches is free: thread t takes
+//     piece (t % PCS) ^ (j % 16), so the row of lane l holds piece k at 16 (k ^ (l % 16)) and the owning thread's
+//     ds_read_b128 column walk is bank-conflict free without padding;
+//   * thread l reads its pieces, runs the steps in registers, writes the results over the same pieces; the wave then
+//     re-reads the slot linearly and stores whole runs.  The NEXT tile's loads are issued right after the hand-over,
+//     so they are in flight during the arithmetic and the stores (the compiler counts them: plain loads).
+//     Per 64 x 128 samples: 32 loads + 128 LDS + 32 stores instead of 128 + 512 + 128.
+// What the run length is worth at 65536 lanes x 4096 frames (tools/tune_lm.hip, profiles/r02_tune_lm.jsonl; same
+// arithmetic, i32 DF1): 128-byte runs 0.54 of the HBM peak whatever the prefetch depth, 256-byte 0.56-0.58, 512-byte
+// 0.65-0.70 (this kernel; the 4-byte tile kernel 0.60-0.64), 1 KiB runs no better at the two waves per CU their LDS
+// allows.  An LDS-DMA twin (global_load_lds_dwordx4 rings of 1-4 slots) ran the same rates per run length: the bound
+// is the access pattern (65536 concurrent streams of short runs 16 KiB apart), not latency or issue.
+// One wave per workgroup, no barriers.  Needs 16-byte aligned rows (base and pitch).  A last partial tile moves its
+// whole 16-byte pieces the same way; the final frames % (4 / W) samples of every lane go sample by sample.  x == y is
+// safe (a tile is stored after it has been read; the rows of one wave are touched by no other).
+constexpr int kLmRun = 512;  // bytes per lane and tile
+template <class P, class = void>
+struct LmStagedOf {
+    static constexpr bool value = false;
+};
+template <class P>
+struct LmStagedOf<P, std::enable_if_t<P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == sizeof(typename P::Out) &&
+                                      (sizeof(typename P::In) == 4 || sizeof(typename P::In) == 8) && BatchOf<P>::value == 1>> {
+    static constexpr bool value = true;
+};
+
+template <class P>
+__global__ __launch_bounds__(kWave) void stream_lane_major_staged(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    static_assert(LmStagedOf<P>::value, "one input and one output of the same 4- or 8-byte size per lane and frame");
+    constexpr int LB = kLmRun;
+    constexpr int W = sizeof(In) / 4;        // words per sample
+    constexpr int TF = LB / 4 / W;           // frames per tile
+    constexpr int PCS = LB / 16;             // 16-byte pieces per lane and tile = load / store instructions per tile
+    constexpr int G = kWave / PCS;           // lanes per instruction
+    constexpr int SWM = (PCS < 16 ? PCS : 16) - 1;  // swizzle mask
+    constexpr int SPP = 4 / W;               // samples per piece
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *ptab = smem + kWave * LB / 4;  // [P::LDS_WORDS]
+    const int lid = threadIdx.x;
+
+    const size_t lane0 = size_t(blockIdx.x) * kWave;
+    const size_t nrows = lanes - lane0 < size_t(kWave) ? lanes - lane0 : size_t(kWave);
+    const bool active = size_t(lid) < nrows;
+
+    P p;
+    if constexpr (P::LDS_WORDS > 0) {
+        P::fill_shared(ptab, lid, kWave);
+        lds_wave_sync();
+        p.set_shared(ptab);
+    }
+    if (active) p.load(prm, st, lanes, lane0 + lid);
+
+    // mover role of this thread: in instruction j, lane mq + j of the tile, piece mpc ^ (j & SWM) of its run
+    const int mq = (lid / PCS) * PCS, mpc = lid % PCS;
+    const uint32_t *xq = reinterpret_cast<const uint32_t *>(x) + (lane0 + mq) * xl * W;
+    uint32_t *yq = reinterpret_cast<uint32_t *>(y) + (lane0 + mq) * yl * W;
+    const size_t xrow = xl * W, yrow = yl * W;  // words between lanes
+    // owner role: slot row of this thread's lane, and the byte offset of its piece k = own ^ (16 k)
+    const uint32_t own = uint32_t((lid % PCS) * G + lid / PCS) * LB + uint32_t(lid & SWM) * 16;
+    char *const slot = reinterpret_cast<char *>(smem);
+
+    const size_t nfull = frames / TF;
+    const int ntail = int((frames - nfull * TF) / SPP);  // whole pieces of the last, partial tile
+    u32x4 stage[PCS];
+    // WHOLE: all 64 lanes of the wave exist; FULL: all PCS pieces of the tile exist (else np of them)
+    auto fetch = [&](size_t v, auto whole, auto full, int np) __attribute__((always_inline)) {
+        const uint32_t *src = xq + v * (TF * W);
+#pragma unroll
+        for (int j = 0; j < PCS; j++) {
+            const int pc = mpc ^ (j & SWM);
+            if ((decltype(whole)::value || size_t(mq + j) < nrows) && (decltype(full)::value || pc < np))
+                stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * xrow + pc * 4));
+        }
+    };
+    auto hand_over = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PCS; j++) *reinterpret_cast<u32x4 *>(slot + j * 1024 + lid * 16) = stage[j];
+    };
+    auto piece = [&](int k) __attribute__((always_inline)) {
+        u32x4 *q = reinterpret_cast<u32x4 *>(slot + (own ^ uint32_t(k * 16)));
+        u32x4 v = *q;
+#pragma unroll
+        for (int s = 0; s < SPP; s++) {
+            uint32_t w[W];
+#pragma unroll
+            for (int h = 0; h < W; h++) w[h] = v[s * W + h];
+            const Out o = step1(p, prm, words_to<In>(w));
+            to_words<Out>(o, w);
+#pragma unroll
+            for (int h = 0; h < W; h++) v[s * W + h] = w[h];
+        }
+        *q = v;
+    };
+    auto compute = [&](auto full, int np) __attribute__((always_inline)) {
+        if (!active) return;
+        if constexpr (!decltype(full)::value || MaxU<P>::value < 24) {
+            for (int k = 0; k < np; k++) piece(k);  // partial tile, or a large body: keep the loop rolled
+        } else {
+#pragma unroll
+            for (int k = 0; k < PCS; k++) piece(k);
+        }
+    };
+    auto store = [&](size_t v, auto whole, auto full, int np) __attribute__((always_inline)) {
+        uint32_t *dst = yq + v * (TF * W);
+#pragma unroll
+        for (int j = 0; j < PCS; j++) {
+            const int pc = mpc ^ (j & SWM);
+            const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
+            if ((decltype(whole)::value || size_t(mq + j) < nrows) && (decltype(full)::value || pc < np))
+                __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst + j * yrow + pc * 4));
+        }
+    };
+    auto walk = [&](auto whole) __attribute__((always_inline)) {
+        using Full = std::true_type;
+        using Part = std::false_type;
+        if (nfull > 0)
+            fetch(0, whole, Full{}, PCS);
+        else
+            fetch(0, whole, Part{}, ntail);
+        for (size_t i = 0; i < nfull; i++) {
+            hand_over();
+            lds_wave_sync();
+            if (i + 1 < nfull)
+                fetch(i + 1, whole, Full{}, PCS);
+            else if (ntail > 0)
+                fetch(i + 1, whole, Part{}, ntail);
+            compute(Full{}, PCS);
+            lds_wave_sync();
+            store(i, whole, Full{}, PCS);
+            lds_wave_sync();
+        }
+        if (ntail > 0) {
+            hand_over();
+            lds_wave_sync();
+            compute(Part{}, ntail);
+            lds_wave_sync();
+            store(nfull, whole, Part{}, ntail);
+        }
+    };
+    if (nrows == size_t(kWave))
+        walk(std::true_type{});
+    else
+        walk(std::false_type{});
+
+    if (active) {  // the last frames % SPP samples of this lane's own row
+        const In *xr = x + (lane0 + lid) * xl;
+        Out *yr = y + (lane0 + lid) * yl;
+        for (size_t f = nfull * TF + size_t(ntail) * SPP; f < frames; f++) yr[f] = step1(p, prm, xr[f]);
+        p.store(prm, st, lanes, lane0 + lid);
+    }
+}
+
 // --------------------------------------------------------------------- launch
 // Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
 // latency, so go deep; with many resident waves keep the register budget low.
@@ -657,6 +823,20 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
     if (layout == IDSP_LANE_MAJOR) {
         const size_t xl = pitch.x ? pitch.x : frames, yl = pitch.y ? pitch.y : frames;
         const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
+        if constexpr (LmStagedOf<P>::value) {
+            // 16-byte pieces need 16-byte aligned rows; below a quarter tile of frames the 4-byte tile kernel has less to set up
+            // (IDSP_DIAG=1 IDSP_NO_LM_STAGED=1: always the tile kernel)
+            static const bool no_staged = diag_env("IDSP_NO_LM_STAGED") != nullptr;
+            constexpr size_t sz = sizeof(typename P::In);
+            if (!no_staged && frames * sz >= size_t(kLmRun) / 4 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                reinterpret_cast<uintptr_t>(y) % 16 == 0 && (xl * sz) % 16 == 0 && (yl * sz) % 16 == 0) {
+                const size_t bytes = size_t(kWave) * kLmRun + P::LDS_WORDS * 4;
+                if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P>>(bytes)) return rc;
+                note_kernel("stream_lane_major_staged", typeid(P).name());
+                hipLaunchKernelGGL((stream_lane_major_staged<P>), dim3(grid), dim3(kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl);
+                return launch_status();
+            }
+        }
         note_kernel("stream_lane_major", typeid(P).name());
         hipLaunchKernelGGL((stream_lane_major<P>), dim3(grid), dim3(kWave), 0, s, prm, st, x, y, lanes, frames, xl, yl);
     } else {

@@ -1,0 +1,128 @@
+"""LANE_MAJOR on the staged 16-byte-piece kernel (`stream_lane_major_staged`, idsp_amd/csrc/lane_stream.h): every
+biquad-family entry (1- and 2-word samples), ragged lane counts (partial last wave), every kind of frame count — whole
+512-byte tiles, a partial last tile of whole 16-byte pieces, a scalar remainder of frames % (4 / words) samples — padded
+rows, out of place and in place, against the oracle bit for bit; the kernel taken is asserted through
+`idsp_last_kernel()`.  Rows that are not 16-byte aligned must fall back to the 4-byte tile kernel with the same result.
+Reference semantics: one independent filter per lane over its own contiguous row (`View<LaneMajor>`,
+dsp-process/src/view.rs:181-195; `Lanes::process`, dsp-process/src/compose.rs:468-494)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import _harness as H
+from tests.test_gpu_pitch import DEV, SENT, cases, init_state, p, sample, tdtype
+
+pytestmark = pytest.mark.gpu
+LM = H.LM
+
+# (lanes, frames, pitch): pitch * sizeof(sample) is a multiple of 16 in every case
+SHAPES = [
+    (64, 128, 128), (64, 256, 256), (1, 128, 128), (63, 384, 384), (65, 129, 132), (130, 131, 132), (257, 77, 80),
+    (1000, 513, 516), (64, 1025, 1028), (100, 36, 36), (7, 32, 48), (192, 640, 644), (300, 127, 128), (129, 255, 260),
+]
+
+
+def kernel_of(eng):
+    return eng.fn["last_kernel"]().decode()
+
+
+def run_case(eng, op, cfg, n, words, dt, rng, lanes, frames, pitch, inplace):
+    o = H.oracle()
+    xh = sample(rng, dt, lanes * frames).reshape(lanes, frames)
+    want = np.empty_like(xh)
+    st0 = init_state(rng, dt, words * n, lanes)
+    so = st0.copy()
+    assert o.stream(op, cfg, n, so, xh, want, lanes, frames, LM) == 0
+    t = tdtype(dt)
+    xb = torch.full((lanes * pitch,), SENT, dtype=t, device=DEV)
+    xb.view(lanes, pitch)[:, :frames] = torch.from_numpy(xh).to(DEV)
+    yb = xb if inplace else torch.full((lanes * pitch,), SENT, dtype=t, device=DEV)
+    sg = torch.from_numpy(st0.view(np.int32)).to(DEV)
+    rc = eng.fn[op + "_pitch"](C.cast(cfg, C.c_void_p), n, p(sg), p(xb), pitch, p(yb), pitch, lanes, frames, LM, None)
+    torch.cuda.synchronize()
+    assert rc == 0, (op, eng.err())
+    yv = yb.view(lanes, pitch)
+    got = yv[:, :frames].cpu().numpy()
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (op, lanes, frames, pitch, inplace)
+    assert np.array_equal(sg.cpu().numpy().view(np.uint32), so), (op, lanes, frames, "state")
+    assert (yv[:, frames:] == SENT).all(), (op, "row padding must stay untouched")
+
+
+def test_every_biquad_entry_on_the_staged_kernel(gpu):
+    rng = np.random.default_rng(77)
+    for op, cfg, n, words, dt in cases(rng):
+        for lanes, frames, pitch in SHAPES:
+            for inplace in (False, True):
+                run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, inplace)
+                k = kernel_of(gpu)
+                staged = frames * np.dtype(dt).itemsize >= 128
+                assert k.startswith("stream_lane_major_staged<" if staged else "stream_lane_major<"), (op, lanes, frames, k)
+
+
+def test_cascades_normal_lowpass_on_the_staged_kernel(gpu):
+    """The other one-in / one-out per-lane processors of the path that share the LANE_MAJOR launcher."""
+    from tests._backends import GpuBackend, OracleBackend
+    ob, gb = OracleBackend(), GpuBackend()
+    rng = np.random.default_rng(78)
+    rows = [(rng.integers(-(1 << 29), 1 << 29, size=5).tolist(), 29) for _ in range(8)]
+    frows = [(rng.standard_normal(5) * 0.3).tolist() for _ in range(8)]
+    for lanes, frames in ((130, 132), (64, 1028), (1000, 516), (63, 128)):
+        xi = rng.integers(-(1 << 31), (1 << 31) - 1, size=lanes * frames, dtype=np.int64).astype(np.int32)
+        xf = rng.standard_normal(lanes * frames).astype(np.float32)
+        xd = rng.standard_normal(lanes * frames)
+        todo = [
+            ("cascade_i32_df1", H.biquad_i32(rows), 8, 18, xi), ("cascade_i32_df1", H.biquad_i32(rows[:3]), 3, 8, xi),
+            ("cascade_f32_df1", H.biquad_f32(frows[:4]), 4, 10, xf), ("cascade_f64_df1", H.biquad_f64(frows[:2]), 2, 12, xd),
+            ("normal_i32_df1", H.biquad_i32(rows[:2]), 2, 8, xi), ("normal_f32_df1", H.biquad_f32(frows[:1]), 1, 4, xf),
+        ]
+        for op, cfg, n, words, x in todo:
+            for inplace in (False, True):
+                if x.dtype == np.int32:
+                    init = rng.integers(0, 1 << 32, size=(words, lanes), dtype=np.uint64).astype(np.uint32)
+                elif x.dtype == np.float32:
+                    init = rng.standard_normal(size=(words, lanes)).astype(np.float32).view(np.uint32)
+                else:
+                    init = init_state(rng, np.float64, words, lanes)
+                so, sg = init.copy(), init.copy()
+                rco, yo = ob.stream(op, cfg, n, so, x.copy(), lanes, frames, LM, inplace=inplace)
+                rcg, yg = gb.stream(op, cfg, n, sg, x.copy(), lanes, frames, LM, inplace=inplace)
+                assert rco == 0 and rcg == 0, (op, H.engine().err())
+                assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), (op, kernel_of(H.engine()))
+                assert np.array_equal(yo.view(np.uint8), yg.view(np.uint8)) and np.array_equal(so, sg), (op, lanes, frames, inplace)
+        # Lowpass<N> cascades
+        for order, casc in ((1, 1), (2, 2)):
+            ks = [[int(v) for v in rng.integers(1 << 16, 1 << 26, size=order)] for _ in range(casc)]
+            if order == 2:
+                ks = [[k[0], -abs(k[1])] for k in ks]
+            cfg = H.lockin_cfg(ks)
+            st = rng.integers(0, 1 << 32, size=(2 * order * casc, lanes), dtype=np.uint64).astype(np.uint32)
+            so, sg = st.copy(), st.copy()
+            rco, yo = ob.cfgcall("lowpass_i32", cfg, so, xi, (lanes * frames,), np.int32, lanes, frames, LM)
+            rcg, yg = gb.cfgcall("lowpass_i32", cfg, sg, xi, (lanes * frames,), np.int32, lanes, frames, LM)
+            assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), ("lowpass", order, casc)
+            assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), kernel_of(H.engine())
+
+
+def test_unaligned_rows_fall_back_to_the_tile_kernel(gpu):
+    rng = np.random.default_rng(79)
+    op, cfg, n, words, dt = cases(rng)[0]
+    for lanes, frames, pitch in ((130, 257, 257), (64, 130, 130), (65, 1001, 1003)):
+        run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, False)
+        assert kernel_of(gpu).startswith("stream_lane_major<"), kernel_of(gpu)
+    # aligned pitch, base 4 bytes off a 16-byte boundary
+    o = H.oracle()
+    lanes, frames = 70, 256
+    xh = sample(rng, dt, lanes * frames).reshape(lanes, frames)
+    want = np.empty_like(xh)
+    so = np.zeros((words * n, lanes), np.uint32)
+    assert o.stream(op, cfg, n, so, xh, want, lanes, frames, LM) == 0
+    xb = torch.zeros(lanes * frames + 4, dtype=torch.int32, device=DEV)
+    xb[1:1 + lanes * frames] = torch.from_numpy(xh.reshape(-1)).to(DEV)
+    yb = torch.zeros(lanes * frames, dtype=torch.int32, device=DEV)
+    sg = torch.zeros((words * n, lanes), dtype=torch.int32, device=DEV)
+    rc = gpu.fn[op](C.cast(cfg, C.c_void_p), n, p(sg), C.c_void_p(xb.data_ptr() + 4), p(yb), lanes, frames, LM, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and kernel_of(gpu).startswith("stream_lane_major<"), kernel_of(gpu)
+    assert np.array_equal(yb.cpu().numpy().reshape(lanes, frames), want)
