@@ -30,8 +30,12 @@ namespace {
 constexpr int kLwB = 8;     // frames per batch, FrameMajor
 constexpr int kLwBLm = 16;  // LaneMajor: 16 frames = one whole 128-byte line of 8-byte output elements per lane and batch
 enum { MODE_IQ = 0, MODE_ARG = 1, MODE_NORM_SQR = 2 };
-enum { IN_FM_REG = 0, IN_FM_DMA = 1, IN_LM_REG = 2 };
+enum { IN_FM_REG = 0, IN_FM_DMA = 1, IN_LM_REG = 2, IN_LM_DMA = 3 };
 constexpr int kLwRing = 4, kLwAhead = 3;  // LDS input ring slots, batches in flight
+#ifndef IDSP_LW_OUT_GROUP
+#define IDSP_LW_OUT_GROUP 1
+#endif
+constexpr int kLwOutGroup = IDSP_LW_OUT_GROUP;  // LaneMajor: batches a read-out thread stores together
 
 template <int MODE>
 struct LwOut {
@@ -47,11 +51,11 @@ struct LwOut<MODE_NORM_SQR> {
 };
 
 template <int N, int K, int W, int IN, int MODE, int B>
-__global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams prm, uint32_t *st, const int32_t *x,
+__global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN == IN_LM_REG || IN == IN_LM_DMA ? 2 : 10))) void lockin_waves_kernel(const LpParams prm, uint32_t *st, const int32_t *x,
                                                                  typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames)
 {
     using Out = typename LwOut<MODE>::type;
-    constexpr bool LM = IN == IN_LM_REG, DMA = IN == IN_FM_DMA;
+    constexpr bool LMD = IN == IN_LM_DMA, LM = IN == IN_LM_REG || LMD, DMA = IN == IN_FM_DMA;
     constexpr int kLut = 1 << kCossinDepth;
     constexpr int P = W - 2, C = B / P;  // read-out waves; each takes frames b = r * C + j, j < C, of a batch
     static_assert(B % P == 0 && B % 8 == 0, "batch splits evenly over the read-out waves and into 4-row DMA groups per arm wave");
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
     __shared__ uint32_t tab[32];
     __shared__ Cplx lo[2][B][kWave];
     __shared__ int32_t arm[2][2][B][kWave];  // [buffer][I/Q][frame][lane]
-    __shared__ __attribute__((aligned(16))) int32_t xs[DMA ? kLwRing : 1][B * kWave];  // [frame][lane]
+    // FM DMA: [slot][frame][lane]; LM DMA: kLwRing slots of 64 lanes x 128 bytes (two batches), rows permuted and pieces swizzled
+    __shared__ __attribute__((aligned(16))) int32_t xs[DMA ? kLwRing : LMD ? 2 * kLwRing : 1][B * kWave];
     const int w = threadIdx.x / kWave, lid = threadIdx.x % kWave;
     const bool arm_wave = w < 2;         // wave-uniform role
     const int r = arm_wave ? w : w - 2;  // arm waves: I / Q; read-out waves: frame group
@@ -104,6 +109,26 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
                    uint32_t(reinterpret_cast<uintptr_t>(&xs[n % kLwRing][r0 * kWave])));
         }
     };
+    // LaneMajor input by DMA: a pair of batches = one whole 128-byte line per lane.  Instruction j of a pair fetches the lines
+    // of lanes j, j + 8, ... (8 threads per line) so that every line is requested once, by one instruction; thread t takes
+    // piece (t % 8) ^ j, which leaves lane l's piece k at slot row (l % 8) 8 + l / 8, offset 16 (k ^ (l % 8)): the arm
+    // threads' ds_read_b128 of their own row are conflict free.  Arm wave r issues instructions 4 r .. 4 r + 3; pieces past
+    // the end of the row (odd number of batches) and pairs past the end re-read frame 0 (never consumed), so that every
+    // pair issues exactly four operations per arm wave.
+    auto dma_lm = [&](size_t pair) {
+        if constexpr (LMD) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int j = 4 * r + g;
+                size_t gl = size_t(blockIdx.x) * kWave + size_t(j + 8 * (lid / 8));
+                gl = gl < lanes ? gl : lanes - 1;
+                const size_t f = pair * 32 + size_t(((lid % 8) ^ j) * 4);
+                glds16(x + gl * frames + (f + 4 <= frames ? f : 0),
+                       uint32_t(reinterpret_cast<uintptr_t>(&xs[0][0])) + uint32_t((pair % kLwRing) * 8192 + j * 1024));
+            }
+        }
+    };
+    const uint32_t xs_own = uint32_t((lid % 8) * 8 + lid / 8) * 128 + uint32_t(lid % 8) * 16;  // LM DMA: own row, piece k at ^ 16 k
     auto lo_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < C; j++) {
@@ -121,19 +146,45 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
         else
             return int64_t(uint64_t(int64_t(re) * re) + uint64_t(int64_t(im) * im));  // wraps for (MIN, MIN) as in release
     };
-    auto out_stage = [&](size_t f0, int buf, int nb, auto full) {
+    // LaneMajor: a read-out thread keeps its pieces of kLwOutGroup batches in registers and stores them together, so that the
+    // wave leaves kLwOutGroup * 16 frames (512 bytes of Complex<i32>) per lane in one burst of store instructions
+    // instead of one 128-byte line per lane and batch (run length per lane is what the LaneMajor rate follows, see
+    // stream_lane_major_staged)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int GV = int(sizeof(Out)) * C / 16;  // 16-byte vectors a read-out thread writes per batch (LaneMajor)
+    u32x4 held[LM ? kLwOutGroup : 1][LM ? GV : 1];
+    // `slot` (static): position of the batch inside its output group; `flush`: last batch of the call
+    auto out_stage = [&](size_t f0, int buf, int nb, auto full, auto slot_tag, bool flush) {
         if constexpr (LM) {
             // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the 16 frames of one lane, so that one store
             // instruction leaves 8 * sizeof(Out) contiguous bytes per lane instead of two (four) pieces at different times
-            struct alignas(sizeof(Out) * C > 16 ? 16 : sizeof(Out) * C) Group {
-                Out v[C];
-            };
+            static_assert((sizeof(Out) * C) % 16 == 0, "a thread's piece of a batch is whole 16-byte vectors");
             const int ll = r * (kWave / P) + lid / P, part = lid % P;
             const size_t gl = size_t(blockIdx.x) * kWave + size_t(ll);
-            Group g;
+            constexpr int slot = decltype(slot_tag)::value;
+            constexpr int OW = int(sizeof(Out)) / 4;
+            uint32_t w[C * OW];
 #pragma unroll
-            for (int j = 0; j < C; j++) g.v[j] = element(buf, part * C + j, ll);
-            if (gl < lanes) *reinterpret_cast<Group *>(y + gl * frames + f0 + part * C) = g;
+            for (int j = 0; j < C; j++) {
+                const Out e = element(buf, part * C + j, ll);
+                if constexpr (OW == 1) {
+                    w[j] = __builtin_bit_cast(uint32_t, e);
+                } else {
+                    const uint64_t u = __builtin_bit_cast(uint64_t, e);
+                    w[2 * j] = uint32_t(u), w[2 * j + 1] = uint32_t(u >> 32);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < GV; v++) held[slot][v] = u32x4{w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]};
+            if (slot == kLwOutGroup - 1 || flush) {
+                u32x4 *dst = reinterpret_cast<u32x4 *>(y + gl * frames + (f0 - size_t(slot) * B) + part * C);
+#pragma unroll
+                for (int q = 0; q <= slot; q++)
+                    if (gl < lanes) {
+#pragma unroll
+                        for (int v = 0; v < GV; v++) dst[q * (B * int(sizeof(Out)) / 16) + v] = held[q][v];
+                    }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < C; j++) {
@@ -145,7 +196,7 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
             }
         }
     };
-    auto iter = [&](size_t n, int nb, auto full, auto first) {
+    auto iter = [&](size_t n, int nb, auto full, auto first, auto slot_tag) {
         const size_t f0 = n * B;
         const int buf = int(n & 1);
         if (arm_wave) {
@@ -154,6 +205,15 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
                 dma(n + kLwAhead);
 #pragma unroll
                 for (int b = 0; b < B; b++) xv[b] = xs[n % kLwRing][b * kWave + lid];
+            } else if constexpr (LMD) {
+                static_assert(B == 16, "a pair of batches is one 128-byte line per lane");
+                if (n % 2 == 0) dma_lm(n / 2 + kLwAhead);
+                const char *slot = reinterpret_cast<const char *>(&xs[0][0]) + ((n / 2) % kLwRing) * 8192;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const i32x4 a = *reinterpret_cast<const i32x4 *>(slot + (xs_own ^ uint32_t(((n % 2) * 4 + v) * 16)));
+                    xv[4 * v] = a.x, xv[4 * v + 1] = a.y, xv[4 * v + 2] = a.z, xv[4 * v + 3] = a.w;
+                }
             } else {
 #pragma unroll
                 for (int b = 0; b < B; b++) xv[b] = xn[b];
@@ -167,9 +227,12 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
             for (int b = 0; b < B; b++)
                 if (decltype(full)::value || b < nb) arm[buf][r][b][lid] = bank.step(prm, __mulhi(lo_mine[b * kWave * 2], xv[b]));
             if constexpr (DMA) wait_vmcnt<(kLwAhead - 1) * (B / 8)>();  // batch n + 1 has landed
+            if constexpr (LMD) {
+                if (n % 2 == 1) wait_vmcnt<(kLwAhead - 1) * 4>();  // the pair of batches n + 1, n + 2 has landed
+            }
         } else {
             lo_stage(buf ^ 1);
-            if constexpr (!decltype(first)::value) out_stage(f0 - B, buf ^ 1, B, std::true_type{});
+            if constexpr (!decltype(first)::value) out_stage(f0 - B, buf ^ 1, B, std::true_type{}, slot_tag, false);
         }
         __syncthreads();
     };
@@ -177,6 +240,9 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
         if constexpr (DMA) {
             for (int n = 0; n < kLwAhead; n++) dma(size_t(n));
             wait_vmcnt<(kLwAhead - 1) * (B / 8)>();  // batch 0 has landed
+        } else if constexpr (LMD) {
+            for (int n = 0; n < kLwAhead; n++) dma_lm(size_t(n));
+            wait_vmcnt<(kLwAhead - 1) * 4>();  // pair 0 has landed
         } else if (frames >= size_t(B)) {
             fetch(0, std::true_type{});
         } else {
@@ -188,18 +254,37 @@ __global__ __launch_bounds__(W * kWave) void lockin_waves_kernel(const LpParams 
     __syncthreads();
     const size_t nfull = frames / B;
     const int tail = int(frames % B);
-    if (nfull) {
-        iter(0, B, std::true_type{}, std::true_type{});
-        for (size_t n = 1; n < nfull; n++) iter(n, B, std::true_type{}, std::false_type{});
-    }
-    if (tail) {
-        if (nfull)
-            iter(nfull, tail, std::false_type{}, std::false_type{});
-        else
-            iter(0, tail, std::false_type{}, std::true_type{});
-        if (!arm_wave) out_stage(nfull * B, int(nfull & 1), tail, std::false_type{});
-    } else if (!arm_wave) {
-        out_stage((nfull - 1) * B, int((nfull - 1) & 1), B, std::true_type{});
+    using Slot0 = std::integral_constant<int, 0>;
+    if constexpr (LM) {
+        // whole batches only (launcher): batch n - 1 leaves in iteration n, its group slot (n - 1) % kLwOutGroup is static
+        iter(0, B, std::true_type{}, std::true_type{}, Slot0{});
+        size_t n = 1;
+        while (n < nfull)
+            static_for<kLwOutGroup>([&](auto q) {
+                if (n < nfull) {
+                    iter(n, B, std::true_type{}, std::false_type{}, q);
+                    n++;
+                }
+            });
+        if (!arm_wave)
+            static_for<kLwOutGroup>([&](auto q) {
+                if (int((nfull - 1) % kLwOutGroup) == decltype(q)::value)
+                    out_stage((nfull - 1) * B, int((nfull - 1) & 1), B, std::true_type{}, q, true);
+            });
+    } else {
+        if (nfull) {
+            iter(0, B, std::true_type{}, std::true_type{}, Slot0{});
+            for (size_t n = 1; n < nfull; n++) iter(n, B, std::true_type{}, std::false_type{}, Slot0{});
+        }
+        if (tail) {
+            if (nfull)
+                iter(nfull, tail, std::false_type{}, std::false_type{}, Slot0{});
+            else
+                iter(0, tail, std::false_type{}, std::true_type{}, Slot0{});
+            if (!arm_wave) out_stage(nfull * B, int(nfull & 1), tail, std::false_type{}, Slot0{}, true);
+        } else if (!arm_wave) {
+            out_stage((nfull - 1) * B, int((nfull - 1) & 1), B, std::true_type{}, Slot0{}, true);
+        }
     }
     if (active && arm_wave) {
         if (r == 0) st[lane] = acc0 + inc * uint32_t(frames);
@@ -236,7 +321,14 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
         return e ? atoi(e) : 0;
     }();
     const bool b16 = forced_b == 16 || (forced_b != 8 && lanes <= kSplitMaxLanes);
-    if (layout == IDSP_LANE_MAJOR) return launch_lockin_waves_in<MODE, N, K, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
+    if (layout == IDSP_LANE_MAJOR) {
+        // input by DMA (whole 128-byte lines, each requested once) for the 4-wave I/Q and norm_sqr forms: 0.48 -> 0.43-0.44 ms
+        // at 32768 lanes x 4096 frames, 0.94 -> 0.86 at 65536; its 32 KiB ring halves the workgroups a CU can hold, which
+        // costs the 6-wave form and the arg read-out more than the input gains (tools/exp_lockin_lm.py)
+        if (!no_dma && waves == 4 && MODE != MODE_ARG)
+            return launch_lockin_waves_in<MODE, N, K, IN_LM_DMA, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
+        return launch_lockin_waves_in<MODE, N, K, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
+    }
     if (!no_dma && lanes % kWave == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
         if (b16) return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s);
         return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s);
