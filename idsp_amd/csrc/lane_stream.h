@@ -648,6 +648,16 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 // whole 16-byte pieces the same way; the final frames % (4 / W) samples of every lane go sample by sample.  x == y is
 // safe (a tile is stored after it has been read; the rows of one wave are touched by no other).
 constexpr int kLmRun = 512;  // bytes per lane and tile
+// A wave-uniform pointer pinned to SGPRs.  readfirstlane is opaque to the loop optimiser: without it the per-instruction
+// addresses `uniform base + constant * tile + thread offset` are strength-reduced into one 64-bit VGPR induction pointer
+// per load and per store instruction (2 x 32 pairs next to the 32 staged pieces: scratch spills).
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *q)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(u)), hi = __builtin_amdgcn_readfirstlane(uint32_t(u >> 32));
+    return reinterpret_cast<T *>((uint64_t(hi) << 32) | lo);
+}
 template <class P, class = void>
 struct LmStagedOf {
     static constexpr bool value = false;
@@ -692,10 +702,15 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     if (active) p.load(prm, st, lanes, lane0 + lid);
 
     // mover role of this thread: in instruction j, lane mq + j of the tile, piece mpc ^ (j & SWM) of its run
+    // Addresses = wave-uniform 64-bit base (the wave's first lane, instruction j, tile: SGPRs) + a 32-bit per-thread
+    // byte offset (lane mq of the instruction's group and the piece): the global_load / store `saddr` form.  With one
+    // 64-bit pointer per instruction in VGPRs the PCS source and PCS destination pointers sat next to the PCS staged
+    // pieces and the kernel spilled.  (The launcher checks that 64 rows span less than 4 GiB.)
     const int mq = (lid / PCS) * PCS, mpc = lid % PCS;
-    const uint32_t *xq = reinterpret_cast<const uint32_t *>(x) + (lane0 + mq) * xl * W;
-    uint32_t *yq = reinterpret_cast<uint32_t *>(y) + (lane0 + mq) * yl * W;
-    const size_t xrow = xl * W, yrow = yl * W;  // words between lanes
+    const size_t xrowb = xl * sizeof(In), yrowb = yl * sizeof(Out);  // bytes between lanes
+    const char *const xbase = reinterpret_cast<const char *>(x) + lane0 * xrowb;
+    char *const ybase = reinterpret_cast<char *>(y) + lane0 * yrowb;
+    const uint32_t xoff = uint32_t(mq) * uint32_t(xrowb), yoff = uint32_t(mq) * uint32_t(yrowb);
     // owner role: slot row of this thread's lane, and the byte offset of its piece k = own ^ (16 k)
     const uint32_t own = uint32_t((lid % PCS) * G + lid / PCS) * LB + uint32_t(lid & SWM) * 16;
     char *const slot = reinterpret_cast<char *>(smem);
@@ -705,21 +720,19 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     u32x4 stage[PCS];
     // WHOLE: all 64 lanes of the wave exist; FULL: all PCS pieces of the tile exist (else np of them)
     auto fetch = [&](size_t v, auto whole, auto full, int np) __attribute__((always_inline)) {
-        const uint32_t *src = xq + v * (TF * W);
+        const char *src = xbase + v * size_t(LB);
 #pragma unroll
         for (int j = 0; j < PCS; j++) {
             const int pc = mpc ^ (j & SWM);
             if ((decltype(whole)::value || size_t(mq + j) < nrows) && (decltype(full)::value || pc < np))
-                stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * xrow + pc * 4));
+                stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + j * xrowb) + size_t(xoff + uint32_t(pc * 16))));
         }
     };
     auto hand_over = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < PCS; j++) *reinterpret_cast<u32x4 *>(slot + j * 1024 + lid * 16) = stage[j];
     };
-    auto piece = [&](int k) __attribute__((always_inline)) {
-        u32x4 *q = reinterpret_cast<u32x4 *>(slot + (own ^ uint32_t(k * 16)));
-        u32x4 v = *q;
+    auto steps = [&](u32x4 &v) __attribute__((always_inline)) {  // the SPP samples of one piece, in place
 #pragma unroll
         for (int s = 0; s < SPP; s++) {
             uint32_t w[W];
@@ -730,6 +743,11 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
 #pragma unroll
             for (int h = 0; h < W; h++) v[s * W + h] = w[h];
         }
+    };
+    auto piece = [&](int k) __attribute__((always_inline)) {
+        u32x4 *q = reinterpret_cast<u32x4 *>(slot + (own ^ uint32_t(k * 16)));
+        u32x4 v = *q;
+        steps(v);
         *q = v;
     };
     auto compute = [&](auto full, int np) __attribute__((always_inline)) {
@@ -737,18 +755,39 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
         if constexpr (!decltype(full)::value || MaxU<P>::value < 24) {
             for (int k = 0; k < np; k++) piece(k);  // partial tile, or a large body: keep the loop rolled
         } else {
+            // groups of GP pieces: the next group's LDS reads are issued before the current group's arithmetic, and a
+            // scheduling fence per group keeps the compiler from hoisting all PCS reads above the first step (which,
+            // next to the PCS staged pieces of the next tile, overflowed the register file into scratch)
+            constexpr int GP = 4;
+            u32x4 cur[GP], nxt[GP];
 #pragma unroll
-            for (int k = 0; k < PCS; k++) piece(k);
+            for (int c = 0; c < GP; c++) cur[c] = *reinterpret_cast<const u32x4 *>(slot + (own ^ uint32_t(c * 16)));
+#pragma unroll
+            for (int g = 0; g < PCS / GP; g++) {
+                if (g + 1 < PCS / GP) {
+#pragma unroll
+                    for (int c = 0; c < GP; c++) nxt[c] = *reinterpret_cast<const u32x4 *>(slot + (own ^ uint32_t(((g + 1) * GP + c) * 16)));
+                }
+#pragma unroll
+                for (int c = 0; c < GP; c++) {
+                    steps(cur[c]);
+                    *reinterpret_cast<u32x4 *>(slot + (own ^ uint32_t((g * GP + c) * 16))) = cur[c];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < GP; c++) cur[c] = nxt[c];
+            }
         }
     };
     auto store = [&](size_t v, auto whole, auto full, int np) __attribute__((always_inline)) {
-        uint32_t *dst = yq + v * (TF * W);
+        char *dst = ybase + v * size_t(LB);
 #pragma unroll
         for (int j = 0; j < PCS; j++) {
             const int pc = mpc ^ (j & SWM);
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
             if ((decltype(whole)::value || size_t(mq + j) < nrows) && (decltype(full)::value || pc < np))
-                __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst + j * yrow + pc * 4));
+                __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + j * yrowb) + size_t(yoff + uint32_t(pc * 16))));
+            if (j % 8 == 7) asm volatile("" ::: "memory");  // at most 8 pieces between LDS and the store (the staged tile holds PCS)
         }
     };
     auto walk = [&](auto whole) __attribute__((always_inline)) {
@@ -824,11 +863,13 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         const size_t xl = pitch.x ? pitch.x : frames, yl = pitch.y ? pitch.y : frames;
         const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
         if constexpr (LmStagedOf<P>::value) {
-            // 16-byte pieces need 16-byte aligned rows; below a quarter tile of frames the 4-byte tile kernel has less to set up
+            // 16-byte pieces need 16-byte aligned rows (of less than 64 MiB: 32-bit offsets inside a wave's 64 rows); below a
+            // quarter tile of frames the 4-byte tile kernel has less to set up
             // (IDSP_DIAG=1 IDSP_NO_LM_STAGED=1: always the tile kernel)
             static const bool no_staged = diag_env("IDSP_NO_LM_STAGED") != nullptr;
             constexpr size_t sz = sizeof(typename P::In);
-            if (!no_staged && frames * sz >= size_t(kLmRun) / 4 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+            if (!no_staged && frames * sz >= size_t(kLmRun) / 4 && xl * sz < (size_t(1) << 26) && yl * sz < (size_t(1) << 26) &&
+                reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                 reinterpret_cast<uintptr_t>(y) % 16 == 0 && (xl * sz) % 16 == 0 && (yl * sz) % 16 == 0) {
                 const size_t bytes = size_t(kWave) * kLmRun + P::LDS_WORDS * 4;
                 if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P>>(bytes)) return rc;
