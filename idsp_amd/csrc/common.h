@@ -76,6 +76,16 @@ __device__ __forceinline__ void lds_wave_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// A wave-uniform pointer pinned to SGPRs.  readfirstlane is opaque to the loop optimiser: without it the per-instruction
+// addresses `uniform base + constant * tile + thread offset` are strength-reduced into one 64-bit VGPR induction pointer
+// per load and per store instruction (2 x 32 pairs next to the 32 staged pieces: scratch spills).
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *q)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(u)), hi = __builtin_amdgcn_readfirstlane(uint32_t(u >> 32));
+    return reinterpret_cast<T *>((uint64_t(hi) << 32) | lo);
+}
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the ABI lets one
 // process switch devices (idsp_device_set), and the attribute is per device.
 // The kernel is a template ARGUMENT (not a function parameter) so that the flag below is one per kernel: kernels of

@@ -648,16 +648,6 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 // whole 16-byte pieces the same way; the final frames % (4 / W) samples of every lane go sample by sample.  x == y is
 // safe (a tile is stored after it has been read; the rows of one wave are touched by no other).
 constexpr int kLmRun = 512;  // bytes per lane and tile
-// A wave-uniform pointer pinned to SGPRs.  readfirstlane is opaque to the loop optimiser: without it the per-instruction
-// addresses `uniform base + constant * tile + thread offset` are strength-reduced into one 64-bit VGPR induction pointer
-// per load and per store instruction (2 x 32 pairs next to the 32 staged pieces: scratch spills).
-template <class T>
-__device__ __forceinline__ T *uniform_ptr(T *q)
-{
-    const uint64_t u = reinterpret_cast<uint64_t>(q);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(u)), hi = __builtin_amdgcn_readfirstlane(uint32_t(u >> 32));
-    return reinterpret_cast<T *>((uint64_t(hi) << 32) | lo);
-}
 template <class P, class = void>
 struct LmStagedOf {
     static constexpr bool value = false;
