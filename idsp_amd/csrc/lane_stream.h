@@ -647,15 +647,37 @@ __global__ __launch_bounds__(kWave) void stream_lane_major(
 // One wave per workgroup, no barriers.  Needs 16-byte aligned rows (base and pitch).  A last partial tile moves its
 // whole 16-byte pieces the same way; the final frames % (4 / W) samples of every lane go sample by sample.  x == y is
 // safe (a tile is stored after it has been read; the rows of one wave are touched by no other).
-constexpr int kLmRun = 512;  // bytes per lane and tile
+constexpr int kLmRun = 512;  // bytes per lane and tile on the wider of the two sides
+// Processors the staged kernel takes: one lane per thread (IN_DIV == 1), 4- or 8-byte samples, no input or an input of the
+// output's size, and a pre-stage batch of 1 or 4 frames.  The kernel itself also handles samples of different sizes (a tile
+// is then 128 / max(words) frames: 512-byte runs on the wider side, 256-byte runs on the narrower, separate LDS slots), but
+// its 48 KiB of LDS leave a CU three waves and those processors (fm_disc, the lock-in with Complex output) are VALU-bound:
+// fm_disc LaneMajor 1.89 ms staged against 1.46 ms on the tile kernel at 65536 lanes x 4096, so they stay there.
 template <class P, class = void>
 struct LmStagedOf {
     static constexpr bool value = false;
 };
 template <class P>
-struct LmStagedOf<P, std::enable_if_t<P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == sizeof(typename P::Out) &&
-                                      (sizeof(typename P::In) == 4 || sizeof(typename P::In) == 8) && BatchOf<P>::value == 1>> {
+struct LmStagedOf<P, std::enable_if_t<P::IN_DIV == 1 && (!P::HAS_IN || sizeof(typename P::In) == sizeof(typename P::Out)) &&
+                                      (sizeof(typename P::Out) == 4 || sizeof(typename P::Out) == 8) &&
+                                      (BatchOf<P>::value == 1 || BatchOf<P>::value == 4)>> {
     static constexpr bool value = true;
+};
+// bytes of LDS the kernel needs for P (slots + the processor's table)
+template <class P>
+constexpr size_t lm_staged_lds_bytes()
+{
+    constexpr int IW = P::HAS_IN ? int(sizeof(typename P::In)) / 4 : 0, OW = int(sizeof(typename P::Out)) / 4;
+    constexpr int S = IW > OW ? IW : OW, TF = kLmRun / 4 / S;
+    constexpr int IB = TF * IW * 4, OB = TF * OW * 4;
+    return size_t(kWave) * (IB == OB ? OB : IB + OB) + size_t(P::LDS_WORDS) * 4;
+}
+
+// geometry of one side of a tile: RB bytes per lane, moved as PCS 16-byte pieces; instruction j covers the G lanes
+// j, j + PCS, ...; lane l sits in slot row (l % PCS) G + l / PCS with piece k at 16 (k ^ (l & SWM))
+template <int RB>
+struct LmSide {
+    static constexpr int PCS = RB / 16, G = PCS ? kWave / PCS : 0, SWM = (PCS < 16 ? PCS : 16) - 1;
 };
 
 template <class P>
@@ -665,18 +687,25 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
 {
     using In = typename P::In;
     using Out = typename P::Out;
-    static_assert(LmStagedOf<P>::value, "one input and one output of the same 4- or 8-byte size per lane and frame");
-    constexpr int LB = kLmRun;
-    constexpr int W = sizeof(In) / 4;        // words per sample
-    constexpr int TF = LB / 4 / W;           // frames per tile
-    constexpr int PCS = LB / 16;             // 16-byte pieces per lane and tile = load / store instructions per tile
-    constexpr int G = kWave / PCS;           // lanes per instruction
-    constexpr int SWM = (PCS < 16 ? PCS : 16) - 1;  // swizzle mask
-    constexpr int SPP = 4 / W;               // samples per piece
+    static_assert(LmStagedOf<P>::value, "one lane per thread, 4- or 8-byte samples, pre-stage batch 1 or 4");
+    constexpr bool HAS_IN = P::HAS_IN;
+    constexpr int IW = HAS_IN ? int(sizeof(In)) / 4 : 0, OW = int(sizeof(Out)) / 4;  // words per sample
+    constexpr int S = IW > OW ? IW : OW;
+    constexpr int TF = kLmRun / 4 / S;             // frames per tile
+    constexpr int IB = TF * IW * 4, OB = TF * OW * 4;  // bytes per lane and tile
+    using SI = LmSide<IB>;
+    using SO = LmSide<OB>;
+    constexpr int PI = SI::PCS, PO = SO::PCS;      // pieces per lane and tile = load / store instructions per tile
+    constexpr bool kAlias = IB == OB;              // results overwrite the input pieces
+    constexpr int NS = 16 / S;                     // samples per compute chunk (4 pieces of the wider side)
+    constexpr int CI = NS * IW / 4, CO = NS * OW / 4;  // pieces per chunk
+    constexpr int B = BatchOf<P>::value;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *ptab = smem + kWave * LB / 4;  // [P::LDS_WORDS]
+    char *const slot_in = reinterpret_cast<char *>(smem);
+    char *const slot_out = slot_in + (kAlias ? 0 : kWave * IB);
+    uint32_t *ptab = reinterpret_cast<uint32_t *>(slot_out + kWave * OB);  // [P::LDS_WORDS]
     const int lid = threadIdx.x;
 
     const size_t lane0 = size_t(blockIdx.x) * kWave;
@@ -691,120 +720,143 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     }
     if (active) p.load(prm, st, lanes, lane0 + lid);
 
-    // mover role of this thread: in instruction j, lane mq + j of the tile, piece mpc ^ (j & SWM) of its run
     // Addresses = wave-uniform 64-bit base (the wave's first lane, instruction j, tile: SGPRs) + a 32-bit per-thread
-    // byte offset (lane mq of the instruction's group and the piece): the global_load / store `saddr` form.  With one
-    // 64-bit pointer per instruction in VGPRs the PCS source and PCS destination pointers sat next to the PCS staged
-    // pieces and the kernel spilled.  (The launcher checks that 64 rows span less than 4 GiB.)
-    const int mq = (lid / PCS) * PCS, mpc = lid % PCS;
+    // byte offset (the lane of the instruction's group and the piece): the global_load / store `saddr` form.  With one
+    // 64-bit pointer per instruction in VGPRs the source and destination pointers sat next to the staged pieces and
+    // the kernel spilled.  (The launcher checks that 64 rows span less than 4 GiB.)
     const size_t xrowb = xl * sizeof(In), yrowb = yl * sizeof(Out);  // bytes between lanes
     const char *const xbase = reinterpret_cast<const char *>(x) + lane0 * xrowb;
     char *const ybase = reinterpret_cast<char *>(y) + lane0 * yrowb;
-    const uint32_t xoff = uint32_t(mq) * uint32_t(xrowb), yoff = uint32_t(mq) * uint32_t(yrowb);
+    // mover role on either side: in instruction j, lane mq + j of the tile, piece mpc ^ (j & SWM) of its run
+    const int mqi = PI ? (lid / (PI ? PI : 1)) * PI : 0, mpci = PI ? lid % (PI ? PI : 1) : 0;
+    const int mqo = (lid / PO) * PO, mpco = lid % PO;
+    const uint32_t xoff = uint32_t(mqi) * uint32_t(xrowb), yoff = uint32_t(mqo) * uint32_t(yrowb);
     // owner role: slot row of this thread's lane, and the byte offset of its piece k = own ^ (16 k)
-    const uint32_t own = uint32_t((lid % PCS) * G + lid / PCS) * LB + uint32_t(lid & SWM) * 16;
-    char *const slot = reinterpret_cast<char *>(smem);
+    const uint32_t owni = PI ? uint32_t((lid % (PI ? PI : 1)) * SI::G + lid / (PI ? PI : 1)) * IB + uint32_t(lid & SI::SWM) * 16 : 0;
+    const uint32_t owno = uint32_t((lid % PO) * SO::G + lid / PO) * OB + uint32_t(lid & SO::SWM) * 16;
 
     const size_t nfull = frames / TF;
-    const int ntail = int((frames - nfull * TF) / SPP);  // whole pieces of the last, partial tile
-    u32x4 stage[PCS];
-    // WHOLE: all 64 lanes of the wave exist; FULL: all PCS pieces of the tile exist (else np of them)
-    auto fetch = [&](size_t v, auto whole, auto full, int np) __attribute__((always_inline)) {
-        const char *src = xbase + v * size_t(LB);
+    const int nquad = int((frames - nfull * TF) / 4);  // whole groups of 4 samples of the last, partial tile
+    u32x4 stage[PI ? PI : 1];
+    // WHOLE: all 64 lanes of the wave exist; FULL: the whole tile exists (else nq groups of 4 samples)
+    auto fetch = [&](size_t v, auto whole, auto full, int nq) __attribute__((always_inline)) {
+        if constexpr (HAS_IN) {
+            const char *src = xbase + v * size_t(IB);
 #pragma unroll
-        for (int j = 0; j < PCS; j++) {
-            const int pc = mpc ^ (j & SWM);
-            if ((decltype(whole)::value || size_t(mq + j) < nrows) && (decltype(full)::value || pc < np))
-                stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + j * xrowb) + size_t(xoff + uint32_t(pc * 16))));
-        }
-    };
-    auto hand_over = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < PCS; j++) *reinterpret_cast<u32x4 *>(slot + j * 1024 + lid * 16) = stage[j];
-    };
-    auto steps = [&](u32x4 &v) __attribute__((always_inline)) {  // the SPP samples of one piece, in place
-#pragma unroll
-        for (int s = 0; s < SPP; s++) {
-            uint32_t w[W];
-#pragma unroll
-            for (int h = 0; h < W; h++) w[h] = v[s * W + h];
-            const Out o = step1(p, prm, words_to<In>(w));
-            to_words<Out>(o, w);
-#pragma unroll
-            for (int h = 0; h < W; h++) v[s * W + h] = w[h];
-        }
-    };
-    auto piece = [&](int k) __attribute__((always_inline)) {
-        u32x4 *q = reinterpret_cast<u32x4 *>(slot + (own ^ uint32_t(k * 16)));
-        u32x4 v = *q;
-        steps(v);
-        *q = v;
-    };
-    auto compute = [&](auto full, int np) __attribute__((always_inline)) {
-        if (!active) return;
-        if constexpr (!decltype(full)::value || MaxU<P>::value < 24) {
-            for (int k = 0; k < np; k++) piece(k);  // partial tile, or a large body: keep the loop rolled
-        } else {
-            // groups of GP pieces: the next group's LDS reads are issued before the current group's arithmetic, and a
-            // scheduling fence per group keeps the compiler from hoisting all PCS reads above the first step (which,
-            // next to the PCS staged pieces of the next tile, overflowed the register file into scratch)
-            constexpr int GP = 4;
-            u32x4 cur[GP], nxt[GP];
-#pragma unroll
-            for (int c = 0; c < GP; c++) cur[c] = *reinterpret_cast<const u32x4 *>(slot + (own ^ uint32_t(c * 16)));
-#pragma unroll
-            for (int g = 0; g < PCS / GP; g++) {
-                if (g + 1 < PCS / GP) {
-#pragma unroll
-                    for (int c = 0; c < GP; c++) nxt[c] = *reinterpret_cast<const u32x4 *>(slot + (own ^ uint32_t(((g + 1) * GP + c) * 16)));
-                }
-#pragma unroll
-                for (int c = 0; c < GP; c++) {
-                    steps(cur[c]);
-                    *reinterpret_cast<u32x4 *>(slot + (own ^ uint32_t((g * GP + c) * 16))) = cur[c];
-                }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int c = 0; c < GP; c++) cur[c] = nxt[c];
+            for (int j = 0; j < PI; j++) {
+                const int pc = mpci ^ (j & SI::SWM);
+                if ((decltype(whole)::value || size_t(mqi + j) < nrows) && (decltype(full)::value || pc < nq * IW))
+                    stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + j * xrowb) + size_t(xoff + uint32_t(pc * 16))));
             }
         }
     };
-    auto store = [&](size_t v, auto whole, auto full, int np) __attribute__((always_inline)) {
-        char *dst = ybase + v * size_t(LB);
+    auto hand_over = [&]() __attribute__((always_inline)) {
+        if constexpr (HAS_IN) {
 #pragma unroll
-        for (int j = 0; j < PCS; j++) {
-            const int pc = mpc ^ (j & SWM);
-            const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
-            if ((decltype(whole)::value || size_t(mq + j) < nrows) && (decltype(full)::value || pc < np))
+            for (int j = 0; j < PI; j++) *reinterpret_cast<u32x4 *>(slot_in + j * 1024 + lid * 16) = stage[j];
+        }
+    };
+    // four consecutive samples: IW input pieces in, OW output pieces out
+    auto quad = [&](const u32x4 *in, u32x4 *out) __attribute__((always_inline)) {
+        uint32_t wi[IW ? 4 * IW : 1], wo[4 * OW];
+        if constexpr (HAS_IN) {
+#pragma unroll
+            for (int h = 0; h < IW; h++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) wi[4 * h + e] = in[h][e];
+        }
+        auto sample = [&](int b) __attribute__((always_inline)) {
+            In v{};
+            if constexpr (HAS_IN) v = words_to<In>(wi + b * IW);
+            return v;
+        };
+        if constexpr (B == 4) {
+            typename P::Pre pre[4];
+            pre_all<P, 4>(p, prm, pre);
+#pragma unroll
+            for (int b = 0; b < 4; b++) to_words<Out>(p.step(prm, sample(b), pre[b]), wo + b * OW);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) to_words<Out>(p.step(prm, sample(b)), wo + b * OW);
+        }
+#pragma unroll
+        for (int h = 0; h < OW; h++) out[h] = u32x4{wo[4 * h], wo[4 * h + 1], wo[4 * h + 2], wo[4 * h + 3]};
+    };
+    auto in_piece = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4 *>(slot_in + (owni ^ uint32_t(k * 16))); };
+    auto out_piece = [&](int k, const u32x4 &v) __attribute__((always_inline)) { *reinterpret_cast<u32x4 *>(slot_out + (owno ^ uint32_t(k * 16))) = v; };
+    auto compute = [&](auto full, int nq) __attribute__((always_inline)) {
+        if (!active) return;
+        if constexpr (!decltype(full)::value || MaxU<P>::value < 24) {
+            for (int q = 0; q < nq; q++) {  // partial tile, or a large body: keep the loop rolled
+                u32x4 in[IW ? IW : 1], out[OW];
+#pragma unroll
+                for (int h = 0; h < IW; h++) in[h] = in_piece(q * IW + h);
+                quad(in, out);
+#pragma unroll
+                for (int h = 0; h < OW; h++) out_piece(q * OW + h, out[h]);
+            }
+        } else {
+            // chunks of NS samples (4 pieces of the wider side): the next chunk's LDS reads are issued before the
+            // current chunk's arithmetic, and a scheduling fence per chunk keeps the compiler from hoisting all reads
+            // of the tile above the first step (which, next to the staged pieces of the next tile, overflowed the
+            // register file into scratch)
+            constexpr int NCH = TF / NS;
+            u32x4 cur[CI ? CI : 1], nxt[CI ? CI : 1];
+#pragma unroll
+            for (int c = 0; c < CI; c++) cur[c] = in_piece(c);
+#pragma unroll
+            for (int g = 0; g < NCH; g++) {
+                if (g + 1 < NCH) {
+#pragma unroll
+                    for (int c = 0; c < CI; c++) nxt[c] = in_piece((g + 1) * CI + c);
+                }
+                u32x4 out[CO];
+#pragma unroll
+                for (int q = 0; q < NS / 4; q++) quad(cur + q * IW, out + q * OW);
+#pragma unroll
+                for (int c = 0; c < CO; c++) out_piece(g * CO + c, out[c]);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < CI; c++) cur[c] = nxt[c];
+            }
+        }
+    };
+    auto store = [&](size_t v, auto whole, auto full, int nq) __attribute__((always_inline)) {
+        char *dst = ybase + v * size_t(OB);
+#pragma unroll
+        for (int j = 0; j < PO; j++) {
+            const int pc = mpco ^ (j & SO::SWM);
+            const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot_out + j * 1024 + lid * 16);
+            if ((decltype(whole)::value || size_t(mqo + j) < nrows) && (decltype(full)::value || pc < nq * OW))
                 __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + j * yrowb) + size_t(yoff + uint32_t(pc * 16))));
-            if (j % 8 == 7) asm volatile("" ::: "memory");  // at most 8 pieces between LDS and the store (the staged tile holds PCS)
+            if (j % 8 == 7) asm volatile("" ::: "memory");  // at most 8 pieces between LDS and the store (the staged tile holds PI)
         }
     };
     auto walk = [&](auto whole) __attribute__((always_inline)) {
         using Full = std::true_type;
         using Part = std::false_type;
         if (nfull > 0)
-            fetch(0, whole, Full{}, PCS);
+            fetch(0, whole, Full{}, TF / 4);
         else
-            fetch(0, whole, Part{}, ntail);
+            fetch(0, whole, Part{}, nquad);
         for (size_t i = 0; i < nfull; i++) {
             hand_over();
             lds_wave_sync();
             if (i + 1 < nfull)
-                fetch(i + 1, whole, Full{}, PCS);
-            else if (ntail > 0)
-                fetch(i + 1, whole, Part{}, ntail);
-            compute(Full{}, PCS);
+                fetch(i + 1, whole, Full{}, TF / 4);
+            else if (nquad > 0)
+                fetch(i + 1, whole, Part{}, nquad);
+            compute(Full{}, TF / 4);
             lds_wave_sync();
-            store(i, whole, Full{}, PCS);
+            store(i, whole, Full{}, TF / 4);
             lds_wave_sync();
         }
-        if (ntail > 0) {
+        if (nquad > 0) {
             hand_over();
             lds_wave_sync();
-            compute(Part{}, ntail);
+            compute(Part{}, nquad);
             lds_wave_sync();
-            store(nfull, whole, Part{}, ntail);
+            store(nfull, whole, Part{}, nquad);
         }
     };
     if (nrows == size_t(kWave))
@@ -812,10 +864,14 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     else
         walk(std::false_type{});
 
-    if (active) {  // the last frames % SPP samples of this lane's own row
+    if (active) {  // the last frames % 4 samples of this lane's own row
         const In *xr = x + (lane0 + lid) * xl;
         Out *yr = y + (lane0 + lid) * yl;
-        for (size_t f = nfull * TF + size_t(ntail) * SPP; f < frames; f++) yr[f] = step1(p, prm, xr[f]);
+        for (size_t f = nfull * TF + size_t(nquad) * 4; f < frames; f++) {
+            In v{};
+            if constexpr (HAS_IN) v = xr[f];
+            yr[f] = step1(p, prm, v);
+        }
         p.store(prm, st, lanes, lane0 + lid);
     }
 }
@@ -857,11 +913,11 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             // quarter tile of frames the 4-byte tile kernel has less to set up
             // (IDSP_DIAG=1 IDSP_NO_LM_STAGED=1: always the tile kernel)
             static const bool no_staged = diag_env("IDSP_NO_LM_STAGED") != nullptr;
-            constexpr size_t sz = sizeof(typename P::In);
-            if (!no_staged && frames * sz >= size_t(kLmRun) / 4 && xl * sz < (size_t(1) << 26) && yl * sz < (size_t(1) << 26) &&
-                reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
-                reinterpret_cast<uintptr_t>(y) % 16 == 0 && (xl * sz) % 16 == 0 && (yl * sz) % 16 == 0) {
-                const size_t bytes = size_t(kWave) * kLmRun + P::LDS_WORDS * 4;
+            constexpr size_t isz = P::HAS_IN ? sizeof(typename P::In) : 0, osz = sizeof(typename P::Out), wide = isz > osz ? isz : osz;
+            const bool x_ok = !P::HAS_IN || (reinterpret_cast<uintptr_t>(x) % 16 == 0 && (xl * isz) % 16 == 0 && xl * isz < (size_t(1) << 26));
+            if (!no_staged && frames * wide >= size_t(kLmRun) / 4 && x_ok && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+                (yl * osz) % 16 == 0 && yl * osz < (size_t(1) << 26)) {
+                constexpr size_t bytes = lm_staged_lds_bytes<P>();
                 if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P>>(bytes)) return rc;
                 note_kernel("stream_lane_major_staged", typeid(P).name());
                 hipLaunchKernelGGL((stream_lane_major_staged<P>), dim3(grid), dim3(kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl);

@@ -126,3 +126,27 @@ def test_unaligned_rows_fall_back_to_the_tile_kernel(gpu):
     torch.cuda.synchronize()
     assert rc == 0 and kernel_of(gpu).startswith("stream_lane_major<"), kernel_of(gpu)
     assert np.array_equal(yb.cpu().numpy().reshape(lanes, frames), want)
+
+
+def test_dds_and_polar_lockin_on_the_staged_kernel(gpu):
+    """Processors without an input (DDS: Complex<i32> out, above the I/Q thread-split lane count) and with a pre-stage
+    batch (the stream lock-in with `arg` read-out, taken when the frame count is not a whole number of 16-frame batches)."""
+    from tests._backends import GpuBackend, OracleBackend
+    ob, gb = OracleBackend(), GpuBackend()
+    rng = np.random.default_rng(80)
+    for lanes, frames in ((41000, 70), (40961, 18)):  # 40960 lanes and fewer split the I / Q arms over two threads
+        st = rng.integers(0, 1 << 32, size=(2, lanes), dtype=np.uint64).astype(np.uint32)
+        so, sg = st.copy(), st.copy()
+        _, yo = ob.dds(so, lanes, frames, LM)
+        rc, yg = gb.dds(sg, lanes, frames, LM)
+        assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
+        assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), kernel_of(H.engine())
+    lc = H.lockin_cfg([[1 << 20, -(1 << 27)]] * 2)
+    for lanes, frames in ((200, 100), (65, 36), (64, 516)):
+        x = rng.integers(-(1 << 28), 1 << 28, size=lanes * frames, dtype=np.int32)
+        st = rng.integers(0, 1 << 32, size=(18, lanes), dtype=np.uint64).astype(np.uint32)
+        so, sg = st.copy(), st.copy()
+        rco, yo = ob.cfgcall("lockin_i32_arg", lc, so, x, (lanes * frames,), np.int32, lanes, frames, LM)
+        rcg, yg = gb.cfgcall("lockin_i32_arg", lc, sg, x, (lanes * frames,), np.int32, lanes, frames, LM)
+        assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
+        assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), kernel_of(H.engine())
