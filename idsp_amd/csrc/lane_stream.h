@@ -664,23 +664,29 @@ struct LmStagedOf<P, std::enable_if_t<P::IN_DIV == 1 && (!P::HAS_IN || sizeof(ty
     static constexpr bool value = true;
 };
 // bytes of LDS the kernel needs for P (slots + the processor's table)
-template <class P>
+template <class P, int LW>
 constexpr size_t lm_staged_lds_bytes()
 {
     constexpr int IW = P::HAS_IN ? int(sizeof(typename P::In)) / 4 : 0, OW = int(sizeof(typename P::Out)) / 4;
     constexpr int S = IW > OW ? IW : OW, TF = kLmRun / 4 / S;
     constexpr int IB = TF * IW * 4, OB = TF * OW * 4;
-    return size_t(kWave) * (IB == OB ? OB : IB + OB) + size_t(P::LDS_WORDS) * 4;
+    return size_t(LW) * (IB == OB ? OB : IB + OB) + size_t(P::LDS_WORDS) * 4;
 }
 
-// geometry of one side of a tile: RB bytes per lane, moved as PCS 16-byte pieces; instruction j covers the G lanes
-// j, j + PCS, ...; lane l sits in slot row (l % PCS) G + l / PCS with piece k at 16 (k ^ (l & SWM))
-template <int RB>
+// geometry of one side of a tile of LW lanes: RB bytes per lane, moved as PCS 16-byte pieces; one instruction covers G
+// lanes, a tile takes NI instructions; instruction j covers lanes j, j + NI, ...; lane l sits in slot row (l % NI) G + l / NI
+// with piece k at 16 (k ^ (l % 16))
+template <int RB, int LW>
 struct LmSide {
-    static constexpr int PCS = RB / 16, G = PCS ? kWave / PCS : 0, SWM = (PCS < 16 ? PCS : 16) - 1;
+    static constexpr int PCS = RB / 16, G = PCS ? kWave / PCS : 1, NI = LW / G;
+    static_assert(PCS == 0 || PCS == 16 || PCS == 32, "256- or 512-byte runs");
 };
 
-template <class P>
+// LW = lanes per wave (64, 32 or 16).  With fewer than 64 the wave still moves whole runs with all its threads, but only
+// the first LW threads own a lane: a launch of few lanes then spreads over LW / 64 times as many waves (SIMDs) — below
+// 65536 lanes a 64-lane wave per SIMD leaves most of the chip without a wave, and the per-lane recurrence is a serial
+// chain that one wave cannot speed up.
+template <class P, int LW = kWave>
 __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
@@ -693,9 +699,11 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     constexpr int S = IW > OW ? IW : OW;
     constexpr int TF = kLmRun / 4 / S;             // frames per tile
     constexpr int IB = TF * IW * 4, OB = TF * OW * 4;  // bytes per lane and tile
-    using SI = LmSide<IB>;
-    using SO = LmSide<OB>;
-    constexpr int PI = SI::PCS, PO = SO::PCS;      // pieces per lane and tile = load / store instructions per tile
+    static_assert(LW == 64 || LW == 32 || LW == 16, "lanes per wave");
+    using SI = LmSide<IB, LW>;
+    using SO = LmSide<OB, LW>;
+    constexpr int PI = SI::PCS, PO = SO::PCS;      // pieces per lane and tile
+    constexpr int NII = HAS_IN ? SI::NI : 0, NIO = SO::NI;  // load / store instructions per tile
     constexpr bool kAlias = IB == OB;              // results overwrite the input pieces
     constexpr int NS = 16 / S;                     // samples per compute chunk (4 pieces of the wider side)
     constexpr int CI = NS * IW / 4, CO = NS * OW / 4;  // pieces per chunk
@@ -704,12 +712,12 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     char *const slot_in = reinterpret_cast<char *>(smem);
-    char *const slot_out = slot_in + (kAlias ? 0 : kWave * IB);
-    uint32_t *ptab = reinterpret_cast<uint32_t *>(slot_out + kWave * OB);  // [P::LDS_WORDS]
+    char *const slot_out = slot_in + (kAlias ? 0 : LW * IB);
+    uint32_t *ptab = reinterpret_cast<uint32_t *>(slot_out + LW * OB);  // [P::LDS_WORDS]
     const int lid = threadIdx.x;
 
-    const size_t lane0 = size_t(blockIdx.x) * kWave;
-    const size_t nrows = lanes - lane0 < size_t(kWave) ? lanes - lane0 : size_t(kWave);
+    const size_t lane0 = size_t(blockIdx.x) * LW;
+    const size_t nrows = lanes - lane0 < size_t(LW) ? lanes - lane0 : size_t(LW);
     const bool active = size_t(lid) < nrows;
 
     P p;
@@ -727,24 +735,25 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     const size_t xrowb = xl * sizeof(In), yrowb = yl * sizeof(Out);  // bytes between lanes
     const char *const xbase = reinterpret_cast<const char *>(x) + lane0 * xrowb;
     char *const ybase = reinterpret_cast<char *>(y) + lane0 * yrowb;
-    // mover role on either side: in instruction j, lane mq + j of the tile, piece mpc ^ (j & SWM) of its run
-    const int mqi = PI ? (lid / (PI ? PI : 1)) * PI : 0, mpci = PI ? lid % (PI ? PI : 1) : 0;
-    const int mqo = (lid / PO) * PO, mpco = lid % PO;
+    // mover role on either side: in instruction j, lane mq + j of the tile, piece mpc ^ ((mq + j) % 16) of its run
+    const int mqi = PI ? (lid / (PI ? PI : 1)) * NII : 0, mpci = PI ? lid % (PI ? PI : 1) : 0;
+    const int mqo = (lid / PO) * NIO, mpco = lid % PO;
     const uint32_t xoff = uint32_t(mqi) * uint32_t(xrowb), yoff = uint32_t(mqo) * uint32_t(yrowb);
-    // owner role: slot row of this thread's lane, and the byte offset of its piece k = own ^ (16 k)
-    const uint32_t owni = PI ? uint32_t((lid % (PI ? PI : 1)) * SI::G + lid / (PI ? PI : 1)) * IB + uint32_t(lid & SI::SWM) * 16 : 0;
-    const uint32_t owno = uint32_t((lid % PO) * SO::G + lid / PO) * OB + uint32_t(lid & SO::SWM) * 16;
+    // owner role (threads < LW): slot row of this thread's lane, and the byte offset of its piece k = own ^ (16 k)
+    const int ol = lid % LW;
+    const uint32_t owni = NII ? uint32_t((ol % (NII ? NII : 1)) * SI::G + ol / (NII ? NII : 1)) * IB + uint32_t(ol & 15) * 16 : 0;
+    const uint32_t owno = uint32_t((ol % NIO) * SO::G + ol / NIO) * OB + uint32_t(ol & 15) * 16;
 
     const size_t nfull = frames / TF;
     const int nquad = int((frames - nfull * TF) / 4);  // whole groups of 4 samples of the last, partial tile
-    u32x4 stage[PI ? PI : 1];
+    u32x4 stage[NII ? NII : 1];
     // WHOLE: all 64 lanes of the wave exist; FULL: the whole tile exists (else nq groups of 4 samples)
     auto fetch = [&](size_t v, auto whole, auto full, int nq) __attribute__((always_inline)) {
         if constexpr (HAS_IN) {
             const char *src = xbase + v * size_t(IB);
 #pragma unroll
-            for (int j = 0; j < PI; j++) {
-                const int pc = mpci ^ (j & SI::SWM);
+            for (int j = 0; j < NII; j++) {
+                const int pc = mpci ^ ((mqi + j) & 15);
                 if ((decltype(whole)::value || size_t(mqi + j) < nrows) && (decltype(full)::value || pc < nq * IW))
                     stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + j * xrowb) + size_t(xoff + uint32_t(pc * 16))));
             }
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     auto hand_over = [&]() __attribute__((always_inline)) {
         if constexpr (HAS_IN) {
 #pragma unroll
-            for (int j = 0; j < PI; j++) *reinterpret_cast<u32x4 *>(slot_in + j * 1024 + lid * 16) = stage[j];
+            for (int j = 0; j < NII; j++) *reinterpret_cast<u32x4 *>(slot_in + j * 1024 + lid * 16) = stage[j];
         }
     };
     // four consecutive samples: IW input pieces in, OW output pieces out
@@ -824,8 +833,8 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     auto store = [&](size_t v, auto whole, auto full, int nq) __attribute__((always_inline)) {
         char *dst = ybase + v * size_t(OB);
 #pragma unroll
-        for (int j = 0; j < PO; j++) {
-            const int pc = mpco ^ (j & SO::SWM);
+        for (int j = 0; j < NIO; j++) {
+            const int pc = mpco ^ ((mqo + j) & 15);
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot_out + j * 1024 + lid * 16);
             if ((decltype(whole)::value || size_t(mqo + j) < nrows) && (decltype(full)::value || pc < nq * OW))
                 __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + j * yrowb) + size_t(yoff + uint32_t(pc * 16))));
@@ -859,7 +868,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
             store(nfull, whole, Part{}, nquad);
         }
     };
-    if (nrows == size_t(kWave))
+    if (nrows == size_t(LW))
         walk(std::true_type{});
     else
         walk(std::false_type{});
@@ -917,11 +926,28 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             const bool x_ok = !P::HAS_IN || (reinterpret_cast<uintptr_t>(x) % 16 == 0 && (xl * isz) % 16 == 0 && xl * isz < (size_t(1) << 26));
             if (!no_staged && frames * wide >= size_t(kLmRun) / 4 && x_ok && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
                 (yl * osz) % 16 == 0 && yl * osz < (size_t(1) << 26)) {
-                constexpr size_t bytes = lm_staged_lds_bytes<P>();
-                if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P>>(bytes)) return rc;
-                note_kernel("stream_lane_major_staged", typeid(P).name());
-                hipLaunchKernelGGL((stream_lane_major_staged<P>), dim3(grid), dim3(kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl);
-                return launch_status();
+                // lanes per wave: 64 when that already gives every SIMD a wave, else 32 or 16 (tools/tune_lm.hip;
+                // IDSP_DIAG=1 IDSP_LM_LANES_PER_WAVE = 64 / 32 / 16 forces one)
+                static const size_t forced_lw = diag_size("IDSP_LM_LANES_PER_WAVE", 0);
+                // measured (profiles/r02_tune_lm_lanes_per_wave.jsonl, 4096 frames): i32 DF1 at 16384 lanes 0.168 / 0.157 / 0.136 ms
+                // with 64 / 32 / 16 lanes per wave, at 32768 lanes 0.232 / 0.216 / 0.213, at 65536 0.382 / 0.393 / 0.446; the
+                // 8-section cascade (VALU-bound: half-empty waves cost arithmetic) 0.57 / 0.45 / 0.52 at 16384 and
+                // 0.61 / 0.91 / 1.56 at 65536
+                constexpr bool heavy = P::COST > 120;
+                const size_t lw = forced_lw ? forced_lw : lanes >= 49152 ? 64 : (lanes >= 24576 || heavy) ? 32 : 16;
+                auto go = [&](auto lw_tag) {
+                    constexpr int LW = decltype(lw_tag)::value;
+                    constexpr size_t bytes = lm_staged_lds_bytes<P, LW>();
+                    if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P, LW>>(bytes)) return rc;
+                    note_kernel(LW == 64 ? "stream_lane_major_staged" : LW == 32 ? "stream_lane_major_staged[32 lanes/wave]" : "stream_lane_major_staged[16 lanes/wave]",
+                                typeid(P).name());
+                    hipLaunchKernelGGL((stream_lane_major_staged<P, LW>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
+                                       lanes, frames, xl, yl);
+                    return launch_status();
+                };
+                if (lw == 16) return go(std::integral_constant<int, 16>{});
+                if (lw == 32) return go(std::integral_constant<int, 32>{});
+                return go(std::integral_constant<int, 64>{});
             }
         }
         note_kernel("stream_lane_major", typeid(P).name());

@@ -6,6 +6,9 @@ rows, out of place and in place, against the oracle bit for bit; the kernel take
 Reference semantics: one independent filter per lane over its own contiguous row (`View<LaneMajor>`,
 dsp-process/src/view.rs:181-195; `Lanes::process`, dsp-process/src/compose.rs:468-494)."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -16,6 +19,8 @@ from tests.test_gpu_pitch import DEV, SENT, cases, init_state, p, sample, tdtype
 
 pytestmark = pytest.mark.gpu
 LM = H.LM
+# lanes per wave forced by the environment (the last test re-runs this file that way); default: chosen by lane count and cost
+FORCED_LW = os.environ.get("IDSP_LM_LANES_PER_WAVE") if os.environ.get("IDSP_DIAG") == "1" else None
 
 # (lanes, frames, pitch): pitch * sizeof(sample) is a multiple of 16 in every case
 SHAPES = [
@@ -58,7 +63,9 @@ def test_every_biquad_entry_on_the_staged_kernel(gpu):
                 run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, inplace)
                 k = kernel_of(gpu)
                 staged = frames * np.dtype(dt).itemsize >= 128
-                assert k.startswith("stream_lane_major_staged<" if staged else "stream_lane_major<"), (op, lanes, frames, k)
+                assert k.startswith("stream_lane_major_staged" if staged else "stream_lane_major<"), (op, lanes, frames, k)
+                if staged and FORCED_LW:
+                    assert ("[%s lanes/wave]" % FORCED_LW in k) == (FORCED_LW != "64"), k
 
 
 def test_cascades_normal_lowpass_on_the_staged_kernel(gpu):
@@ -89,7 +96,7 @@ def test_cascades_normal_lowpass_on_the_staged_kernel(gpu):
                 rco, yo = ob.stream(op, cfg, n, so, x.copy(), lanes, frames, LM, inplace=inplace)
                 rcg, yg = gb.stream(op, cfg, n, sg, x.copy(), lanes, frames, LM, inplace=inplace)
                 assert rco == 0 and rcg == 0, (op, H.engine().err())
-                assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), (op, kernel_of(H.engine()))
+                assert kernel_of(H.engine()).startswith("stream_lane_major_staged"), (op, kernel_of(H.engine()))
                 assert np.array_equal(yo.view(np.uint8), yg.view(np.uint8)) and np.array_equal(so, sg), (op, lanes, frames, inplace)
         # Lowpass<N> cascades
         for order, casc in ((1, 1), (2, 2)):
@@ -102,7 +109,7 @@ def test_cascades_normal_lowpass_on_the_staged_kernel(gpu):
             rco, yo = ob.cfgcall("lowpass_i32", cfg, so, xi, (lanes * frames,), np.int32, lanes, frames, LM)
             rcg, yg = gb.cfgcall("lowpass_i32", cfg, sg, xi, (lanes * frames,), np.int32, lanes, frames, LM)
             assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), ("lowpass", order, casc)
-            assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), kernel_of(H.engine())
+            assert kernel_of(H.engine()).startswith("stream_lane_major_staged"), kernel_of(H.engine())
 
 
 def test_unaligned_rows_fall_back_to_the_tile_kernel(gpu):
@@ -140,7 +147,7 @@ def test_dds_and_polar_lockin_on_the_staged_kernel(gpu):
         _, yo = ob.dds(so, lanes, frames, LM)
         rc, yg = gb.dds(sg, lanes, frames, LM)
         assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
-        assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), kernel_of(H.engine())
+        assert kernel_of(H.engine()).startswith("stream_lane_major_staged"), kernel_of(H.engine())
     lc = H.lockin_cfg([[1 << 20, -(1 << 27)]] * 2)
     for lanes, frames in ((200, 100), (65, 36), (64, 516)):
         x = rng.integers(-(1 << 28), 1 << 28, size=lanes * frames, dtype=np.int32)
@@ -149,4 +156,18 @@ def test_dds_and_polar_lockin_on_the_staged_kernel(gpu):
         rco, yo = ob.cfgcall("lockin_i32_arg", lc, so, x, (lanes * frames,), np.int32, lanes, frames, LM)
         rcg, yg = gb.cfgcall("lockin_i32_arg", lc, sg, x, (lanes * frames,), np.int32, lanes, frames, LM)
         assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
-        assert kernel_of(H.engine()).startswith("stream_lane_major_staged<"), kernel_of(H.engine())
+        assert kernel_of(H.engine()).startswith("stream_lane_major_staged"), kernel_of(H.engine())
+
+
+@pytest.mark.parametrize("lw", ["64", "32", "16"])
+def test_every_lanes_per_wave_form_on_the_ragged_shapes(gpu, lw):
+    """The launcher picks 64 / 32 / 16 lanes per wave from the lane count and the processor's cost; the shapes above are all
+    small, so force each form in turn (IDSP_DIAG=1 IDSP_LM_LANES_PER_WAVE, read once per process) and re-run the biquad and
+    cascade tests of this file: partial last waves, partial tiles and scalar remainders on every form."""
+    if FORCED_LW:
+        pytest.skip("already inside a forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_LM_LANES_PER_WAVE=lw)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "every_biquad or cascades_normal"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -24,7 +24,7 @@ def test_every_family_reports_its_kernel(gpu):
     y = torch.empty(lanes * frames * 2, dtype=torch.int32, device=DEV)
     st = torch.zeros((32, lanes), dtype=torch.int32, device=DEV)
     cfg = H.biquad_i32([([1 << 28, 0, 0, 0, 0], 30)])
-    assert gpu.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, H.LM) == 0 and name().startswith("stream_lane_major_staged<")
+    assert gpu.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, H.LM) == 0 and name().startswith("stream_lane_major_staged[16 lanes/wave]<")
     assert "Df1I32<false>" in name()
     assert gpu.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, H.FM) == 0 and name().startswith("stream_frame_major<")
     lc = H.lockin_cfg([[1 << 20, -(1 << 27)]] * 2)

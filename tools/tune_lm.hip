@@ -255,18 +255,18 @@ void one(const char *name, const typename P::Params &prm, const Bufs &b, const S
     fflush(stdout);
 }
 
-template <class P>
+template <class P, int LW = 64>
 void one_staged(const char *name, const typename P::Params &prm, const Bufs &b, const Shape &sh, float tref, bool inplace = false)
 {
     using In = typename P::In;
     using Out = typename P::Out;
-    const size_t bytes = size_t(kWave) * kLmRun + P::LDS_WORDS * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_lane_major_staged<P>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
-    const unsigned grid = unsigned((sh.lanes + kWave - 1) / kWave);
+    const size_t bytes = lm_staged_lds_bytes<P, LW>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_lane_major_staged<P, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    const unsigned grid = unsigned((sh.lanes + LW - 1) / LW);
     const size_t n = sh.lanes * sh.pitch * sizeof(In);
     char *yy = b.y;
     auto launch = [&]() {
-        hipLaunchKernelGGL((stream_lane_major_staged<P>), dim3(grid), dim3(kWave), bytes, 0, prm, b.st, reinterpret_cast<const In *>(inplace ? yy : b.x),
+        hipLaunchKernelGGL((stream_lane_major_staged<P, LW>), dim3(grid), dim3(kWave), bytes, 0, prm, b.st, reinterpret_cast<const In *>(inplace ? yy : b.x),
                            reinterpret_cast<Out *>(yy), sh.lanes, sh.frames, sh.pitch, sh.pitch);
     };
     CK(hipMemset(b.st, 0, sh.lanes * 256));
@@ -287,8 +287,8 @@ void one_staged(const char *name, const typename P::Params &prm, const Bufs &b, 
         ok = memcmp(&got[l * sh.pitch * sizeof(In) / 4], &want[l * sh.pitch * sizeof(In) / 4], sh.frames * sizeof(In)) == 0;
     const float t = timeit(launch);
     const double gb = double(sh.lanes) * sh.frames * (sizeof(In) + sizeof(Out)) / 1e9;
-    printf("{\"proc\": \"%s\", \"lanes\": %zu, \"frames\": %zu, \"pitch\": %zu, \"nb\": 0, \"lb\": %d, \"nt\": \"staged%s\", \"ok\": %s, \"ms\": %.4f, \"frac\": %.3f, \"tile_ms\": %.4f, \"tile_frac\": %.3f}\n",
-           name, sh.lanes, sh.frames, sh.pitch, kLmRun, inplace ? " in place" : "", ok ? "true" : "false", t, gb / (t * 1e-3) / 8000, tref, gb / (tref * 1e-3) / 8000);
+    printf("{\"proc\": \"%s\", \"lanes\": %zu, \"frames\": %zu, \"pitch\": %zu, \"nb\": %d, \"lb\": %d, \"nt\": \"staged%s\", \"ok\": %s, \"ms\": %.4f, \"frac\": %.3f, \"tile_ms\": %.4f, \"tile_frac\": %.3f}\n",
+           name, sh.lanes, sh.frames, sh.pitch, LW, kLmRun, inplace ? " in place" : "", ok ? "true" : "false", t, gb / (t * 1e-3) / 8000, tref, gb / (tref * 1e-3) / 8000);
     fflush(stdout);
 }
 
@@ -310,8 +310,12 @@ void sweep(const char *name, const typename P::Params &prm, const Bufs &b, const
         CK(hipMemset(b.yref, 0xEE, sh.lanes * sh.pitch * sizeof(In)));
         ref();
         CK(hipDeviceSynchronize());
-        one_staged<P>(name, prm, b, sh, tref);
-        one_staged<P>(name, prm, b, sh, tref, true);
+        one_staged<P, 64>(name, prm, b, sh, tref);
+        one_staged<P, 64>(name, prm, b, sh, tref, true);
+        one_staged<P, 32>(name, prm, b, sh, tref);
+        one_staged<P, 32>(name, prm, b, sh, tref, true);
+        one_staged<P, 16>(name, prm, b, sh, tref);
+        one_staged<P, 16>(name, prm, b, sh, tref, true);
         if (exp_too && sizeof(In) == 4) {
             one<P, 1, 512>(name, prm, b, sh, tref);
             one<P, 2, 256>(name, prm, b, sh, tref);
