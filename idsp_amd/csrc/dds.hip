@@ -342,6 +342,7 @@ struct LockinPolarProc {
     static constexpr int kLut = 1 << kCossinDepth;
     static constexpr int LDS_WORDS = kLut + (MODE == 0 ? 32 : 0);  // cossin table, atan2 reciprocal table
     static constexpr int IN_DIV = 1;
+    static constexpr bool LM_ONE_FORM = true;  // stream fall-back of the multi-wave kernel: one LaneMajor form is enough
     static constexpr int COST = 110 + 80 * N * K + (MODE == 0 ? 80 : 10);
     using Params = LpParams;
     const uint32_t *lut;

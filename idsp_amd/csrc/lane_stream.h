@@ -663,6 +663,10 @@ struct LmStagedOf<P, std::enable_if_t<P::IN_DIV == 1 && (!P::HAS_IN || sizeof(ty
                                       (BatchOf<P>::value == 1 || BatchOf<P>::value == 4)>> {
     static constexpr bool value = true;
 };
+template <class P, class = void>
+struct LmOneFormOf : std::false_type {};
+template <class P>
+struct LmOneFormOf<P, std::void_t<decltype(P::LM_ONE_FORM)>> : std::integral_constant<bool, P::LM_ONE_FORM> {};
 // bytes of LDS the kernel needs for P (slots + the processor's table)
 template <class P, int LW>
 constexpr size_t lm_staged_lds_bytes()
@@ -945,8 +949,14 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                                        lanes, frames, xl, yl);
                     return launch_status();
                 };
-                if (lw == 16) return go(std::integral_constant<int, 16>{});
-                if (lw == 32) return go(std::integral_constant<int, 32>{});
+                // forms instantiated per processor: all three for the cheap ones, 64 / 32 for the heavy ones (never 16 above),
+                // 64 only for processors that ask for it (P::LM_ONE_FORM: rarely taken fall-back paths; build time)
+                if constexpr (!LmOneFormOf<P>::value) {
+                    if constexpr (!heavy) {
+                        if (lw == 16) return go(std::integral_constant<int, 16>{});
+                    }
+                    if (lw <= 32) return go(std::integral_constant<int, 32>{});
+                }
                 return go(std::integral_constant<int, 64>{});
             }
         }
