@@ -12,7 +12,9 @@ ORCFLAGS   := -O3 -std=c11 -fPIC -ffp-contract=off -fno-fast-math \
               -fwrapv -Wall -Wextra -D_GNU_SOURCE
 
 CSRC       := idsp_amd/csrc
-HIP_SRCS   := $(wildcard $(CSRC)/*.hip)
+# the translation units that compile longest go first, so that `make -j` does not end on one of them
+HIP_SLOW   := $(addprefix $(CSRC)/,dds.hip normal_wdf.hip cascade.hip biquad_f64.hip cic_int_i64_hi.hip cic_int_i32_hi.hip)
+HIP_SRCS   := $(HIP_SLOW) $(filter-out $(HIP_SLOW),$(wildcard $(CSRC)/*.hip))
 HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 HIP_HDRS   := $(wildcard $(CSRC)/*.h) include/idsp_hip.h
 

@@ -889,6 +889,163 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     }
 }
 
+// ------------------------------------------- FRAME_MAJOR, few lanes (staged)
+// Below ~49152 lanes the FrameMajor kernels above stop being bandwidth-bound: a lane is a serial chain, the LDS-DMA
+// kernel pays two workgroup barriers per 8 frames and the register-window kernel a global-load wait per frame, and both
+// take the same ~0.33 ms for 4096 frames whatever the lane count (80 ns = 190 cycles per frame and wave), so the rate
+// falls with the lanes: 0.61 of the HBM peak at 49152 lanes, 0.41 at 32768, 0.20 at 16384 — while the LaneMajor staged
+// kernel, whose threads run 128 frames from LDS without a barrier, needs 36 ns per frame.  This kernel gives FrameMajor
+// buffers the same structure: one wave per workgroup owns LW lanes (64 / 32 / 16, as in the LaneMajor kernel); a tile is
+// 32 KiB = TF frames x LW lanes, fetched as 16-byte pieces (one instruction = 1 KiB = 1024 / (LW W 4) row pieces — the
+// neighbouring waves read the neighbouring pieces of the same rows) into VGPRs one tile ahead, handed to LDS linearly
+// (instruction j's 1 KiB at 1024 j: the slot is [frame][lane]), walked by the owning thread down its column (conflict
+// free: consecutive lanes, consecutive banks; two frames per ds_read2st64), results written in place, the slot re-read
+// linearly and stored as whole row pieces.  Rows must be 16-byte aligned (lanes and pitches multiples of 4 / W).
+constexpr int kFmStagedTile = 32768;  // bytes per tile
+template <class P, class = void>
+struct FmStagedOf {
+    static constexpr bool value = false;
+};
+template <class P>
+struct FmStagedOf<P, std::enable_if_t<P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == sizeof(typename P::Out) &&
+                                      (sizeof(typename P::In) == 4 || sizeof(typename P::In) == 8) && BatchOf<P>::value == 1>> {
+    static constexpr bool value = true;
+};
+
+template <class P, int LW>
+__global__ __launch_bounds__(kWave) void stream_frame_major_staged(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    static_assert(FmStagedOf<P>::value && (LW == 64 || LW == 32 || LW == 16), "one 4- or 8-byte input and output per lane and frame");
+    constexpr int W = int(sizeof(In)) / 4;          // words per sample
+    constexpr int RB = LW * W * 4;                  // bytes of a row piece (one frame of the wave's lanes)
+    constexpr int TF = kFmStagedTile / RB;          // frames per tile
+    constexpr int PPR = RB / 16;                    // 16-byte pieces per row piece
+    constexpr int RPI = kWave / PPR;                // rows one instruction covers
+    constexpr int NI = kFmStagedTile / 1024;        // instructions per tile
+    constexpr int NS = 16;                          // frames per compute chunk
+    static_assert(TF % NS == 0 && NI * RPI == TF, "tile shape");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    using Word = std::conditional_t<W == 1, uint32_t, uint64_t>;
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    char *const slot = reinterpret_cast<char *>(smem);
+    uint32_t *ptab = smem + kFmStagedTile / 4;  // [P::LDS_WORDS]
+    const int lid = threadIdx.x;
+
+    const size_t lane0 = size_t(blockIdx.x) * LW;
+    const size_t nrows = lanes - lane0 < size_t(LW) ? lanes - lane0 : size_t(LW);  // lanes of this wave (a multiple of 4 / W)
+    const bool active = size_t(lid) < nrows;
+
+    P p;
+    if constexpr (P::LDS_WORDS > 0) {
+        P::fill_shared(ptab, lid, kWave);
+        lds_wave_sync();
+        p.set_shared(ptab);
+    }
+    if (active) p.load(prm, st, lanes, lane0 + lid);
+
+    // mover role: in instruction j, row j RPI + mrow of the tile, piece mpc of the row piece; addresses = wave-uniform base
+    // (SGPRs, see uniform_ptr) + 32-bit thread offset
+    const size_t xrowb = xl * sizeof(In), yrowb = yl * sizeof(Out);  // bytes between frames
+    const int mrow = lid / PPR, mpc = lid % PPR;
+    const bool mine = size_t(mpc) * 16 < nrows * sizeof(In);  // this thread's piece lies inside the wave's lanes
+    const char *const xbase = reinterpret_cast<const char *>(x) + lane0 * sizeof(In);
+    char *const ybase = reinterpret_cast<char *>(y) + lane0 * sizeof(Out);
+    const uint32_t xoff = uint32_t(mrow) * uint32_t(xrowb) + uint32_t(mpc) * 16, yoff = uint32_t(mrow) * uint32_t(yrowb) + uint32_t(mpc) * 16;
+
+    const size_t nfull = frames / TF;
+    const int ntail = int(frames - nfull * TF);  // frames of the last, partial tile
+    u32x4 stage[NI];
+    // FULL: all TF frames of the tile exist (else nf of them).  `mine` masks the pieces of missing lanes (last wave only; one
+    // code path for whole and partial waves: the predicate is a loop-invariant exec mask, and the kernel compiles once)
+    auto fetch = [&](size_t v, auto full, int nf) __attribute__((always_inline)) {
+        const char *src = xbase + v * TF * xrowb;
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+            if (mine && (decltype(full)::value || j * RPI + mrow < nf))
+                stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + size_t(j * RPI) * xrowb) + size_t(xoff)));
+    };
+    auto hand_over = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NI; j++) *reinterpret_cast<u32x4 *>(slot + j * 1024 + lid * 16) = stage[j];
+    };
+    Word *const col = reinterpret_cast<Word *>(slot) + lid;  // this thread's column: frame f at col[f LW]
+    auto one = [&](Word w) __attribute__((always_inline)) {
+        uint32_t ww[W];
+        ww[0] = uint32_t(w);
+        if constexpr (W == 2) ww[1] = uint32_t(uint64_t(w) >> 32);
+        to_words<Out>(p.step(prm, words_to<In>(ww)), ww);
+        if constexpr (W == 2)
+            return Word(uint64_t(ww[0]) | (uint64_t(ww[1]) << 32));
+        else
+            return Word(ww[0]);
+    };
+    auto compute = [&](auto full, int nf) __attribute__((always_inline)) {
+        if (!active) return;
+        if constexpr (!decltype(full)::value || MaxU<P>::value < 24) {
+            for (int f = 0; f < nf; f++) col[f * LW] = one(col[f * LW]);  // partial tile, or a large body: keep the loop rolled
+        } else {
+            // chunks of NS frames: the next chunk's LDS reads are issued before the current chunk's arithmetic; the fence
+            // keeps the compiler from hoisting all reads of the tile above the first step
+            Word cur[NS], nxt[NS];
+#pragma unroll
+            for (int c = 0; c < NS; c++) cur[c] = col[c * LW];
+#pragma unroll
+            for (int g = 0; g < TF / NS; g++) {
+                if (g + 1 < TF / NS) {
+#pragma unroll
+                    for (int c = 0; c < NS; c++) nxt[c] = col[((g + 1) * NS + c) * LW];
+                }
+#pragma unroll
+                for (int c = 0; c < NS; c++) col[(g * NS + c) * LW] = one(cur[c]);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < NS; c++) cur[c] = nxt[c];
+            }
+        }
+    };
+    auto store = [&](size_t v, auto full, int nf) __attribute__((always_inline)) {
+        char *dst = ybase + v * TF * yrowb;
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
+            if (mine && (decltype(full)::value || j * RPI + mrow < nf))
+                __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + size_t(j * RPI) * yrowb) + size_t(yoff)));
+            if (j % 8 == 7) asm volatile("" ::: "memory");
+        }
+    };
+    using Full = std::true_type;
+    using Part = std::false_type;
+    if (nfull > 0)
+        fetch(0, Full{}, TF);
+    else
+        fetch(0, Part{}, ntail);
+    for (size_t i = 0; i < nfull; i++) {
+        hand_over();
+        lds_wave_sync();
+        if (i + 1 < nfull)
+            fetch(i + 1, Full{}, TF);
+        else if (ntail > 0)
+            fetch(i + 1, Part{}, ntail);
+        compute(Full{}, TF);
+        lds_wave_sync();
+        store(i, Full{}, TF);
+        lds_wave_sync();
+    }
+    if (ntail > 0) {
+        hand_over();
+        lds_wave_sync();
+        compute(Part{}, ntail);
+        lds_wave_sync();
+        store(nfull, Part{}, ntail);
+    }
+    if (active) p.store(prm, st, lanes, lane0 + lid);
+}
+
 // --------------------------------------------------------------------- launch
 // Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
 // latency, so go deep; with many resident waves keep the register budget low.
@@ -965,6 +1122,40 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
     } else {
         const size_t xl = pitch.x ? pitch.x : lanes / P::IN_DIV, yl = pitch.y ? pitch.y : lanes;
         const size_t waves = (lanes + kWave - 1) / kWave;
+        if constexpr (FmStagedOf<P>::value) {
+            // Few lanes (the chip is not full and every FrameMajor kernel below runs at its per-lane latency): the staged
+            // single-wave kernel.  Measured against the register-window and the LDS-DMA kernel (tools/tune_fm_small.hip,
+            // profiles/r02_tune_fm_small.jsonl; i32 DF1 x 4096 frames): 16384 lanes 0.147 ms (32 lanes per wave) against
+            // 0.211 / 0.335; 32768 lanes 0.211 (64) against 0.243 / 0.332; 8192 x 8192 0.247 against 0.384; 49152 lanes 0.32
+            // against 0.33 / 0.33; 65536 lanes 0.43 against 0.41 / 0.335.  Processors with COST > 120 gain only around
+            // 16384-32768 lanes (8-section cascade 0.44 against 0.48) and lose elsewhere.
+            // (IDSP_DIAG=1 IDSP_NO_FM_STAGED=1: never; IDSP_FM_LANES_PER_WAVE = 64 / 32 / 16 forces the form at any lane count)
+            static const bool no_fm_staged = diag_env("IDSP_NO_FM_STAGED") != nullptr;
+            static const size_t forced_flw = diag_size("IDSP_FM_LANES_PER_WAVE", 0);
+            constexpr size_t sz = sizeof(typename P::In);
+            constexpr bool heavy = P::COST > 120;
+            const bool in_range = heavy ? (lanes >= 12288 && lanes < 40960) : lanes < 49152;
+            if (!no_fm_staged && (forced_flw || in_range) && frames >= 16 && (lanes * sz) % 16 == 0 && (xl * sz) % 16 == 0 &&
+                (yl * sz) % 16 == 0 && xl * sz < (size_t(1) << 30) && yl * sz < (size_t(1) << 30) &&
+                reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0) {
+                const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= 24576 ? 64 : lanes >= 8192 ? 32 : 16;
+                auto go = [&](auto lw_tag) {
+                    constexpr int LW = decltype(lw_tag)::value;
+                    constexpr size_t bytes = size_t(kFmStagedTile) + size_t(P::LDS_WORDS) * 4;
+                    if (int rc = ensure_dyn_lds<&stream_frame_major_staged<P, LW>>(bytes)) return rc;
+                    note_kernel(LW == 64 ? "stream_frame_major_staged[64 lanes/wave]" : LW == 32 ? "stream_frame_major_staged[32 lanes/wave]" : "stream_frame_major_staged[16 lanes/wave]",
+                                typeid(P).name());
+                    hipLaunchKernelGGL((stream_frame_major_staged<P, LW>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
+                                       lanes, frames, xl, yl);
+                    return launch_status();
+                };
+                if constexpr (!heavy) {
+                    if (lw == 16) return go(std::integral_constant<int, 16>{});
+                    if (lw == 64) return go(std::integral_constant<int, 64>{});
+                }
+                return go(std::integral_constant<int, 32>{});
+            }
+        }
         if constexpr (P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4) {
             // cheap per-sample arithmetic (the extra LDS hop and the two barriers per tile cost issue
             // slots), whole 256-lane blocks, 16-byte aligned rows: LDS-DMA path

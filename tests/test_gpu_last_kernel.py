@@ -26,7 +26,7 @@ def test_every_family_reports_its_kernel(gpu):
     cfg = H.biquad_i32([([1 << 28, 0, 0, 0, 0], 30)])
     assert gpu.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, H.LM) == 0 and name().startswith("stream_lane_major_staged[16 lanes/wave]<")
     assert "Df1I32<false>" in name()
-    assert gpu.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, H.FM) == 0 and name().startswith("stream_frame_major<")
+    assert gpu.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, H.FM) == 0 and name().startswith("stream_frame_major_staged[16 lanes/wave]<")
     lc = H.lockin_cfg([[1 << 20, -(1 << 27)]] * 2)
     assert gpu.cfgcall("lockin_i32_process", lc, st, x, y, lanes, frames, H.FM) == 0 and name().startswith("lockin_waves_kernel[4 waves")
     hc = _abi.HbfCascadeF32()

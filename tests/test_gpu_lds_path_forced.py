@@ -83,7 +83,7 @@ print("forced LDS path ok")
 
 
 def test_heavy_processors_on_the_lds_dma_kernel(gpu):
-    env = dict(os.environ, IDSP_DIAG="1", IDSP_LDS_COST="100000", IDSP_LDS_MIN_WAVES="0", IDSP_LOCKIN_NO_WAVES="1")
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_LDS_COST="100000", IDSP_LDS_MIN_WAVES="0", IDSP_LOCKIN_NO_WAVES="1", IDSP_NO_FM_STAGED="1")
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "forced LDS path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -97,7 +97,7 @@ sys.path.insert(0, %r)
 from tests import _harness as H
 from tests._backends import GpuBackend
 gb = GpuBackend()
-lanes, frames = 16384, 16
+lanes, frames = 65536, 16  # from 49152 lanes up FrameMajor takes the LDS-DMA kernel (below: the staged single-wave kernel)
 x = np.zeros(lanes * frames, np.int32); st = np.zeros((4, lanes), np.uint32)
 rc, _ = gb.stream("biquad_i32_df1", H.biquad_i32([([1 << 28, 0, 0, 0, 0], 30)]), 1, st, x, lanes, frames, H.FM)
 assert rc == 0

@@ -28,7 +28,8 @@ def test_parity_suites_on_buffers_without_16_byte_alignment(gpu, mode):
         # every FrameMajor case with whole 256-lane blocks (SHAPES holds ragged-frame ones) on the LDS-DMA kernel whatever
         # the processor's cost or the launch size: clamp / f32 DF1 / ByLane / Normal functors meet the oracle there;
         # "lds-persistent": a grid of 3 workgroups walks the 256-lane blocks (uneven shares, several blocks per workgroup)
-        env.update(IDSP_DIAG="1", IDSP_LDS_MIN_WAVES="0", IDSP_LDS_COST="100000", IDSP_LDS_GRID="3" if mode == "lds-persistent" else "0")
+        env.update(IDSP_DIAG="1", IDSP_LDS_MIN_WAVES="0", IDSP_LDS_COST="100000", IDSP_LDS_GRID="3" if mode == "lds-persistent" else "0",
+                   IDSP_NO_FM_STAGED="1")
     r = subprocess.run([sys.executable, "-m", "pytest", *SUITES, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

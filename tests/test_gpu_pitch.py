@@ -128,11 +128,12 @@ def test_dense_pitch_equals_plain_entry_and_errors(gpu):
 
 
 def test_frame_major_lane_block_in_place_on_the_lds_kernel(gpu):
-    """A 512-lane block at lane offset 256 of a 1280-lane FRAME_MAJOR tensor, in place, 16384+ lanes' worth of rows so the
-    LDS-DMA kernel takes it (pitch 1280 elements: 16-byte aligned rows), against the oracle; neighbours untouched."""
+    """A 65536-lane block at lane offset 8192 of a 98304-lane FRAME_MAJOR tensor, in place, wide enough for the LDS-DMA kernel
+    (16-byte aligned rows), against the oracle; neighbours untouched.  (A 16384-lane block of a 32768-lane tensor the same
+    way on the staged few-lanes kernel.)"""
     o = H.oracle()
     rng = np.random.default_rng(9)
-    L, lanes, frames, off = 32768, 16384, 67, 8192
+    L, lanes, frames, off = 98304, 65536, 35, 8192
     xh = sample(rng, np.int32, L * frames).reshape(frames, L)
     cfg = H.biquad_i32([(rng.integers(-(1 << 29), 1 << 29, size=5).tolist(), 30)])
     sub = np.ascontiguousarray(xh[:, off:off + lanes])
