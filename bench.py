@@ -262,7 +262,7 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
     alg_bytes = algorithmic_bytes(cfg, lanes_rank, frames)
     med = statistics.median(kern_ms) if kern_ms else 0.0
     achieved = alg_bytes / (med * 1e-3) / 1e9 if med > 0 else 0.0
-    traffic, traffic_src = committed_traffic(cfg_name, kernel) if args.layout == "frame" and not args.lanes else (None, None)
+    traffic, traffic_src = committed_traffic(cfg_name if args.layout == "frame" else cfg_name + "_lane", kernel) if not args.lanes else (None, None)
     return {
         "metric": cfg["metric"],
         "value": round(samples_all * args.steps / elapsed / 1e6, 1),

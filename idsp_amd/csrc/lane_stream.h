@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
             const char *src = xbase + v * size_t(IB);
 #pragma unroll
             for (int j = 0; j < NII; j++) {
-                const int pc = mpci ^ ((mqi + j) & 15);
+                const int pc = mpci ^ (NII % 16 == 0 ? j & 15 : (mqi + j) & 15);  // mqi is a multiple of NII: a constant when 16 | NII
                 if ((decltype(whole)::value || size_t(mqi + j) < nrows) && (decltype(full)::value || pc < nq * IW))
                     stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + j * xrowb) + size_t(xoff + uint32_t(pc * 16))));
             }
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
         char *dst = ybase + v * size_t(OB);
 #pragma unroll
         for (int j = 0; j < NIO; j++) {
-            const int pc = mpco ^ ((mqo + j) & 15);
+            const int pc = mpco ^ (NIO % 16 == 0 ? j & 15 : (mqo + j) & 15);
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot_out + j * 1024 + lid * 16);
             if ((decltype(whole)::value || size_t(mqo + j) < nrows) && (decltype(full)::value || pc < nq * OW))
                 __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + j * yrowb) + size_t(yoff + uint32_t(pc * 16))));
