@@ -1,8 +1,10 @@
-// tune_lm.hip — LaneMajor: the LDS-DMA line mover (exp_lane_major_lds<P, NB, LB, NTL, NTS, PF>) against the 4-byte tile kernel
-// (stream_lane_major<P>) per processor, lane count, row pitch and ring depth; every combination is first compared bit
-// for bit (outputs and states) with the tile kernel on random input.  One JSON line per combination.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fwrapv -fno-slp-vectorize -Iinclude -Iidsp_amd/csrc \
-//         tools/tune_lm.hip -o build/tune_lm
+// tune_lm.hip — LaneMajor: the staged 16-byte-piece kernel (stream_lane_major_staged<P, LW>: 512-byte runs per lane, 64 / 32 /
+// 16 lanes per wave) against the 4-byte tile kernel (stream_lane_major<P>) per processor, lane count and row pitch; every
+// combination is first compared bit for bit (outputs and states) with the tile kernel on random input, out of place and in
+// place.  Also carries the LDS-DMA experiments the staged kernel came from (exp_lane_major_lds<P, NB, LB, NTL, NTS, PF>: run
+// length LB, ring depth NB, nontemporal on / off, touch-prefetch PF), kept here as the record.  One JSON line per combination.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fwrapv -fno-slp-vectorize -Wno-pass-failed -Iinclude \
+//         -Iidsp_amd/csrc tools/tune_lm.hip -o build/tune_lm
 //   build/tune_lm [processor index, -1 = all] [1 = also the LDS-DMA experiments]
 #include <algorithm>
 #include <cstdio>
