@@ -668,11 +668,11 @@ struct LmOneFormOf : std::false_type {};
 template <class P>
 struct LmOneFormOf<P, std::void_t<decltype(P::LM_ONE_FORM)>> : std::integral_constant<bool, P::LM_ONE_FORM> {};
 // bytes of LDS the kernel needs for P (slots + the processor's table)
-template <class P, int LW>
+template <class P, int LW, int LB = kLmRun>
 constexpr size_t lm_staged_lds_bytes()
 {
     constexpr int IW = P::HAS_IN ? int(sizeof(typename P::In)) / 4 : 0, OW = int(sizeof(typename P::Out)) / 4;
-    constexpr int S = IW > OW ? IW : OW, TF = kLmRun / 4 / S;
+    constexpr int S = IW > OW ? IW : OW, TF = LB / 4 / S;
     constexpr int IB = TF * IW * 4, OB = TF * OW * 4;
     return size_t(LW) * (IB == OB ? OB : IB + OB) + size_t(P::LDS_WORDS) * 4;
 }
@@ -683,14 +683,14 @@ constexpr size_t lm_staged_lds_bytes()
 template <int RB, int LW>
 struct LmSide {
     static constexpr int PCS = RB / 16, G = PCS ? kWave / PCS : 1, NI = LW / G;
-    static_assert(PCS == 0 || PCS == 16 || PCS == 32, "256- or 512-byte runs");
+    static_assert(PCS == 0 || PCS == 16 || PCS == 32 || PCS == 64, "256-, 512- or 1024-byte runs");
 };
 
 // LW = lanes per wave (64, 32 or 16).  With fewer than 64 the wave still moves whole runs with all its threads, but only
 // the first LW threads own a lane: a launch of few lanes then spreads over LW / 64 times as many waves (SIMDs) — below
 // 65536 lanes a 64-lane wave per SIMD leaves most of the chip without a wave, and the per-lane recurrence is a serial
 // chain that one wave cannot speed up.
-template <class P, int LW = kWave>
+template <class P, int LW = kWave, int LB = kLmRun>
 __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     constexpr bool HAS_IN = P::HAS_IN;
     constexpr int IW = HAS_IN ? int(sizeof(In)) / 4 : 0, OW = int(sizeof(Out)) / 4;  // words per sample
     constexpr int S = IW > OW ? IW : OW;
-    constexpr int TF = kLmRun / 4 / S;             // frames per tile
+    constexpr int TF = LB / 4 / S;                 // frames per tile (LB = bytes per lane and tile on the wider side)
     constexpr int IB = TF * IW * 4, OB = TF * OW * 4;  // bytes per lane and tile
     static_assert(LW == 64 || LW == 32 || LW == 16, "lanes per wave");
     using SI = LmSide<IB, LW>;
@@ -1098,11 +1098,15 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 const size_t lw = forced_lw ? forced_lw : lanes >= 49152 ? 64 : (lanes >= 24576 || heavy) ? 32 : 16;
                 auto go = [&](auto lw_tag) {
                     constexpr int LW = decltype(lw_tag)::value;
-                    constexpr size_t bytes = lm_staged_lds_bytes<P, LW>();
-                    if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P, LW>>(bytes)) return rc;
+                    // the 32- and 16-lane forms move 1 KiB per lane and tile (the same 32 / 16 KiB slot and staging registers
+                    // as 512-byte runs would need at twice the lanes): 5-10 % faster at 16384 lanes and below, 10-20 % on rows
+                    // that are not 128-byte aligned, equal at 65536 lanes (profiles/r02_tune_lm_run1k.jsonl)
+                    constexpr int LB = LW == 64 ? kLmRun : 2 * kLmRun;
+                    constexpr size_t bytes = lm_staged_lds_bytes<P, LW, LB>();
+                    if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P, LW, LB>>(bytes)) return rc;
                     note_kernel(LW == 64 ? "stream_lane_major_staged" : LW == 32 ? "stream_lane_major_staged[32 lanes/wave]" : "stream_lane_major_staged[16 lanes/wave]",
                                 typeid(P).name());
-                    hipLaunchKernelGGL((stream_lane_major_staged<P, LW>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
+                    hipLaunchKernelGGL((stream_lane_major_staged<P, LW, LB>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
                                        lanes, frames, xl, yl);
                     return launch_status();
                 };

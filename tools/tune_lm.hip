@@ -1,11 +1,11 @@
-// tune_lm.hip — LaneMajor: the staged 16-byte-piece kernel (stream_lane_major_staged<P, LW>: 512-byte runs per lane, 64 / 32 /
+// tune_lm.hip — LaneMajor: the staged 16-byte-piece kernel (stream_lane_major_staged<P, LW, LB>: 512-byte runs per lane, 64 / 32 /
 // 16 lanes per wave) against the 4-byte tile kernel (stream_lane_major<P>) per processor, lane count and row pitch; every
 // combination is first compared bit for bit (outputs and states) with the tile kernel on random input, out of place and in
 // place.  Also carries the LDS-DMA experiments the staged kernel came from (exp_lane_major_lds<P, NB, LB, NTL, NTS, PF>: run
 // length LB, ring depth NB, nontemporal on / off, touch-prefetch PF), kept here as the record.  One JSON line per combination.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fwrapv -fno-slp-vectorize -Wno-pass-failed -Iinclude \
 //         -Iidsp_amd/csrc tools/tune_lm.hip -o build/tune_lm
-//   build/tune_lm [processor index, -1 = all] [1 = also the LDS-DMA experiments]
+//   build/tune_lm [processor index, -1 = all] [1 = also 1 KiB runs at 32 / 16 lanes per wave, 2 = also the LDS-DMA experiments]
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -257,18 +257,18 @@ void one(const char *name, const typename P::Params &prm, const Bufs &b, const S
     fflush(stdout);
 }
 
-template <class P, int LW = 64>
+template <class P, int LW = 64, int LB = kLmRun>
 void one_staged(const char *name, const typename P::Params &prm, const Bufs &b, const Shape &sh, float tref, bool inplace = false)
 {
     using In = typename P::In;
     using Out = typename P::Out;
-    const size_t bytes = lm_staged_lds_bytes<P, LW>();
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_lane_major_staged<P, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    const size_t bytes = lm_staged_lds_bytes<P, LW, LB>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_lane_major_staged<P, LW, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
     const unsigned grid = unsigned((sh.lanes + LW - 1) / LW);
     const size_t n = sh.lanes * sh.pitch * sizeof(In);
     char *yy = b.y;
     auto launch = [&]() {
-        hipLaunchKernelGGL((stream_lane_major_staged<P, LW>), dim3(grid), dim3(kWave), bytes, 0, prm, b.st, reinterpret_cast<const In *>(inplace ? yy : b.x),
+        hipLaunchKernelGGL((stream_lane_major_staged<P, LW, LB>), dim3(grid), dim3(kWave), bytes, 0, prm, b.st, reinterpret_cast<const In *>(inplace ? yy : b.x),
                            reinterpret_cast<Out *>(yy), sh.lanes, sh.frames, sh.pitch, sh.pitch);
     };
     CK(hipMemset(b.st, 0, sh.lanes * 256));
@@ -290,11 +290,12 @@ void one_staged(const char *name, const typename P::Params &prm, const Bufs &b, 
     const float t = timeit(launch);
     const double gb = double(sh.lanes) * sh.frames * (sizeof(In) + sizeof(Out)) / 1e9;
     printf("{\"proc\": \"%s\", \"lanes\": %zu, \"frames\": %zu, \"pitch\": %zu, \"nb\": %d, \"lb\": %d, \"nt\": \"staged%s\", \"ok\": %s, \"ms\": %.4f, \"frac\": %.3f, \"tile_ms\": %.4f, \"tile_frac\": %.3f}\n",
-           name, sh.lanes, sh.frames, sh.pitch, LW, kLmRun, inplace ? " in place" : "", ok ? "true" : "false", t, gb / (t * 1e-3) / 8000, tref, gb / (tref * 1e-3) / 8000);
+           name, sh.lanes, sh.frames, sh.pitch, LW, LB, inplace ? " in place" : "", ok ? "true" : "false", t, gb / (t * 1e-3) / 8000, tref, gb / (tref * 1e-3) / 8000);
     fflush(stdout);
 }
 
 static bool exp_too = false;
+static int exp_level = 0;
 template <class P>
 void sweep(const char *name, const typename P::Params &prm, const Bufs &b, const std::vector<Shape> &shapes)
 {
@@ -318,7 +319,12 @@ void sweep(const char *name, const typename P::Params &prm, const Bufs &b, const
         one_staged<P, 32>(name, prm, b, sh, tref, true);
         one_staged<P, 16>(name, prm, b, sh, tref);
         one_staged<P, 16>(name, prm, b, sh, tref, true);
-        if (exp_too && sizeof(In) == 4) {
+        if (exp_too) {
+            one_staged<P, 32, 1024>(name, prm, b, sh, tref);
+            one_staged<P, 32, 1024>(name, prm, b, sh, tref, true);
+            one_staged<P, 16, 1024>(name, prm, b, sh, tref);
+        }
+        if (exp_level >= 2 && sizeof(In) == 4) {
             one<P, 1, 512>(name, prm, b, sh, tref);
             one<P, 2, 256>(name, prm, b, sh, tref);
             one<P, 4, 128>(name, prm, b, sh, tref);
@@ -345,7 +351,8 @@ bq::ChainParams<SecP, N> params_n()
 int main(int argc, char **argv)
 {
     const int only = argc > 1 ? atoi(argv[1]) : -1;
-    exp_too = argc > 2 && atoi(argv[2]) != 0;
+    exp_level = argc > 2 ? atoi(argv[2]) : 0;
+    exp_too = exp_level != 0;
     Bufs b;
     b.cap = size_t(3) << 30;
     CK(hipMalloc(&b.x, b.cap));
