@@ -5,25 +5,45 @@
     i32 DF1 biquad, 65536 lanes x 4096 samples per lane, shared Q30 coefficients,
     `idsp_biquad_i32_df1` on a FRAME_MAJOR `[[i32; 65536]; 4096]` tensor (1 GiB in, 1 GiB out).
     With --gpus N every rank runs this per-GPU workload on its own lanes (WEAK scaling).
+    The line also carries a `c5` sub-object (below) so that one command yields both scaling curves.
 --config c5 (BASELINE.json configs[4], "C5"):
     f32 DF2T biquad over 2^20 lanes x 4096 samples (16 GiB in, 16 GiB out in total), the lanes split
     contiguously over the ranks by idsp_amd.sharding.lane_shard (STRONG scaling: total work fixed).
 
+Ranks.  `python bench.py --gpus N` with no torchrun environment starts N ranks itself (it re-executes
+this file under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`);
+under an external torchrun (WORLD_SIZE set) it is one of the ranks.  One rank per GPU over RCCL (the
+"nccl" backend on ROCm); when the box has fewer GPUs than ranks the ranks share devices and rendezvous
+over gloo — a control-flow check, said so in the line (`ranks_share_device`).  `rccl_ranks` is the
+result of a 1-int SUM all-reduce over the process group.
+
 A step = one pass of the hot path over the rank's batch, state carried from step to step like
 consecutive `block()` calls (dsp-process/src/process.rs:122-127).  Inputs are resident in HBM before
 the timed region.  Lanes never interact (dsp-process/src/compose.rs:468-494), so there is no data-path
-collective — only the barriers that bracket the timed region and the MAX all-reduce of the elapsed time.
+collective — only the barriers that bracket the timed region, the MAX all-reduce of the elapsed time
+and, outside the timed region, the 8-byte output-checksum all-reduce of SURVEY.md §8e.
 
 Timing: W untimed warm-up steps, then further untimed steps until --settle-ms of wall time have passed
-(the first launches after an idle gap run at a lower clock: round 1's driver run with 5 warm-up steps read
-0.403 ms where the steady state is 0.337 ms), then EXACTLY K timed steps between barrier +
+(the first launches after an idle gap run at a lower clock), then EXACTLY K timed steps between barrier +
 synchronize pairs; `value` comes from that wall-clock interval (max over ranks).  Every timed step is also
 bracketed by HIP events on the launch stream: `roofline` prices the MEDIAN of those kernel durations
 against HBM (8 B of algorithmic traffic per sample + the state planes once each way), and reports the
 minimum and the mean beside it.  x and y are two plain, separate allocations.
 
-`cpu_baseline` times the CPU oracle (a C port of the reference's scalar loop — the reference is Rust and
-cannot be built here) on the host cores of the same box, on a bounded sample of the same workload.
+Integrity (`integrity`): after the timed region every rank zeroes its state, runs ONE more step and sums
+the 32-bit words of its output and of its written-back state (wrapping 64-bit sums).  The y sums meet in
+`sharding.allreduce_checksum`; every rank's pair is compared with the CPU oracle's value for that rank's
+input (tests/golden/bench_checksums.json, made by tests/golden/make_bench_checksums.py) and — at N = 1 —
+with the oracle run live on the same tensor in the cpu_baseline leg.
+
+Inputs.  C2: SURVEY.md §8d's stream, `numpy.random.default_rng(2).integers(-2^24, 2^24, (4096, 65536))`
+on rank 0 (`default_rng([2, r])` on rank r > 0).  C5: a counter hash of (frame, global lane) evaluated on
+the device (`c5_input`), uniform in [-1, 1) — the 2^32-sample tensor is then the same whatever the number of
+ranks, which is what lets the strong-scaling checksums be compared across N.
+
+`cpu_baseline` times the CPU oracle (a C port of the reference's scalar loops — the reference is Rust and
+cannot be built here) on the host cores of the same box: pinned POSIX threads inside the C library over
+contiguous lane blocks, both layouts, all allowed cores and one thread.
 """
 from __future__ import annotations
 
@@ -32,7 +52,9 @@ import ctypes as C
 import json
 import math
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -42,16 +64,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 F0 = 0.01
 FRAC = 30
+MASK64 = (1 << 64) - 1
+C5_BLOCK = 131072  # lanes per checksum block of C5 (= one rank's shard at N = 8)
+C5_CPU_LANES = 16384  # lane prefix of C5 the cpu_baseline leg runs (and the live checksum comparison covers)
 
 CONFIGS = {
     "c2": dict(
         metric="i32_df1_biquad_64k_lanes_throughput", entry="biquad_i32_df1", dtype="i32", lanes=65536, frames=4096,
-        scaling="weak", state_words=4, bytes_per_sample=8, seed=2,
+        scaling="weak", state_words=4, bytes_per_sample=8, seed=2, oracle_kind=0,
         workload="configs[1]: 65536-lane i32 Biquad DF1 (Q30 lowpass f0=0.01), shared coeffs, 4096 samples/lane, per GPU",
     ),
     "c5": dict(
         metric="f32_df2t_biquad_1M_lanes_throughput", entry="biquad_f32_df2t", dtype="f32", lanes=1 << 20, frames=4096,
-        scaling="strong", state_words=2, bytes_per_sample=8, seed=5,
+        scaling="strong", state_words=2, bytes_per_sample=8, seed=5, oracle_kind=1,
         workload="configs[4]: 2^20-lane f32 Biquad DF2T (lowpass f0=0.01), shared coeffs, 4096 samples/lane, "
                  "lanes split contiguously over the GPUs",
     ),
@@ -85,10 +110,114 @@ def algorithmic_bytes(cfg: dict, lanes: int, frames: int) -> int:
     return lanes * frames * cfg["bytes_per_sample"] + 2 * cfg["state_words"] * 4 * lanes
 
 
+def wrap64(v: int) -> int:
+    """v modulo 2^64 as a signed 64-bit value (what a wrapping i64 sum holds)."""
+    v &= MASK64
+    return v - (1 << 64) if v >> 63 else v
+
+
+# ---------------------------------------------------------------------------------------- inputs
+
+def c2_input_host(frames: int, lanes: int, layout: str, rank: int):
+    """SURVEY.md §8d C2 stream (PCG64): i32 uniform in [-2^24, 2^24); FRAME_MAJOR `[frames][lanes]`
+    (LANE_MAJOR runs draw `[lanes][frames]` from the same generator)."""
+    import numpy as np
+
+    rng = np.random.default_rng(CONFIGS["c2"]["seed"] if rank == 0 else [CONFIGS["c2"]["seed"], rank])
+    shape = (frames, lanes) if layout == "frame" else (lanes, frames)
+    return rng.integers(-(1 << 24), 1 << 24, size=shape, dtype=np.int32)
+
+
+def _c5_hash(idx, xp):
+    """murmur3's 32-bit finaliser over a golden-ratio multiple of the index, in 64-bit lanes masked to
+    32 bits (the same expression evaluates on numpy arrays and on torch tensors)."""
+    m = 0xFFFFFFFF
+    h = (idx * 0x9E3779B1 + 0x5BD1E995) & m
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & m
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & m
+    h = h ^ (h >> 16)
+    return h
+
+
+def c5_input(xp, lane_lo: int, lanes: int, f_lo: int, f_hi: int, layout: str = "frame", device=None):
+    """C5 samples of global lanes [lane_lo, lane_lo + lanes), frames [f_lo, f_hi): x = (h >> 8) * 2^-23 - 1
+    with h = hash(frame * 2^20 + lane) — exact in f32, uniform in [-1, 1), independent of the sharding.
+    `xp` is numpy or torch."""
+    if xp.__name__ == "torch":
+        f = xp.arange(f_lo, f_hi, dtype=xp.int64, device=device)
+        l = xp.arange(lane_lo, lane_lo + lanes, dtype=xp.int64, device=device)
+        idx = (f[:, None] << 20) + l[None, :] if layout == "frame" else (f[None, :] << 20) + l[:, None]
+        return (_c5_hash(idx, xp) >> 8).to(xp.float32) * (2.0 ** -23) - 1.0
+    f = xp.arange(f_lo, f_hi, dtype=xp.int64)
+    l = xp.arange(lane_lo, lane_lo + lanes, dtype=xp.int64)
+    idx = (f[:, None] << 20) + l[None, :] if layout == "frame" else (f[None, :] << 20) + l[:, None]
+    return ((_c5_hash(idx, xp) >> 8).astype(xp.float32) * xp.float32(2.0 ** -23) - xp.float32(1.0)).astype(xp.float32)
+
+
+def c5_input_host(lane_lo: int, lanes: int, frames: int, layout: str = "frame"):
+    """The C5 samples of a lane block on the host (numpy), built in pieces of ~4 M samples."""
+    import numpy as np
+
+    out = np.empty((frames, lanes) if layout == "frame" else (lanes, frames), dtype=np.float32)
+    step = max(1, (1 << 22) // max(lanes, 1))
+    for f0 in range(0, frames, step):
+        f1 = min(frames, f0 + step)
+        blk = c5_input(np, lane_lo, lanes, f0, f1, layout)
+        if layout == "frame":
+            out[f0:f1] = blk
+        else:
+            out[:, f0:f1] = blk
+    return out
+
+
+def expected_checksums():
+    """Oracle checksums of the bench workloads (data, made offline by tests/golden/make_bench_checksums.py)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def expected_for(cfg_name: str, layout: str, rank: int, lane_lo: int, lanes: int, overridden: bool):
+    """[y checksum, state checksum] the oracle gives for this rank's input, or None if not on file."""
+    if overridden or layout != "frame":
+        return None
+    tab = expected_checksums().get(cfg_name)
+    if not tab:
+        return None
+    if cfg_name == "c2":
+        e = tab.get("ranks", {}).get(str(rank))
+        return [int(e["y"]), int(e["state"])] if e else None
+    blocks = tab.get("blocks", [])
+    if tab.get("block_lanes") != C5_BLOCK or lane_lo % C5_BLOCK or lanes % C5_BLOCK:
+        return None
+    ids = range(lane_lo // C5_BLOCK, (lane_lo + lanes) // C5_BLOCK)
+    if not ids or ids[-1] >= len(blocks):
+        return None
+    return [wrap64(sum(int(blocks[i]["y"]) for i in ids)), wrap64(sum(int(blocks[i]["state"]) for i in ids))]
+
+
+# ---------------------------------------------------------------------------------------- engine
+
 class HipEngine:
     """The product path: device buffers from torch, launches through the C ABI on one HIP stream."""
 
-    def __init__(self, cfg: dict, lanes: int, frames: int, layout: str, seed: int, device_index: int):
+    @staticmethod
+    def device_setup(local_rank: int):
+        """Bind this rank to its GPU; returns (local device index, number of visible devices)."""
+        import torch
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+        n = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % n)
+        return local_rank % n, n
+
+    def __init__(self, cfg_name: str, cfg: dict, lane_lo: int, lanes: int, frames: int, layout: str, rank: int,
+                 device_index: int):
         import torch
 
         from idsp_amd import _abi
@@ -97,23 +226,32 @@ class HipEngine:
         self.torch, self.call = torch, call
         self.fn, _ = load()
         self.dev = torch.device("cuda", device_index)
-        self.lanes, self.frames = lanes, frames
-        self.layout = _abi.FRAME_MAJOR if layout == "frame" else _abi.LANE_MAJOR
-        gen = torch.Generator(device=self.dev)
-        gen.manual_seed(seed)
-        n = lanes * frames
+        self.lanes, self.frames, self.frame_major = lanes, frames, layout == "frame"
+        self.layout = _abi.FRAME_MAJOR if self.frame_major else _abi.LANE_MAJOR
+        self.x_host = None
         sos = (C.c_double * 6)(*lowpass_sos(F0))
         if cfg["dtype"] == "i32":
             rec = _abi.BiquadI32()
             call("biquad_i32_from_sos", sos, FRAC, C.byref(rec))
             self.cfgs = (_abi.BiquadI32 * 1)(rec)
-            self.x = torch.randint(-(1 << 24), 1 << 24, (n,), dtype=torch.int32, device=self.dev, generator=gen)
+            self.x_host = c2_input_host(frames, lanes, layout, rank)
+            self.x = torch.from_numpy(self.x_host).to(self.dev).reshape(-1)
+            if rank != 0:
+                self.x_host = None
         else:
             rec = _abi.BiquadF32()
             call("biquad_f32_from_sos_f64", sos, C.byref(rec))
             self.cfgs = (_abi.BiquadF32 * 1)(rec)
-            self.x = torch.empty(n, dtype=torch.float32, device=self.dev)
-            self.x.normal_(generator=gen)
+            self.x = torch.empty(lanes * frames, dtype=torch.float32, device=self.dev)
+            xv = self.x.view(frames, lanes) if self.frame_major else self.x.view(lanes, frames)
+            step = max(1, (1 << 24) // max(lanes, 1))  # ~16 M samples (x 8 B x a few temporaries) at a time
+            for f0 in range(0, frames, step):
+                f1 = min(frames, f0 + step)
+                blk = c5_input(torch, lane_lo, lanes, f0, f1, layout, self.dev)
+                if self.frame_major:
+                    xv[f0:f1] = blk
+                else:
+                    xv[:, f0:f1] = blk
         self.y = torch.empty_like(self.x)  # a plain second allocation: no placement tuning
         self.state = torch.zeros((cfg["state_words"], lanes), dtype=torch.int32, device=self.dev)
         self.stream = torch.cuda.Stream(device=self.dev)
@@ -139,11 +277,32 @@ class HipEngine:
             b.record(self.stream)
         return lambda: [a.elapsed_time(b) for a, b in ev]
 
+    def verify(self, sample_lanes: int = 0):
+        """Zero the state, run one step, return [sum of y's words, sum of the state words] as wrapping i64 —
+        a function of (configuration, input) only, whatever was timed before.  With `sample_lanes`, also the
+        y sum over the first `sample_lanes` lanes (what a bounded CPU sample can be compared with)."""
+        from idsp_amd.sharding import checksum_i64
+
+        self.sync()
+        self.state.zero_()
+        self.sync()
+        self.step()
+        self.sync()
+        out = [checksum_i64(self.y), checksum_i64(self.state)]
+        if sample_lanes:
+            yv = self.y.view(self.frames, self.lanes)[:, :sample_lanes] if self.frame_major else self.y.view(self.lanes, self.frames)[:sample_lanes]
+            out.append(checksum_i64(yv.contiguous()))
+        return out
+
     def kernel_name(self) -> str:
         return self.fn["last_kernel"]().decode(errors="replace")
 
     def reduce_device(self, backend: str):
         return self.dev if backend == "nccl" else "cpu"
+
+    def free(self):
+        self.x = self.y = self.state = None
+        self.torch.cuda.empty_cache()
 
 
 def run_timed(engine, steps: int, warmup: int, settle_ms: float, dist=None):
@@ -173,14 +332,16 @@ def run_timed(engine, steps: int, warmup: int, settle_ms: float, dist=None):
     return time.perf_counter() - t0, durations(), done
 
 
-def cpu_baseline(cfg: dict, seconds_budget: float = 12.0):
-    """Time the CPU oracle (kind "port") on a bounded sample of the workload: 8192 lanes x 4096 samples,
-    LANE_MAJOR (each lane a contiguous slice — what `Lanes::process_view` walks,
-    dsp-process/src/compose.rs:478-494), same coefficients and input distribution; repeated until
-    ~seconds_budget of wall time, once with the lanes dealt to all host cores (one block per thread)
-    and once on one thread (the reference's serial lane loop)."""
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_baseline(cfg_name: str, cfg: dict, x_host=None, layout: str = "frame", seconds_budget: float = 14.0):
+    """Time the CPU oracle (kind "port") on the host cores of this box.
 
+    C2: the FULL 65536 x 4096 tensor the GPU was timed on (`x_host`); C5: the first C5_CPU_LANES lanes of it.  The
+    oracle's `idsp_ref_biquad_mt_reps` cuts the lanes into one contiguous block per thread (pinned POSIX
+    threads inside the C library; every thread repeats its block `reps` times with the state carried, so
+    thread start-up is paid once per measurement), in FRAME_MAJOR — the reference's `[X; N]` frames-outer
+    loop, dsp-process/src/compose.rs:468-476 — and in LANE_MAJOR — its serial lane loop over contiguous
+    slices, compose.rs:478-494 — with all allowed cores and with one thread.  The first pass (zero state)
+    also yields the oracle's checksums of the tensor for the `integrity` comparison."""
     import numpy as np
 
     import oracle  # cpu_baseline leg only
@@ -192,9 +353,12 @@ def cpu_baseline(cfg: dict, seconds_budget: float = 12.0):
     except Exception:
         lib = oracle.load()
         flavour = "-O3"
-    fn = getattr(lib, "idsp_ref_" + cfg["entry"])
-    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
-    fn.restype = C.c_int
+    mt = lib.idsp_ref_biquad_mt_reps
+    mt.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                   C.c_int, C.c_int, C.c_int]
+    mt.restype = C.c_int
+    lib.idsp_ref_host_cpus.restype = C.c_int
+    cores = max(1, int(lib.idsp_ref_host_cpus()))
     sos = (C.c_double * 6)(*lowpass_sos(F0))
     if cfg["dtype"] == "i32":
         rec = _abi.BiquadI32()
@@ -202,43 +366,64 @@ def cpu_baseline(cfg: dict, seconds_budget: float = 12.0):
     else:
         rec = _abi.BiquadF32()
         lib.idsp_ref_biquad_f32_from_sos_f64(sos, C.byref(rec))
-    lanes, frames = 8192, cfg["frames"]
-    rng = np.random.default_rng(cfg["seed"])
-    if cfg["dtype"] == "i32":
-        x = rng.integers(-(1 << 24), 1 << 24, size=(lanes, frames), dtype=np.int32)
+    frames = cfg["frames"]
+    if cfg_name == "c2":
+        if x_host is None:
+            x_host = c2_input_host(frames, cfg["lanes"], layout, 0)
+        lanes = x_host.shape[1] if layout == "frame" else x_host.shape[0]
+        frames = x_host.size // lanes
+        native = np.ascontiguousarray(x_host)
     else:
-        x = rng.standard_normal(size=(lanes, frames), dtype=np.float32)
-    y = np.empty_like(x)
-    cores = os.cpu_count() or 1
+        lanes = C5_CPU_LANES
+        native = c5_input_host(0, lanes, frames, layout)
+    kind, words = cfg["oracle_kind"], cfg["state_words"]
+    n = lanes * frames
+    # the same samples in the other layout (a transpose of the tensor, not a new draw)
+    fm = native if layout == "frame" else np.ascontiguousarray(native.reshape(lanes, frames).T)
+    lm = native if layout == "lane" else np.ascontiguousarray(native.reshape(frames, lanes).T)
+    y = np.zeros(n, dtype=native.dtype)  # touched: no page faults inside the timed passes
 
-    def run(threads, budget):
-        from idsp_amd.sharding import lane_shard
+    def run(x, lay, threads, reps):
+        st = np.zeros((words, lanes), dtype=np.uint32)
+        t0 = time.perf_counter()
+        rc = mt(kind, C.byref(rec), 1, st.ctypes.data, x.ctypes.data, y.ctypes.data, lanes, frames, lay, threads, reps)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        return dt, st
 
-        blocks = [lane_shard(lanes, t, threads) for t in range(threads)]
-        states = [np.zeros((cfg["state_words"], hi - lo), dtype=np.uint32) for lo, hi in blocks]
+    def checksum(a):
+        return wrap64(int(a.reshape(-1).view(np.int32).sum(dtype=np.int64)))
 
-        def work(i):
-            lo, hi = blocks[i]
-            if hi > lo:
-                rc = fn(C.byref(rec), 1, states[i].ctypes.data, x[lo:hi].ctypes.data, y[lo:hi].ctypes.data, hi - lo, frames, 1)
-                assert rc == 0
+    def rate(x, lay, threads, budget):
+        dt1, _ = run(x, lay, threads, 1)  # calibration (and warm caches / page tables)
+        reps = max(1, min(4096, int(budget / max(dt1, 1e-4))))
+        dt, _ = run(x, lay, threads, reps)
+        return reps * n / dt / 1e6, reps
 
-        n, t0 = 0, time.perf_counter()
-        with ThreadPoolExecutor(max_workers=threads) as pool:  # ctypes releases the GIL during the call
-            while True:
-                list(pool.map(work, range(threads)))
-                n += 1
-                dt = time.perf_counter() - t0
-                if dt > budget:
-                    return n * lanes * frames / dt / 1e6
-
-    all_cores = run(min(cores, lanes), seconds_budget * 0.6)
-    one = run(1, seconds_budget * 0.4)
+    # oracle checksums of the GPU's tensor in the GPU's layout (zero state, one pass)
+    _, st0 = run(native, 0 if layout == "frame" else 1, cores, 1)
+    oracle_sums = [checksum(y), checksum(st0)]
+    leg = seconds_budget / 4.0
+    res = {}
+    for name, x, lay in (("frame", fm, 0), ("lane", lm, 1)):
+        all_rate, all_reps = rate(x, lay, cores, leg)
+        one_rate, one_reps = rate(x, lay, 1, leg)
+        res[name] = {"all_cores": round(all_rate, 1), "one_thread": round(one_rate, 1),
+                     "parallel_efficiency": round(all_rate / (one_rate * cores), 3), "passes": [all_reps, one_reps]}
+    best_layout = max(res, key=lambda k: res[k]["all_cores"])
+    best = res[best_layout]
     return {
-        "value": round(all_cores, 1), "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "single_thread_value": round(one, 1),
-        "sample": f"{lanes} of {cfg['lanes']} lanes x {frames} samples, LANE_MAJOR, C oracle {flavour}, "
-                  f"repeated ~{seconds_budget:.0f} s; reference is Rust (no toolchain here)",
+        "value": best["all_cores"], "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "single_thread_value": max(res[k]["one_thread"] for k in res),
+        "layout_of_value": best_layout, "by_layout": res,
+        "parallel_efficiency": best["parallel_efficiency"],
+        "dram_gbs_at_value": round(best["all_cores"] * cfg["bytes_per_sample"] / 1e3, 1),
+        "note": "all-core rate / (one-thread rate x cores) below ~0.5 means the all-core leg is capped by host DRAM "
+                "bandwidth (dram_gbs_at_value = 8 B per sample at that rate; x and y are first-touched by one thread)",
+        "sample": f"{lanes} of {cfg['lanes']} lanes x {frames} samples ({'the full tensor the GPU ran' if lanes == cfg['lanes'] else 'a lane prefix of it'}), "
+                  f"C oracle {flavour}, pinned pthreads over contiguous lane blocks, ~{seconds_budget:.0f} s in 4 legs; "
+                  "reference is Rust (no toolchain here)",
+        "oracle_checksums": oracle_sums, "oracle_checksum_lanes": lanes,
     }
 
 
@@ -293,7 +478,161 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
     }
 
 
-def main(argv=None):
+# ---------------------------------------------------------------------------------------- ranks
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_command(n: int, argv, script: str | None = None):
+    """The launcher line of the bench contract, on a free local port."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script or os.path.abspath(__file__), *argv]
+
+
+def spawn(n: int, argv, script: str | None = None, **popen_kw) -> int:
+    """Start n ranks of `script` (default: this file) and wait for them; rank 0 prints the JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(spawn_command(n, argv, script), env=env, **popen_kw)
+
+
+def gather_ints(values, dist, device):
+    """[[values of rank 0], [values of rank 1], …] (signed 64-bit integers)."""
+    import torch
+
+    t = torch.tensor([wrap64(int(v)) for v in values], dtype=torch.int64, device=device)
+    if not dist:
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend, steps, warmup, settle_ms, lanes_override,
+               frames_override):
+    """One configuration on this rank: build the engine, the timed region, the reductions and the integrity
+    step.  Returns (line or None on ranks > 0, engine) — the caller frees the engine."""
+    import torch
+
+    from idsp_amd.sharding import allreduce_checksum
+
+    cfg = CONFIGS[cfg_name]
+    frames = frames_override or cfg["frames"]
+    lane_lo, lanes_rank = job_shard(cfg, rank, world, lanes_override or None)
+    total_lanes = (lanes_override or cfg["lanes"]) * (world if cfg["scaling"] == "weak" else 1)
+    engine = engine_factory(cfg_name, cfg, lane_lo, lanes_rank, frames, args.layout, rank, local)
+    rdev = engine.reduce_device(backend)
+    elapsed, kern_ms, untimed = run_timed(engine, steps, warmup, settle_ms, dist)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t.item())
+    med_us = int(round(statistics.median(kern_ms) * 1e3)) if kern_ms else 0
+    sample = C5_CPU_LANES if cfg_name == "c5" and world == 1 and lanes_rank > C5_CPU_LANES else 0
+    sums = engine.verify(sample)
+    y_sum_all = allreduce_checksum(sums[0], device=rdev)  # SURVEY §8e: the 8-byte checksum all-reduce
+    per_rank = gather_ints([sums[0], sums[1], med_us, lane_lo, lanes_rank], dist, rdev)
+    if rank != 0:
+        return None, engine
+    a = argparse.Namespace(**{**vars(args), "steps": steps, "warmup": warmup, "settle_ms": settle_ms,
+                              "lanes": lanes_override, "frames": frames_override})
+    line = report(cfg_name, cfg, a, world, lanes_rank, frames, elapsed_max, kern_ms, untimed, engine.kernel_name(), total_lanes)
+    overridden = bool(lanes_override or frames_override)
+    exp = [expected_for(cfg_name, args.layout, r, pr[3], pr[4], overridden) for r, pr in enumerate(per_rank)]
+    match = [None if e is None else (e[0] == pr[0] and e[1] == pr[1]) for e, pr in zip(exp, per_rank)]
+    assert wrap64(sum(pr[0] for pr in per_rank)) == y_sum_all, "checksum all-reduce disagrees with the gathered sums"
+    line["ranks"] = {
+        "kernel_ms_median": [round(pr[2] / 1e3, 4) for pr in per_rank],
+        "lanes": [pr[4] for pr in per_rank], "first_lane": [pr[3] for pr in per_rank],
+    }
+    line["integrity"] = {
+        "method": "state zeroed, one more step, wrapping i64 sums of the 32-bit words of y and of the written-back state; "
+                  "y sums all-reduced (SUM) over the ranks",
+        "checksum_y_allreduce": y_sum_all, "checksum_state_sum": wrap64(sum(pr[1] for pr in per_rank)),
+        "per_rank": [[pr[0], pr[1]] for pr in per_rank],
+        "expected_source": "tests/golden/bench_checksums.json (CPU oracle on the same inputs)" if any(e is not None for e in exp) else None,
+        "per_rank_match": match,
+        "match": (all(match) if all(m is not None for m in match) else None),
+    }
+    if sample:
+        line["integrity"]["sample_lanes"] = sample
+        line["integrity"]["sample_checksum_y"] = sums[2]
+    return line, engine
+
+
+def rank_main(args, engine_factory=HipEngine):
+    """One rank of the bench (the only rank when WORLD_SIZE is unset)."""
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local, ndev = engine_factory.device_setup(local)
+    shared = world > ndev
+    # RCCL ("nccl" on ROCm) is the backend, one rank per GPU.  With fewer GPUs than ranks (a 1-GPU box) two
+    # ranks cannot join one RCCL communicator from the same device: the ranks then share devices and meet over
+    # gloo, which exercises the control flow only.  IDSP_BENCH_BACKEND overrides the choice.
+    backend = os.environ.get("IDSP_BENCH_BACKEND") or ("gloo" if shared else "nccl")
+    dist = None
+    rccl_ranks = 1
+    if world > 1:
+        import torch.distributed as dist
+
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+        one = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == dist.get_world_size() == world
+
+    line, engine = run_config(args.config, args, engine_factory, dist, rank, world, local, backend, args.steps, args.warmup,
+                              args.settle_ms, args.lanes, args.frames)
+    x_host = getattr(engine, "x_host", None)
+    engine.free()
+    sub = None
+    if args.config == "c2" and not args.no_c5 and (args.c5_lanes or not (args.lanes or args.frames)):
+        # the strong-scaling job beside the weak-scaling headline: 2^20 / N lanes per rank
+        sub, e5 = run_config("c5", args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
+                             min(args.warmup, 3), min(args.settle_ms, 100.0), args.c5_lanes, args.c5_frames)
+        e5.free()
+    if rank == 0:
+        line["rccl_ranks"] = rccl_ranks
+        line["backend"] = "nccl (RCCL)" if backend == "nccl" else backend
+        line["ranks_share_device"] = shared
+        line["launcher"] = os.environ.get("IDSP_BENCH_LAUNCHER", "torchrun (external)" if world > 1 else "single process")
+        if world != args.gpus:
+            line["config"]["note"] = f"--gpus {args.gpus} but WORLD_SIZE={world}: the process group's size is what ran"
+        if sub is not None:
+            keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config",
+                    "roofline", "ranks", "integrity")
+            line["c5"] = {k: sub[k] for k in keep}
+        if world == 1 and not args.no_cpu:
+            cb = cpu_baseline(args.config, CONFIGS[args.config], x_host, args.layout)
+            integ = line["integrity"]
+            if cb["oracle_checksum_lanes"] == line["config"]["lanes_per_gpu"]:
+                integ["oracle_live"] = cb["oracle_checksums"]
+                integ["oracle_live_match"] = cb["oracle_checksums"] == integ["per_rank"][0]
+            elif integ.get("sample_lanes") == cb["oracle_checksum_lanes"]:
+                integ["oracle_live_sample_y"] = cb["oracle_checksums"][0]
+                integ["oracle_live_match"] = cb["oracle_checksums"][0] == integ["sample_checksum_y"]
+            line["cpu_baseline"] = cb
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -305,47 +644,19 @@ def main(argv=None):
     ap.add_argument("--lanes", type=int, default=0, help="override the configuration's lane count (diagnostics)")
     ap.add_argument("--frames", type=int, default=0, help="override the samples per lane (diagnostics)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    args = ap.parse_args(argv)
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 strong-scaling sub-object of the default run")
+    ap.add_argument("--c5-lanes", type=int, default=0, help="total lanes of the C5 sub-object (diagnostics; default 2^20)")
+    ap.add_argument("--c5-frames", type=int, default=0, help="samples per lane of the C5 sub-object (diagnostics; default 4096)")
+    return ap.parse_args(argv)
 
-    import torch
 
-    cfg = CONFIGS[args.config]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    local %= torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    dist = None
-    # RCCL ("nccl" on ROCm) is the backend; IDSP_BENCH_BACKEND=gloo exists only so the multi-rank
-    # control flow can be exercised on a single-GPU box (ranks then share the device).
-    backend = os.environ.get("IDSP_BENCH_BACKEND", "nccl")
-    if world > 1:
-        import torch.distributed as dist
-
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-
-    frames = args.frames or cfg["frames"]
-    _, lanes_rank = job_shard(cfg, rank, world, args.lanes or None)
-    total_lanes = (args.lanes or cfg["lanes"]) * (world if cfg["scaling"] == "weak" else 1)
-    engine = HipEngine(cfg, lanes_rank, frames, args.layout, cfg["seed"] + rank, local)
-    elapsed, kern_ms, untimed = run_timed(engine, args.steps, args.warmup, args.settle_ms, dist)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=engine.reduce_device(backend))
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    if rank == 0:
-        out = report(args.config, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, untimed, engine.kernel_name(), total_lanes)
-        out["cpu_baseline"] = cpu_baseline(cfg) if world == 1 and not args.no_cpu else None
-        print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the N ranks ourselves, exactly as the contract's torchrun line would
+        os.environ["IDSP_BENCH_LAUNCHER"] = "self-spawned torch.distributed.run"
+        raise SystemExit(spawn(args.gpus, sys.argv[1:] if argv is None else list(argv)))
+    rank_main(args)
 
 
 if __name__ == "__main__":

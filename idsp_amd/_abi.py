@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+ABI_VERSION = 2  # IDSP_ABI_VERSION of include/idsp_hip.h
+
 IDSP_OK = 0
 IDSP_EINVAL = -1
 IDSP_EHIP = -2
@@ -244,6 +246,7 @@ UTILS = {
     "device_h2d": (_I, [_P, _P, _SZ, _P]),
     "device_d2h": (_I, [_P, _P, _SZ, _P]),
     "stream_sync": (_I, [_P]),
+    "device_sync": (_I, []),
     # single-process lane split over several devices
     "multi_create": (_I, [_P, _I, C.POINTER(_P)]),
     "multi_destroy": (_I, [_P]),
@@ -253,6 +256,7 @@ UTILS = {
     "multi_shard": (_I, [_P, _SZ, _I, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "multi_for_each": (_I, [_P, _SZ, _P, _P]),
     "multi_sync": (_I, [_P]),
+    "multi_last_block": (_I, []),
     "multi_alloc": (_I, [_P, _SZ, _SZ, C.POINTER(_P)]),
     "multi_free": (_I, [_P, C.POINTER(_P)]),
     "multi_copy": (_I, [_P, _SZ, _SZ, C.POINTER(_P), _P, _I]),

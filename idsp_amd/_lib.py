@@ -37,8 +37,8 @@ def load():
             )
         _lib = ctypes.CDLL(LIB_PATH)
         _fn = _abi.bind(_lib, "idsp_", with_stream=True, utils=True)
-        if _fn["version"]() != 1:
-            raise ImportError("libidsp_hip.so ABI version mismatch")
+        if _fn["version"]() != _abi.ABI_VERSION:
+            raise ImportError(f"libidsp_hip.so reports ABI version {_fn['version']()}, this package binds version {_abi.ABI_VERSION}: rebuild (`make lib`)")
     return _fn, _lib
 
 

@@ -164,6 +164,12 @@ int idsp_stream_sync(void *stream)
     return IDSP_OK;
 }
 
+int idsp_device_sync(void)
+{
+    IDSP_HIP_TRY(hipDeviceSynchronize());
+    return IDSP_OK;
+}
+
 // src/iir/biquad.rs:545-566 then :570-576
 int idsp_biquad_i32_from_sos(const double sos[6], int frac, idsp_biquad_i32 *out)
 {

@@ -403,7 +403,9 @@ __global__ __launch_bounds__(kBlock) void cic_int_lm_kernel(const idsp_cic cfg, 
     const size_t lane4 = 4 * frames * R / V::n;
     const T *xrow = x + lane * frames;
     // inputs of kInTiles tiles ahead, so that waiting for one does not drain the row stores issued since
-    constexpr int kInTiles = 8;
+    // (64-bit samples: 128-byte tiles keep 4, and order 6 at 64-byte tiles 6, so that the ring stays in registers —
+    // 8 tiles spilled 0.15-1.2 KB per thread to scratch there, tools/check_scratch.py)
+    constexpr int kInTiles = sizeof(T) * F >= 128 ? (N >= 6 ? 3 : 4) : (sizeof(T) * F >= 64 && sizeof(T) == 8 && N >= 6 ? 6 : 8);
     T ring[kInTiles][F];
     auto fetch = [&](int u, size_t t) {
 #pragma unroll

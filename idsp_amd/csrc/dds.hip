@@ -343,6 +343,9 @@ struct LockinPolarProc {
     static constexpr int LDS_WORDS = kLut + (MODE == 0 ? 32 : 0);  // cossin table, atan2 reciprocal table
     static constexpr int IN_DIV = 1;
     static constexpr bool LM_ONE_FORM = true;  // stream fall-back of the multi-wave kernel: one LaneMajor form is enough
+    // four cascaded second-order arms + atan2 next to the staged kernel's 128 staging registers: 116 B of scratch per
+    // thread (tools/check_scratch.py) — that one stays on the tile kernel
+    static constexpr bool LM_STAGED = !(MODE == 0 && N * K >= 8);
     static constexpr int COST = 110 + 80 * N * K + (MODE == 0 ? 80 : 10);
     using Params = LpParams;
     const uint32_t *lut;

@@ -383,14 +383,24 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     // Persistent over lane blocks: workgroup w walks the (256 LPT)-lane blocks w, w + grid, w + 2 grid, ... one after
     // the other (state load, the whole frame walk, state store per block).
     constexpr size_t kBlockLanes = size_t(kFmBlock) * LPT;
-    const size_t nblocks = lanes / kBlockLanes;  // lanes % (256 LPT) == 0 (launcher)
+    // LPT == 1 with one-word outputs also takes a ragged last block (lanes % 256 != 0, lanes % 4 == 0: whole 16-byte pieces): a thread whose
+    // piece of the 1 KiB row segment lies beyond the last lane acts as a CLONE of an in-range thread — it requests
+    // that thread's piece again and stores that thread's results to that thread's address (same bytes, twice) — so
+    // the steady-state loop carries no predicate and every wave still issues exactly RPW loads and RPW * OW stores
+    // per tile (the vmcnt bookkeeping below).  Its own column computes on whatever the clone's piece holds and is
+    // dropped; only the state store is predicated.
+    const size_t nblocks = (lanes + kBlockLanes - 1) / kBlockLanes;  // LPT > 1: lanes % (256 LPT) == 0 (launcher)
     // (a workgroup that owns ADJACENT blocks instead — blocks [w rounds, (w + 1) rounds) — was measured slower: 0.58 vs
     // 0.68 of peak at 2^20 lanes, profiles/r02_exp_c5_matrix6.jsonl: the panel order keeps the concurrently active
     // columns in one contiguous 256 KiB piece of every row)
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const size_t lane0 = blk * kBlockLanes;
+    const size_t avail = lanes - lane0;  // lanes of this block that exist (>= 4)
+    const bool ragged_block = LPT == 1 && OW == 1 && avail < size_t(kFmBlock);
+    const int lid4 = ragged_block && size_t(lid * 4) >= avail ? int(size_t(lid * 4) % avail) : lid * 4;  // first lane of this thread's piece
+    const bool lane_ok = !ragged_block || size_t(tid) < avail;
 #pragma unroll
-    for (int s = 0; s < LPT; s++) p[s].load(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
+    for (int s = 0; s < LPT; s++) p[s].load(prm, st, lanes, lane_ok ? lane0 + size_t(s) * kFmBlock + tid : lanes - 1);
     // The state loads must have landed HERE, in a way the compiler's wait-count pass sees: it cannot see the DMA
     // requests of glds16(), and if it first needs a state register inside the steady-state loop it protects that use
     // with `s_waitcnt vmcnt(0)` on every iteration — which drains the whole prefetch ring each tile (0.52 instead of
@@ -410,8 +420,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     //                operations per sample) run 0.77-0.78 at ring 5 this way in every placement, against 0.67-0.68
     //                (ring 5-7) or 0.67 / 0.75 by placement (ring 8) the other way.
     const size_t xstep = size_t(R) * xl, ystep = size_t(R) * yl * OW;
-    const In *xq = x + lane0 + lid * 4;                                       // RUN: tile about to be requested
-    uint32_t *yq = reinterpret_cast<uint32_t *>(y) + lane0 * OW + lid * 4;    // RUN: tile about to be stored
+    const In *xq = x + lane0 + lid4;                                          // RUN: tile about to be requested
+    uint32_t *yq = reinterpret_cast<uint32_t *>(y) + lane0 * OW + lid4;       // RUN: tile about to be stored
     int slot_run = 0;                                                         // RUN: i % NB
     auto issue = [&](size_t v, auto full) {
         constexpr bool FULL = decltype(full)::value;
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
         for (int j = 0; j < RPW; j++) {
             const int g = wave + 4 * j;
             if (FULL || g < ns) {
-                const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * kFmBlock : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid * 4;
+                const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * kFmBlock : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid4;
                 glds16(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
             }
         }
@@ -437,9 +447,9 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
             if (FULL || g < ns) {
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
-                    const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid * 4);
+                    const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid4);
                     uint32_t *dst = RUN ? yq + (size_t(g / LPT) * yl + (g % LPT) * kFmBlock) * OW + h * kFmBlock
-                                        : yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid * 4;
+                                        : yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid4;
                     __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst));
                 }
             }
@@ -505,7 +515,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     }
     for (; i < ntiles; i++) slow_iter();
 #pragma unroll
-    for (int s = 0; s < LPT; s++) p[s].store(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
+    for (int s = 0; s < LPT; s++)
+        if (lane_ok) p[s].store(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
     // No barrier needed here: the next block's first lds_barrier() (after each wave's lgkmcnt wait) orders this
     // block's last output-tile reads before the compute() that overwrites the tile, and its first DMA rows only
     // touch input slots whose last readers passed the barrier after the final compute().
@@ -653,6 +664,12 @@ constexpr int kLmRun = 512;  // bytes per lane and tile on the wider of the two 
 // is then 128 / max(words) frames: 512-byte runs on the wider side, 256-byte runs on the narrower, separate LDS slots), but
 // its 48 KiB of LDS leave a CU three waves and those processors (fm_disc, the lock-in with Complex output) are VALU-bound:
 // fm_disc LaneMajor 1.89 ms staged against 1.46 ms on the tile kernel at 65536 lanes x 4096, so they stay there.
+// A processor can opt out (P::LM_STAGED = false): with 128 staging registers next to a large state the kernel spills
+// (tools/check_scratch.py is the build check).
+template <class P, class = void>
+struct LmStagedAllowed : std::true_type {};
+template <class P>
+struct LmStagedAllowed<P, std::void_t<decltype(P::LM_STAGED)>> : std::integral_constant<bool, P::LM_STAGED> {};
 template <class P, class = void>
 struct LmStagedOf {
     static constexpr bool value = false;
@@ -660,7 +677,7 @@ struct LmStagedOf {
 template <class P>
 struct LmStagedOf<P, std::enable_if_t<P::IN_DIV == 1 && (!P::HAS_IN || sizeof(typename P::In) == sizeof(typename P::Out)) &&
                                       (sizeof(typename P::Out) == 4 || sizeof(typename P::Out) == 8) &&
-                                      (BatchOf<P>::value == 1 || BatchOf<P>::value == 4)>> {
+                                      (BatchOf<P>::value == 1 || BatchOf<P>::value == 4) && LmStagedAllowed<P>::value>> {
     static constexpr bool value = true;
 };
 template <class P, class = void>
@@ -1140,7 +1157,8 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             constexpr bool heavy = P::COST > 120;
             const bool in_range = heavy ? (lanes >= 12288 && lanes < 40960) : lanes < 49152;
             if (!no_fm_staged && (forced_flw || in_range) && frames >= 16 && (lanes * sz) % 16 == 0 && (xl * sz) % 16 == 0 &&
-                (yl * sz) % 16 == 0 && xl * sz < (size_t(1) << 30) && yl * sz < (size_t(1) << 30) &&
+                (yl * sz) % 16 == 0 && xl * sz < (size_t(1) << 28) && yl * sz < (size_t(1) << 28) &&  // 32-bit offsets: up to 15 row pitches + 1 KiB inside a tile (16 lanes/wave)
+               
                 reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0) {
                 const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= 24576 ? 64 : lanes >= 8192 ? 32 : 16;
                 auto go = [&](auto lw_tag) {
@@ -1172,7 +1190,9 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             static const size_t lds_max_waves = diag_size("IDSP_LDS_MAX_WAVES", size_t(1) << 40);
             static const bool no_lds = diag_env("IDSP_NO_LDS_PATH") != nullptr;
             constexpr size_t ow = sizeof(typename P::Out) / 4;
-            if (!no_lds && eligible && waves >= lds_min_waves() && waves <= lds_max_waves && lanes % kFmBlock == 0 &&
+            // whole 256-lane blocks — or, for one-word outputs, any multiple of 4 lanes: the kernel's last block may be ragged
+            // (reference: any N in `Lanes<C>`, dsp-process/src/compose.rs:468)
+            if (!no_lds && eligible && waves >= lds_min_waves() && waves <= lds_max_waves && (lanes % kFmBlock == 0 || (ow == 1 && lanes % 4 == 0)) &&
                 reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && (yl * ow) % 4 == 0) {
                 // Grid (profiles/r02_exp_c5_*.jsonl).  Up to 384 workgroups: one per 256-lane block.  Beyond: a persistent
                 // grid of <= 256 workgroups (one per CU) that walks the lane blocks in column panels of equal rounds —
@@ -1182,10 +1202,12 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 // P::LDS_LPT_MAX; none does (see the kernel).  IDSP_DIAG=1 IDSP_LDS_LPT / IDSP_LDS_GRID override both.
                 static const size_t forced_lpt = diag_size("IDSP_LDS_LPT", 0);
                 static const size_t forced_grid = diag_size("IDSP_LDS_GRID", ~size_t(0));
-                const size_t nblocks = lanes / kFmBlock;
+                const size_t nblocks = (lanes + kFmBlock - 1) / kFmBlock;
                 constexpr int kMaxLpt = LdsLptMaxOf<P>::value;
                 int lpt = 1;
-                if (forced_lpt) {
+                if (lanes % kFmBlock != 0) {
+                    // ragged last block: one lane per thread only
+                } else if (forced_lpt) {
                     lpt = int(forced_lpt) > kMaxLpt ? kMaxLpt : int(forced_lpt);
                     while (lpt > 1 && nblocks % size_t(lpt) != 0) lpt >>= 1;
                 } else {

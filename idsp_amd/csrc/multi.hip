@@ -33,6 +33,15 @@ struct DeviceGuard {  // restores the caller's current device
     }
 };
 
+// index of the lane block at which the last idsp_multi_for_each / idsp_multi_biquad_* of this thread stopped (-1: none)
+inline int &last_block()
+{
+    static thread_local int b = -1;
+    return b;
+}
+
+inline bool mul_overflows(size_t a, size_t b) { return b != 0 && a > SIZE_MAX / b; }
+
 }  // namespace
 
 using namespace idsp;
@@ -120,10 +129,20 @@ int idsp_multi_for_each(idsp_multi *m, size_t lanes, idsp_shard_fn fn, void *use
         shard(lanes, g, G, lo, hi);
         IDSP_HIP_TRY(hipSetDevice(m->devices[g]));
         const int rc = fn(user, int(g), lo, hi, m->streams[g]);
-        if (rc < 0) return rc;  // the callee's status and idsp_last_error() text stand
+        // Any non-zero status stops the walk and is returned as it is (negative: the callee's idsp_status, with its
+        // idsp_last_error() text; positive: the callback's own "stop" code).  Blocks 0..g-1 have been handed to fn
+        // already and whatever they launched is in flight on their streams: after a failure the per-block state is
+        // indeterminate — idsp_multi_sync() and reload it.  idsp_multi_last_block() tells which block stopped.
+        if (rc != 0) {
+            last_block() = int(g);
+            return rc;
+        }
     }
+    last_block() = -1;
     return IDSP_OK;
 }
+
+int idsp_multi_last_block(void) { return last_block(); }
 
 int idsp_multi_sync(idsp_multi *m)
 {
@@ -139,6 +158,7 @@ int idsp_multi_sync(idsp_multi *m)
 int idsp_multi_alloc(idsp_multi *m, size_t lanes, size_t bytes_per_lane, void **ptrs)
 {
     if (!m || !ptrs) return fail(IDSP_EINVAL, "m or ptrs is NULL");
+    if (mul_overflows(lanes, bytes_per_lane)) return fail(IDSP_EINVAL, "lanes * bytes_per_lane overflows size_t");
     DeviceGuard guard;
     const size_t G = m->devices.size();
     for (size_t g = 0; g < G; g++) ptrs[g] = nullptr;
@@ -178,8 +198,14 @@ int idsp_multi_free(idsp_multi *m, void **ptrs)
 int idsp_multi_copy(idsp_multi *m, size_t lanes, size_t bytes_per_lane, void *const *dev_ptrs, void *host, int to_device)
 {
     if (!m || !dev_ptrs || (!host && lanes)) return fail(IDSP_EINVAL, "m, dev_ptrs or host is NULL");
+    if (mul_overflows(lanes, bytes_per_lane)) return fail(IDSP_EINVAL, "lanes * bytes_per_lane overflows size_t");
     DeviceGuard guard;
     const size_t G = m->devices.size();
+    for (size_t g = 0; g < G; g++) {  // nothing is queued unless every non-empty block has a buffer
+        size_t lo, hi;
+        shard(lanes, g, G, lo, hi);
+        if (hi > lo && !dev_ptrs[g]) return fail(IDSP_EINVAL, "dev_ptrs[%zu] is NULL for a block of %zu lanes", g, hi - lo);
+    }
     for (size_t g = 0; g < G; g++) {
         size_t lo, hi;
         shard(lanes, g, G, lo, hi);
@@ -205,13 +231,34 @@ int multi_biquad(idsp_multi *m, Fn entry, const Cfg *cfg, size_t n, void *const 
     if (!m || !state || !x || !y) return fail(IDSP_EINVAL, "m, state, x or y is NULL");
     DeviceGuard guard;
     const size_t G = m->devices.size();
+    last_block() = -1;
+    // Validate EVERY block before launching any: a zero-frame call of the entry runs all of its argument checks
+    // (configuration, section count, layout, NULL buffers) and launches nothing, so a bad block is reported before
+    // any block's state has advanced.
+    for (size_t g = 0; g < G; g++) {
+        size_t lo, hi;
+        shard(lanes, g, G, lo, hi);
+        if (hi == lo) continue;
+        if (!state[g] || !x[g] || !y[g]) {
+            last_block() = int(g);
+            return fail(IDSP_EINVAL, "state, x or y of block %zu is NULL (%zu lanes)", g, hi - lo);
+        }
+        const int rc = entry(cfg, n, state[g], x[g], y[g], hi - lo, 0, layout, m->streams[g]);
+        if (rc < 0) {
+            last_block() = int(g);
+            return rc;
+        }
+    }
     for (size_t g = 0; g < G; g++) {
         size_t lo, hi;
         shard(lanes, g, G, lo, hi);
         if (hi == lo) continue;
         IDSP_HIP_TRY(hipSetDevice(m->devices[g]));
         const int rc = entry(cfg, n, state[g], x[g], y[g], hi - lo, frames, layout, m->streams[g]);
-        if (rc < 0) return rc;
+        if (rc < 0) {  // a launch failure after validation: blocks 0..g-1 are in flight, state indeterminate
+            last_block() = int(g);
+            return rc;
+        }
     }
     return IDSP_OK;
 }

@@ -25,8 +25,8 @@ def checksum_i64(t) -> int:
     32-bit words — summed over shards it equals the checksum of the whole."""
     import torch
 
-    w = t.reshape(-1).view(torch.int32).to(torch.int64)
-    return int(w.sum().item())  # torch int64 sum wraps modulo 2^64
+    w = t.reshape(-1).view(torch.int32)
+    return int(w.sum(dtype=torch.int64).item())  # accumulated in int64 (no widened copy); wraps modulo 2^64
 
 
 def allreduce_checksum(value: int, device=None) -> int:

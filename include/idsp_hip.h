@@ -51,7 +51,10 @@
 extern "C" {
 #endif
 
-#define IDSP_ABI_VERSION 1
+/* 1: round-1 surface.  2: + the `_pitch` twins, idsp_multi_*, idsp_last_kernel, idsp_device_sync,
+ * idsp_multi_last_block; dispatch switches honoured only with IDSP_DIAG=1.  A host binding should refuse a
+ * library whose idsp_version() is lower than the version it was generated from. */
+#define IDSP_ABI_VERSION 2
 
 typedef enum idsp_status {
     IDSP_OK = 0,
@@ -100,6 +103,10 @@ int idsp_device_memset(void *ptr, int value, size_t bytes, void *stream);
 int idsp_device_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int idsp_device_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int idsp_stream_sync(void *stream);
+/* Wait for ALL work of the current device, whatever stream it was launched on (hipDeviceSynchronize) — what a
+ * host must call before reading results back on another stream than the one it launched on: the idsp_multi
+ * streams are non-blocking, so a NULL-stream copy does NOT wait for them. */
+int idsp_device_sync(void);
 
 /* ------------------------------------------------------------------------ */
 /* iir::Biquad — fixed point (src/iir/biquad.rs)                            */
@@ -748,10 +755,16 @@ void *idsp_multi_stream(const idsp_multi *m, int index);
 int idsp_multi_shard(const idsp_multi *m, size_t lanes, int index, size_t *lane_lo, size_t *lane_hi);
 
 /* Generic driver: for every block, make its device current and call fn(user, index, lane_lo, lane_hi, stream) —
- * fn issues whatever entry points it likes on that stream for that lane block.  A negative return stops the loop
- * and is returned.  The caller's current device is restored. */
+ * fn issues whatever entry points it likes on that stream for that lane block.  ANY non-zero return stops the
+ * loop and is returned as it is (negative: an idsp_status; positive: the callback's own stop code).  Blocks before
+ * the stopping one have been handed to fn already and their work is in flight: after a stop the per-block state is
+ * indeterminate until the caller has synchronised and reloaded it; idsp_multi_last_block() names the block.
+ * The caller's current device is restored. */
 typedef int (*idsp_shard_fn)(void *user, int index, size_t lane_lo, size_t lane_hi, void *stream);
 int idsp_multi_for_each(idsp_multi *m, size_t lanes, idsp_shard_fn fn, void *user);
+/* Index of the lane block at which the most recent idsp_multi_for_each / idsp_multi_biquad_* call of this thread
+ * stopped with a non-zero status; -1 if it ran through. */
+int idsp_multi_last_block(void);
 /* Wait for every block's stream (the "barrier" of a single-process run). */
 int idsp_multi_sync(idsp_multi *m);
 
@@ -764,7 +777,9 @@ int idsp_multi_free(idsp_multi *m, void **ptrs);
 int idsp_multi_copy(idsp_multi *m, size_t lanes, size_t bytes_per_lane, void *const *dev_ptrs, void *host, int to_device);
 
 /* The two headline operators over the split: state[g], x[g], y[g] are block g's device buffers; `lanes` is the
- * TOTAL lane count.  Asynchronous; idsp_multi_sync() waits. */
+ * TOTAL lane count.  Every block's arguments are validated BEFORE any block is launched (a bad block is reported
+ * with nothing in flight); a failure after that leaves earlier blocks running and the state indeterminate, see
+ * idsp_multi_last_block().  Asynchronous; idsp_multi_sync() waits. */
 int idsp_multi_biquad_i32_df1(idsp_multi *m, const idsp_biquad_i32 *cfg, size_t n, void *const *state,
                               const int32_t *const *x, int32_t *const *y, size_t lanes, size_t frames, int layout);
 int idsp_multi_biquad_f32_df2t(idsp_multi *m, const idsp_biquad_f32 *cfg, size_t n, void *const *state,

@@ -549,37 +549,165 @@ int idsp_ref_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, 
 
 /* --------------------------------------------------- threaded CPU baseline */
 
+/*
+ * FRAME_MAJOR traversal: the reference's `Lanes<C>: SplitProcess<[X; N], [Y; N], [S; N]>`
+ * (dsp-process/src/compose.rs:468-476) under the default `block()` loop of process.rs:122-127 —
+ * frames outer, the lanes of a frame inner, state[i] indexed by lane.  Per sample the sections run
+ * as the serial slice composition's `process()` (compose.rs:43-60).  Results equal the lane-outer
+ * drivers above (lanes never interact; each section sees the same input sequence either way).
+ */
+/* The block's state is held as the reference holds it — one record per lane, `[S; N]` — and moved
+ * from / to the ABI's word planes at entry / exit. */
+static uint32_t *fm_state_in(const uint32_t *st, size_t words, size_t lanes, size_t l0, size_t L)
+{
+    uint32_t *s = (uint32_t *)malloc((L ? L : 1) * words * sizeof(uint32_t));
+    if (!s) return NULL;
+    for (size_t l = 0; l < L; l++) for (size_t w = 0; w < words; w++) s[l * words + w] = st[w * lanes + l0 + l];
+    return s;
+}
+static void fm_state_out(uint32_t *st, uint32_t *s, size_t words, size_t lanes, size_t l0, size_t L)
+{
+    for (size_t l = 0; l < L; l++) for (size_t w = 0; w < words; w++) st[w * lanes + l0 + l] = s[l * words + w];
+    free(s);
+}
+
+static int fm_rows_i32_df1(const idsp_biquad_i32 *cfg, size_t n, uint32_t *st, const int32_t *x, int32_t *y,
+                           size_t lanes, size_t frames, size_t l0, size_t l1)
+{
+    const size_t L = l1 - l0, W = 4 * n;
+    uint32_t *rec = fm_state_in(st, W, lanes, l0, L);
+    if (!rec) return IDSP_EINVAL;
+    for (size_t f = 0; f < frames; f++) {
+        const int32_t *xr = x + f * lanes + l0;
+        int32_t *yr = y + f * lanes + l0;
+        for (size_t l = 0; l < L; l++) {
+            int32_t v = xr[l];
+            for (size_t k = 0; k < n; k++) v = df1_i32(cfg[k].ba, cfg[k].frac, rec + l * W + 4 * k, v);
+            yr[l] = v;
+        }
+    }
+    fm_state_out(st, rec, W, lanes, l0, L);
+    return IDSP_OK;
+}
+
+static int fm_rows_f32_df2t(const idsp_biquad_f32 *cfg, size_t n, uint32_t *st, const float *x, float *y,
+                            size_t lanes, size_t frames, size_t l0, size_t l1)
+{
+    const size_t L = l1 - l0, W = 2 * n;
+    uint32_t *rec = fm_state_in(st, W, lanes, l0, L);
+    if (!rec) return IDSP_EINVAL;
+    for (size_t f = 0; f < frames; f++) {
+        const float *xr = x + f * lanes + l0;
+        float *yr = y + f * lanes + l0;
+        for (size_t l = 0; l < L; l++) {
+            float v = xr[l];
+            for (size_t k = 0; k < n; k++) v = df2t_f32(cfg[k].ba, rec + l * W + 2 * k, v);
+            yr[l] = v;
+        }
+    }
+    fm_state_out(st, rec, W, lanes, l0, L);
+    return IDSP_OK;
+}
+
 typedef struct {
-    const idsp_biquad_i32 *cfg; size_t n; void *state; const int32_t *x; int32_t *y;
-    size_t lanes, frames; int layout; size_t l0, l1;
+    int kind; const void *cfg; size_t n; void *state; const void *x; void *y;
+    size_t lanes, frames; int layout; size_t l0, l1; int reps; int cpu;
 } mt_job;
+
+static void mt_run_block(const mt_job *j)
+{
+    for (int r = 0; r < j->reps; r++) {
+        if (j->kind == 0) {
+            if (j->layout == IDSP_FRAME_MAJOR)
+                fm_rows_i32_df1((const idsp_biquad_i32 *)j->cfg, j->n, (uint32_t *)j->state, (const int32_t *)j->x,
+                                (int32_t *)j->y, j->lanes, j->frames, j->l0, j->l1);
+            else
+                idsp_ref_biquad_i32_df1_range((const idsp_biquad_i32 *)j->cfg, j->n, j->state, (const int32_t *)j->x,
+                                              (int32_t *)j->y, j->lanes, j->frames, j->layout, j->l0, j->l1);
+        } else {
+            if (j->layout == IDSP_FRAME_MAJOR)
+                fm_rows_f32_df2t((const idsp_biquad_f32 *)j->cfg, j->n, (uint32_t *)j->state, (const float *)j->x,
+                                 (float *)j->y, j->lanes, j->frames, j->l0, j->l1);
+            else
+                idsp_ref_biquad_f32_df2t_range((const idsp_biquad_f32 *)j->cfg, j->n, j->state, (const float *)j->x,
+                                               (float *)j->y, j->lanes, j->frames, j->layout, j->l0, j->l1);
+        }
+    }
+}
 
 static void *mt_worker(void *p)
 {
     mt_job *j = (mt_job *)p;
-    idsp_ref_biquad_i32_df1_range(j->cfg, j->n, j->state, j->x, j->y, j->lanes, j->frames, j->layout, j->l0, j->l1);
+    if (j->cpu >= 0) {               /* one thread per allowed CPU: keep it there */
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(j->cpu, &one);
+        pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+    }
+    mt_run_block(j);
     return NULL;
+}
+
+/* Number of CPUs this process may run on (sched_getaffinity; what `nproc` prints). */
+int idsp_ref_host_cpus(void)
+{
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) != 0) return 1;
+    int c = CPU_COUNT(&set);
+    return c < 1 ? 1 : c;
+}
+
+/*
+ * kind 0 = idsp_ref_biquad_i32_df1 (cfg: idsp_biquad_i32), kind 1 = idsp_ref_biquad_f32_df2t (cfg:
+ * idsp_biquad_f32).  The lanes are cut into `threads` contiguous blocks, one POSIX thread each, pinned
+ * to the allowed CPUs in order when threads > 1; every thread runs its block `reps` times back to back
+ * (state carried from pass to pass like consecutive block() calls) so that thread start-up is paid once
+ * per timed region, not once per pass.  LANE_MAJOR blocks take the lane-outer driver (compose.rs:478-494),
+ * FRAME_MAJOR blocks the frame-outer one above.  threads == 1 runs on the calling thread.
+ */
+int idsp_ref_biquad_mt_reps(int kind, const void *cfg, size_t n, void *state, const void *x, void *y,
+                            size_t lanes, size_t frames, int layout, int threads, int reps)
+{
+    int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (kind < 0 || kind > 1 || threads < 1 || threads > 4096 || reps < 1) return IDSP_EINVAL;
+    if (kind == 0 && !frac_ok_i32((const idsp_biquad_i32 *)cfg, n)) return IDSP_EINVAL;
+    if (threads == 1) {
+        mt_job j = {kind, cfg, n, state, x, y, lanes, frames, layout, 0, lanes, reps, -1};
+        mt_run_block(&j);
+        return IDSP_OK;
+    }
+    cpu_set_t allowed;
+    int ncpu = 0, cpus[CPU_SETSIZE];
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)threads);
+    unsigned char *started = (unsigned char *)calloc((size_t)threads, 1);
+    if (!tid || !jobs || !started) { free(tid); free(jobs); free(started); return IDSP_EINVAL; }
+    for (int t = 0; t < threads; t++) {
+        mt_job j = {kind, cfg, n, state, x, y, lanes, frames, layout,
+                    lanes * (size_t)t / (size_t)threads, lanes * (size_t)(t + 1) / (size_t)threads, reps,
+                    ncpu > 0 ? cpus[t % ncpu] : -1};
+        jobs[t] = j;
+        started[t] = pthread_create(&tid[t], NULL, mt_worker, &jobs[t]) == 0;
+        if (!started[t]) mt_run_block(&jobs[t]);     /* could not start a thread: do the block here */
+    }
+    for (int t = 0; t < threads; t++) if (started[t]) pthread_join(tid[t], NULL);
+    free(tid); free(jobs); free(started);
+    return IDSP_OK;
 }
 
 int idsp_ref_biquad_i32_df1_mt(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x,
                                int32_t *y, size_t lanes, size_t frames, int layout, int threads)
 {
-    int rc = check_common(cfg, n, state, x, y, lanes, frames, layout);
-    if (rc) return rc;
-    if (!frac_ok_i32(cfg, n) || threads < 1 || threads > 1024) return IDSP_EINVAL;
-    if (threads == 1) return idsp_ref_biquad_i32_df1_range(cfg, n, state, x, y, lanes, frames, layout, 0, lanes);
-    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
-    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)threads);
-    if (!tid || !jobs) { free(tid); free(jobs); return IDSP_EINVAL; }
-    for (int t = 0; t < threads; t++) {
-        mt_job j = {cfg, n, state, x, y, lanes, frames, layout,
-                    lanes * (size_t)t / (size_t)threads, lanes * (size_t)(t + 1) / (size_t)threads};
-        jobs[t] = j;
-        pthread_create(&tid[t], NULL, mt_worker, &jobs[t]);
-    }
-    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
-    free(tid); free(jobs);
-    return IDSP_OK;
+    return idsp_ref_biquad_mt_reps(0, cfg, n, state, x, y, lanes, frames, layout, threads, 1);
+}
+
+int idsp_ref_biquad_f32_df2t_mt(const idsp_biquad_f32 *cfg, size_t n, void *state, const float *x,
+                                float *y, size_t lanes, size_t frames, int layout, int threads)
+{
+    return idsp_ref_biquad_mt_reps(1, cfg, n, state, x, y, lanes, frames, layout, threads, 1);
 }
 
 /* ------------------------------------------------------------------- hbf */

@@ -153,13 +153,20 @@ int idsp_ref_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const 
 int idsp_ref_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
                          size_t lanes, size_t frames, int layout);
 
-/* CPU-baseline helper for bench.py: run idsp_ref_biquad_i32_df1 over `lanes`
- * split across `threads` POSIX threads (contiguous lane blocks, LANE_MAJOR or
- * FRAME_MAJOR as given).  threads == 1 mirrors the reference's serial lane
- * loop (dsp-process/src/compose.rs:490-492). */
+/* CPU-baseline helpers for bench.py (and the full-size GPU tests): the lanes split into `threads`
+ * contiguous blocks, one pinned POSIX thread each.  LANE_MAJOR blocks run the reference's serial lane loop
+ * (dsp-process/src/compose.rs:478-494), FRAME_MAJOR blocks its frames-outer `[X; N]` loop
+ * (compose.rs:468-476 under process.rs:122-127).  `_mt_reps`: kind 0 = biquad_i32_df1, 1 = biquad_f32_df2t;
+ * each thread repeats its block `reps` times (state carried) so thread start-up is paid once. */
+int idsp_ref_host_cpus(void);
+int idsp_ref_biquad_mt_reps(int kind, const void *cfg, size_t n, void *state, const void *x, void *y,
+                            size_t lanes, size_t frames, int layout, int threads, int reps);
 int idsp_ref_biquad_i32_df1_mt(const idsp_biquad_i32 *cfg, size_t n, void *state,
                                const int32_t *x, int32_t *y, size_t lanes, size_t frames,
                                int layout, int threads);
+int idsp_ref_biquad_f32_df2t_mt(const idsp_biquad_f32 *cfg, size_t n, void *state,
+                                const float *x, float *y, size_t lanes, size_t frames,
+                                int layout, int threads);
 
 #ifdef __cplusplus
 }

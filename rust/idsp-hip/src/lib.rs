@@ -69,6 +69,29 @@ impl Stream {
     }
 }
 
+/// Wait for ALL work of the current device, whatever stream it was launched on (`hipDeviceSynchronize`).
+/// Launches may run on caller-chosen streams (`GpuLanes::on`, the non-blocking `MultiGpu` streams), which a
+/// NULL-stream copy does not wait for; every host read-back and every buffer replacement below goes through
+/// this first, so safe code can never observe a result before its kernel has finished.
+pub fn device_sync() -> Result<(), Error> {
+    // SAFETY: plain FFI call without arguments.
+    check(unsafe { sys::idsp_device_sync() })
+}
+
+/// The library must be at least the ABI revision this binding was generated from (`idsp-hip-sys` links symbols that
+/// revision 1 does not export).  Checked once, on the first allocation.
+fn ensure_abi() -> Result<(), Error> {
+    use std::sync::OnceLock;
+    static OK: OnceLock<bool> = OnceLock::new();
+    // SAFETY: plain FFI call without arguments.
+    let ok = *OK.get_or_init(|| unsafe { sys::idsp_version() } >= sys::IDSP_ABI_VERSION as c_int);
+    if ok {
+        Ok(())
+    } else {
+        Err(Error { code: sys::IDSP_EINVAL as i32, message: format!("libidsp_hip.so is older than ABI revision {} this binding was generated from", sys::IDSP_ABI_VERSION) })
+    }
+}
+
 // -------------------------------------------------------------------------------------- device buffers
 /// Owned device memory holding `len` values of `T` (allocated through `idsp_device_alloc`).
 pub struct DevBuf<T> {
@@ -79,6 +102,7 @@ pub struct DevBuf<T> {
 impl<T: Copy> DevBuf<T> {
     /// Zero-filled buffer (a zero-filled state is the reference's `Default::default()`).
     pub fn zeroed(len: usize) -> Result<Self, Error> {
+        ensure_abi()?;
         let mut raw: *mut c_void = core::ptr::null_mut();
         let bytes = len * core::mem::size_of::<T>();
         // SAFETY: `raw` is a valid out-pointer; the library allocates with hipMalloc.
@@ -102,6 +126,7 @@ impl<T: Copy> DevBuf<T> {
 
     pub fn to_host(&self, dst: &mut [T]) -> Result<(), Error> {
         assert_eq!(dst.len(), self.len);
+        device_sync()?; // the producer may have run on any stream
         // SAFETY: both ranges hold self.len values of T.
         check(unsafe {
             sys::idsp_device_d2h(dst.as_mut_ptr().cast(), self.ptr.cast_const().cast(), core::mem::size_of_val(dst), core::ptr::null_mut())
@@ -339,6 +364,7 @@ impl<S: StateRecord> GpuState<S> {
                 }
             }
         }
+        device_sync()?; // a launch on another stream may still be using the buffer that is replaced here
         self.words = DevBuf::from_host(&planes)?;
         Ok(())
     }

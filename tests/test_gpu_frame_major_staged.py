@@ -93,6 +93,25 @@ def test_unaligned_rows_take_the_other_kernels(gpu):
     assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
 
 
+def test_row_pitch_beyond_the_32_bit_offsets_of_the_staged_kernel(gpu):
+    """A 64-lane block of a FRAME_MAJOR tensor whose rows are 2^28 + 256 bytes apart: the staged kernel builds per-thread
+    byte offsets of up to 15 row pitches in 32 bits, so the launcher must hand such a pitch to the register-window kernel
+    (round 2 guarded 2^30 and would have wrapped here).  Same result, neighbours untouched."""
+    if FORCED_LW:
+        pytest.skip("forced form")
+    rng = np.random.default_rng(94)
+    op, cfg, n, words, dt = cases(rng)[0]
+    pitch = (1 << 26) + 64  # elements: 2^28 + 256 bytes
+    run_case(gpu, op, cfg, n, words, dt, rng, 64, 17, pitch, False, off=128)
+    assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
+    torch.cuda.empty_cache()
+    # just below the guard the staged kernel still runs, and is right
+    pitch = (1 << 26) - 64
+    run_case(gpu, op, cfg, n, words, dt, rng, 64, 17, pitch, False, off=128)
+    assert kernel_of(gpu).startswith("stream_frame_major_staged["), kernel_of(gpu)
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("lw", ["64", "32", "16"])
 def test_every_lanes_per_wave_form_on_the_ragged_shapes(gpu, lw):
     """The launcher picks the lanes per wave from the lane count; force each form in turn (IDSP_DIAG=1

@@ -121,4 +121,49 @@ def test_for_each_drives_any_entry_point(gpu):
     # a failing callee stops the loop and its status comes back
     bad = _abi.SHARD_FN(lambda user, index, lo, hi, stream: _abi.IDSP_EINVAL if index == 1 else 0)
     assert gpu.fn["multi_for_each"](m, lanes, bad, None) == _abi.IDSP_EINVAL
+    assert gpu.fn["multi_last_block"]() == 1
+    # ... and so does a positive "stop" code of the callback's own; a run through resets the block index
+    seen = []
+    stop = _abi.SHARD_FN(lambda user, index, lo, hi, stream: seen.append(index) or (7 if index == 2 else 0))
+    assert gpu.fn["multi_for_each"](m, lanes, stop, None) == 7 and seen == [0, 1, 2] and gpu.fn["multi_last_block"]() == 2
+    ok = _abi.SHARD_FN(lambda user, index, lo, hi, stream: 0)
+    assert gpu.fn["multi_for_each"](m, lanes, ok, None) == 0 and gpu.fn["multi_last_block"]() == -1
+    assert gpu.fn["multi_destroy"](m) == 0
+
+
+def test_headline_operators_validate_every_block_before_launching_any(gpu):
+    """A bad LAST block (NULL buffer) or a bad configuration is reported with nothing launched: the earlier blocks'
+    state and output stay untouched (round 2 returned after launching the blocks before the bad one)."""
+    import torch
+
+    rng = np.random.default_rng(4)
+    lanes, frames, blocks = 300, 40, 3
+    rc, m = make(gpu, [0] * blocks)
+    assert rc == 0
+    cfg = H.biquad_i32([(rng.integers(-(1 << 29), 1 << 29, size=5).tolist(), 30)])
+    xs, ys, ss = [], [], []
+    for g in range(blocks):
+        lo, hi = C.c_size_t(), C.c_size_t()
+        gpu.fn["multi_shard"](m, lanes, g, C.byref(lo), C.byref(hi))
+        n = hi.value - lo.value
+        xs.append(torch.randint(-1000, 1000, (n * frames,), dtype=torch.int32, device="cuda:0"))
+        ys.append(torch.full((n * frames,), 123, dtype=torch.int32, device="cuda:0"))
+        ss.append(torch.full((4, n), 5, dtype=torch.int32, device="cuda:0"))
+    torch.cuda.synchronize()
+    arr = lambda ts, null=None: (C.c_void_p * blocks)(*[None if i == null else t.data_ptr() for i, t in enumerate(ts)])  # noqa: E731
+    args = lambda **kw: (m, C.cast(kw.get("cfg", cfg), C.c_void_p), 1, arr(ss), arr(xs), arr(ys, kw.get("null")), lanes, frames, LM)  # noqa: E731
+    assert gpu.fn["multi_biquad_i32_df1"](*args(null=2)) == _abi.IDSP_EINVAL and gpu.fn["multi_last_block"]() == 2
+    bad = H.biquad_i32([([1, 2, 3, 4, 5], 32)])  # F = 32: `const assert!(F < 32)`
+    assert gpu.fn["multi_biquad_i32_df1"](*args(cfg=bad)) == _abi.IDSP_EINVAL and gpu.fn["multi_last_block"]() == 0
+    assert gpu.fn["multi_sync"](m) == 0
+    for y, st in zip(ys, ss):
+        assert bool((y == 123).all()) and bool((st == 5).all()), "a block was launched before validation finished"
+    assert gpu.fn["multi_biquad_i32_df1"](*args()) == 0 and gpu.fn["multi_sync"](m) == 0 and gpu.fn["multi_last_block"]() == -1
+    assert not bool((ys[0] == 123).all())
+    # overflow of lanes * bytes_per_lane and a NULL block buffer in the copy helper
+    ptrs = (C.c_void_p * blocks)()
+    assert gpu.fn["multi_alloc"](m, 1 << 40, 1 << 40, ptrs) == _abi.IDSP_EINVAL
+    host = np.zeros(lanes, np.int32)
+    assert gpu.fn["multi_copy"](m, lanes, 4, (C.c_void_p * blocks)(), host.ctypes.data, 1) == _abi.IDSP_EINVAL
+    assert gpu.fn["device_sync"]() == 0
     assert gpu.fn["multi_destroy"](m) == 0

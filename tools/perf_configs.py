@@ -320,6 +320,17 @@ def main():
     if want("c2"):
         for layout in (FM, LM):
             biquad("biquad_i32_df1", torch.int32, 4, 65536, 4096, layout, 1, it, "C2")
+    if want("ragged"):
+        # lane counts that are not multiples of 256 (reference: any N in `Lanes<C>`, dsp-process/src/compose.rs:468): 65000 and
+        # 100000 are multiples of 4 (LDS-DMA kernel with a ragged last block), 65537 is not (register-window kernel); their
+        # 256-multiples beside them
+        for lanes in (65536, 65000, 65537, 65532, 99840, 100000, 131072):
+            biquad("biquad_i32_df1", torch.int32, 4, lanes, 4096, FM, 1, it, "ragged")
+        for lanes in (65000, 65537, 100000):
+            biquad("biquad_i32_df1", torch.int32, 4, lanes, 4096, LM, 1, it, "ragged")
+    if sel and "lanesweep" in sel:  # where does the one-workgroup-per-block launch lose to the persistent grid? (IDSP_DIAG=1 IDSP_LDS_GRID=0 forces the former)
+        for blocks in (256, 288, 320, 352, 384, 416, 448, 480, 512, 576, 640, 768):
+            biquad("biquad_i32_df1", torch.int32, 4, blocks * 256, 4096, FM, 1, it, "lanesweep")
     if want("i32var"):
         for op, w in (("biquad_i32_df1_clamp", 4), ("biquad_i32_dither", 5), ("biquad_i32_dither_clamp", 5),
                       ("biquad_i32_wide", 6), ("biquad_i32_wide_clamp", 6)):
