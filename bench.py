@@ -42,8 +42,9 @@ the device (`c5_input`), uniform in [-1, 1) — the 2^32-sample tensor is then t
 ranks, which is what lets the strong-scaling checksums be compared across N.
 
 `cpu_baseline` times the CPU oracle (a C port of the reference's scalar loops — the reference is Rust and
-cannot be built here) on the host cores of the same box: pinned POSIX threads inside the C library over
-contiguous lane blocks, both layouts, all allowed cores and one thread.
+cannot be built here; the GPU box has no cargo / rustc either, profiles/r03_toolchain.txt) on the host cores of the
+same box: pinned POSIX threads inside the C library over contiguous lane blocks, both layouts, with as many threads
+as the container's CPU quota allows (`cores`) and with one thread.
 """
 from __future__ import annotations
 
@@ -332,6 +333,30 @@ def run_timed(engine, steps: int, warmup: int, settle_ms: float, dist=None):
     return time.perf_counter() - t0, durations(), done
 
 
+def host_cpu_budget(affinity_cpus: int):
+    """(threads worth using, CPU quota of this container in cores or None).  The GPU boxes expose all host cores to
+    sched_getaffinity (256) but cap the container with a cgroup CPU quota (cpu.max = "1600000 100000" = 16 cores):
+    threads beyond the quota are throttled, not run — 256 threads measured SLOWER than 16 (profiles/r03_cpu_scaling_probe.txt)."""
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2
+            q, period = f.read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    threads = affinity_cpus if quota is None else max(1, min(affinity_cpus, int(quota + 0.5)))
+    return threads, quota
+
+
 def cpu_baseline(cfg_name: str, cfg: dict, x_host=None, layout: str = "frame", seconds_budget: float = 14.0):
     """Time the CPU oracle (kind "port") on the host cores of this box.
 
@@ -358,7 +383,8 @@ def cpu_baseline(cfg_name: str, cfg: dict, x_host=None, layout: str = "frame", s
                    C.c_int, C.c_int, C.c_int]
     mt.restype = C.c_int
     lib.idsp_ref_host_cpus.restype = C.c_int
-    cores = max(1, int(lib.idsp_ref_host_cpus()))
+    affinity_cpus = max(1, int(lib.idsp_ref_host_cpus()))
+    cores, quota = host_cpu_budget(affinity_cpus)  # threads of the all-core legs = what the container may actually use
     sos = (C.c_double * 6)(*lowpass_sos(F0))
     if cfg["dtype"] == "i32":
         rec = _abi.BiquadI32()
@@ -414,12 +440,14 @@ def cpu_baseline(cfg_name: str, cfg: dict, x_host=None, layout: str = "frame", s
     best = res[best_layout]
     return {
         "value": best["all_cores"], "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "host_cpus": affinity_cpus, "cgroup_cpu_quota": quota,
         "single_thread_value": max(res[k]["one_thread"] for k in res),
         "layout_of_value": best_layout, "by_layout": res,
         "parallel_efficiency": best["parallel_efficiency"],
         "dram_gbs_at_value": round(best["all_cores"] * cfg["bytes_per_sample"] / 1e3, 1),
-        "note": "all-core rate / (one-thread rate x cores) below ~0.5 means the all-core leg is capped by host DRAM "
-                "bandwidth (dram_gbs_at_value = 8 B per sample at that rate; x and y are first-touched by one thread)",
+        "note": "`cores` = threads of the all-core legs = min(CPUs in the affinity mask, cgroup CPU quota): threads beyond the quota are "
+                "throttled.  parallel_efficiency = all-core rate / (one-thread rate x cores); dram_gbs_at_value = 8 B per sample at "
+                "that rate (x and y are first-touched by one thread)",
         "sample": f"{lanes} of {cfg['lanes']} lanes x {frames} samples ({'the full tensor the GPU ran' if lanes == cfg['lanes'] else 'a lane prefix of it'}), "
                   f"C oracle {flavour}, pinned pthreads over contiguous lane blocks, ~{seconds_budget:.0f} s in 4 legs; "
                   "reference is Rust (no toolchain here)",

@@ -32,6 +32,7 @@ inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t f
         return e ? atoi(e) : 0;
     }();
     if (off || frames == 0) return 0;
+    if (lanes >= (size_t(1) << 28)) return 0;  // 32-bit thread offsets inside a row (8-byte elements, 3 input rows of 4 lanes bytes)
     if (layout == IDSP_LANE_MAJOR && !(frames % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0))
         return 0;
     if (forced == 4 || forced == 6) return forced;

@@ -324,6 +324,15 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
                  : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))  // uniform by construction; pin it to an SGPR
                  : "memory");
 }
+// Same with the address split into a wave-uniform base (SGPR pair) and a 32-bit thread offset: no 64-bit VALU add per request
+__device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                 : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {

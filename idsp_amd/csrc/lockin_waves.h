@@ -31,7 +31,9 @@ constexpr int kLwB = 8;     // frames per batch, FrameMajor
 constexpr int kLwBLm = 16;  // LaneMajor: 16 frames = one whole 128-byte line of 8-byte output elements per lane and batch
 enum { MODE_IQ = 0, MODE_ARG = 1, MODE_NORM_SQR = 2 };
 enum { IN_FM_REG = 0, IN_FM_DMA = 1, IN_LM_REG = 2, IN_LM_DMA = 3 };
-constexpr int kLwRing = 4, kLwAhead = 3;  // LDS input ring slots, batches in flight
+// LaneMajor DMA: ring slots of one PAIR of batches (8 KiB) each, pairs requested ahead.  Three slots keep the workgroup at
+// 70 KiB of LDS, so that two of them share a CU (four slots: 78 KiB, measured slower: 0.457 against 0.42-0.44 ms at C4)
+constexpr int kLwRing = 3, kLwAhead = 2;
 #ifndef IDSP_LW_OUT_GROUP
 #define IDSP_LW_OUT_GROUP 1
 #endif
@@ -50,71 +52,147 @@ struct LwOut<MODE_NORM_SQR> {
     using type = int64_t;
 };
 
+// Exchange rows.  Everything the waves hand each other per batch is one ROW per lane and component: B words at a pitch
+// of B + 4 words (80 or 48 bytes: 16-byte aligned, and 5 resp. 3 bank quartets — odd — so that the 16 lanes of every
+// ds_read_b128 group and the 8 lanes of every ds_write_b128 group fall into different banks for any piece).  A thread
+// moves its frames of a row as 16-byte vectors: round 2 exchanged single words in [frame][lane] order, 5 LDS
+// instructions per lane and frame; this is 1.25.
+template <int CNT>
+__device__ __forceinline__ void row_load(const int32_t *p, int32_t (&v)[CNT])
+{
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (CNT == 2) {
+        const i32x2 a = *reinterpret_cast<const i32x2 *>(p);
+        v[0] = a.x, v[1] = a.y;
+    } else {
+        static_assert(CNT % 4 == 0, "whole 16-byte pieces");
+#pragma unroll
+        for (int q = 0; q < CNT / 4; q++) {
+            const i32x4 a = reinterpret_cast<const i32x4 *>(p)[q];
+            v[4 * q] = a.x, v[4 * q + 1] = a.y, v[4 * q + 2] = a.z, v[4 * q + 3] = a.w;
+        }
+    }
+}
+template <int CNT>
+__device__ __forceinline__ void row_store(int32_t *p, const int32_t (&v)[CNT])
+{
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (CNT == 2) {
+        *reinterpret_cast<i32x2 *>(p) = i32x2{v[0], v[1]};
+    } else {
+#pragma unroll
+        for (int q = 0; q < CNT / 4; q++) reinterpret_cast<i32x4 *>(p)[q] = i32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    }
+}
+
+// tools/exp_lockin_trace.hip builds this header with IDSP_LW_TRACE: per-wave cycle sums of the phases of an interval
+#ifdef IDSP_LW_TRACE
+__device__ unsigned long long g_lw_trace[8][8];  // [wave][phase], workgroup 0 only
+__device__ unsigned long long g_lw_wg[4096][8][3];  // [workgroup][wave]: s_memrealtime at start, at end, HW_ID | XCC_ID << 32
+#define LW_T(i)                                           \
+    do {                                                  \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        tr[i] += t_ - tlast;                              \
+        tlast = t_;                                       \
+    } while (0)
+#else
+#define LW_T(i) ((void)0)
+#endif
+
+constexpr int kLwFmRing = 5, kLwFmAhead = 4;  // FrameMajor DMA: LDS input ring slots, batches requested ahead
+
 template <int N, int K, int W, int IN, int MODE, int B>
 __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN == IN_LM_REG || IN == IN_LM_DMA ? 2 : 10))) void lockin_waves_kernel(const LpParams prm, uint32_t *st, const int32_t *x,
                                                                  typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames)
 {
     using Out = typename LwOut<MODE>::type;
     constexpr bool LMD = IN == IN_LM_DMA, LM = IN == IN_LM_REG || LMD, DMA = IN == IN_FM_DMA;
-    constexpr int kLut = 1 << kCossinDepth;
-    constexpr int P = W - 2, C = B / P;  // read-out waves; each takes frames b = r * C + j, j < C, of a batch
-    static_assert(B % P == 0 && B % 8 == 0, "batch splits evenly over the read-out waves and into 4-row DMA groups per arm wave");
-    __shared__ uint32_t lut[kLut];
+    // Where the mixer multiply `x * lo` (src/lockin.rs:34-37) runs: with the input in LDS (both DMA forms) the read-out waves
+    // apply it while they hold cos / sin, and the rows carry the mixed samples — the arm waves are then the two lowpass
+    // chains and nothing else (14 VALU instructions per frame for [Lowpass<2>; 2]); with register prefetch the input lives in
+    // the arm waves' registers, so the rows carry cos / sin and the arm multiplies.
+#ifndef IDSP_LW_MIXR
+#define IDSP_LW_MIXR 0
+#endif
+    constexpr bool MIXR = IDSP_LW_MIXR && (DMA || LMD);
+    constexpr int P = W - 2, C = B / P;  // read-out waves; each takes frames r C .. r C + C - 1 of a batch
+    constexpr int RS = B + 4;            // row pitch in words
+    static_assert(B % P == 0 && B % 8 == 0 && (C == 2 || C % 4 == 0), "batch splits evenly over the read-out waves, into 4-row DMA groups per arm wave, into vectors");
+    __shared__ __attribute__((aligned(16))) uint32_t ctab[kCosWideWords];
     __shared__ uint32_t tab[32];
-    __shared__ Cplx lo[2][B][kWave];
-    __shared__ int32_t arm[2][2][B][kWave];  // [buffer][I/Q][frame][lane]
+    // rows[buffer][I / Q][lane]: batch n lives in buffer n % 3 — written by the read-out waves (LO or mixed samples) during
+    // interval n - 1, turned into the arm outputs IN PLACE by the arm waves during interval n, read back by the read-out waves
+    // during interval n + 1
+    __shared__ __attribute__((aligned(16))) int32_t rows[3][2][kWave * RS];
     // FM DMA: [slot][frame][lane]; LM DMA: kLwRing slots of 64 lanes x 128 bytes (two batches), rows permuted and pieces swizzled
-    __shared__ __attribute__((aligned(16))) int32_t xs[DMA ? kLwRing : LMD ? 2 * kLwRing : 1][B * kWave];
-    const int w = threadIdx.x / kWave, lid = threadIdx.x % kWave;
-    const bool arm_wave = w < 2;         // wave-uniform role
+    __shared__ __attribute__((aligned(16))) int32_t xs[DMA ? kLwFmRing : LMD ? 2 * kLwRing : 1][B * kWave];
+    // wave-uniform role, pinned to SGPRs: everything derived from it (row pointers of the output, LDS slots) is scalar
+    const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave), lid = int(threadIdx.x) % kWave;
+    const bool arm_wave = w < 2;
     const int r = arm_wave ? w : w - 2;  // arm waves: I / Q; read-out waves: frame group
     const size_t lane = size_t(blockIdx.x) * kWave + lid;
     const bool active = lane < lanes;
     const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
-    fill_cossin(lut, threadIdx.x, W * kWave);
+    fill_cossin_wide(ctab, threadIdx.x, W * kWave);
     if (MODE == MODE_ARG && threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
+    const char *const cmine = cossin_wide_base(ctab, lid);
     const uint32_t acc0 = st[la], inc = st[lanes + la];
     LpBank<N, K> bank;
     if (arm_wave) bank.load(st, lanes, la, 2 + (r ? 2 * N * K : 0));
-    // FrameMajor row base pointers are wave-uniform and the lane offset is one 32-bit register
+    // The state loads must have landed HERE, in a way the compiler's wait-count pass sees: it cannot see the DMA requests, and a
+    // first use of a state register inside the steady-state loop would be protected by `s_waitcnt vmcnt(0)` on every interval,
+    // draining the input ring each time (lane_stream.h, stream_frame_major_lds).  vmcnt(0), expcnt / lgkmcnt untouched:
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     const uint32_t lo32 = uint32_t(la), lane32 = uint32_t(lane);
     uint32_t phase = acc0;  // accumulator before the batch whose LO is produced next
-    int32_t xn[B];
+    int32_t xn[DMA || LMD ? 1 : B];
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
     auto fetch = [&](size_t f0, auto full) {
-        if constexpr (LM) {
-            const i32x4 *row = reinterpret_cast<const i32x4 *>(x + la * frames + f0);
+        if constexpr (!DMA && !LMD) {
+            if constexpr (LM) {
+                const i32x4 *row = reinterpret_cast<const i32x4 *>(x + la * frames + f0);
 #pragma unroll
-            for (int v = 0; v < B / 4; v++) {
-                const i32x4 a = row[v];
-                xn[4 * v] = a.x, xn[4 * v + 1] = a.y, xn[4 * v + 2] = a.z, xn[4 * v + 3] = a.w;
-            }
-        } else {
+                for (int v = 0; v < B / 4; v++) {
+                    const i32x4 a = row[v];
+                    xn[4 * v] = a.x, xn[4 * v + 1] = a.y, xn[4 * v + 2] = a.z, xn[4 * v + 3] = a.w;
+                }
+            } else {
 #pragma unroll
-            for (int b = 0; b < B; b++) {
-                const int32_t *row = x + (f0 + b) * lanes;
-                xn[b] = (decltype(full)::value || f0 + b < frames) ? row[lo32] : 0;
+                for (int b = 0; b < B; b++) {
+                    const int32_t *row = x + (f0 + b) * lanes;
+                    xn[b] = (decltype(full)::value || f0 + b < frames) ? row[lo32] : 0;
+                }
             }
         }
     };
-    // arm wave r moves rows r B/2 .. of batch n, 4 rows per instruction: lane l takes the 16 bytes at column (l % 16) * 4 of row l / 16;
-    // rows past the end re-read the last frame (never consumed) so that every interval issues exactly one operation
-    auto dma = [&](size_t n) {
+    // FrameMajor DMA.  Arm wave r moves rows r B/2 .. of batch n into ring slot `slot`, 4 rows per instruction: lane l takes
+    // the 16 bytes at column (l % 16) * 4 of row l / 16; rows past the end re-read the last frame (never consumed) so that every
+    // interval issues exactly B / 8 operations per arm wave
+    // (whole groups: wave-uniform row base in SGPRs + this thread's constant 32-bit offset, no per-request address arithmetic)
+    const uint32_t dma_off = uint32_t(lid / 16) * uint32_t(lanes) * 4u + uint32_t(lid % 16) * 16u;  // launcher: 3 lanes * 4 < 2^32
+    auto dma = [&](size_t n, int slot) {
 #pragma unroll
         for (int g = 0; g < B / 8; g++) {
             const int r0 = r * (B / 2) + 4 * g;  // first of the 4 rows this instruction moves
-            size_t row = n * B + size_t(r0 + lid / 16);
-            row = row < frames ? row : frames - 1;
-            glds16(x + row * lanes + size_t(blockIdx.x) * kWave + size_t(lid % 16) * 4,
-                   uint32_t(reinterpret_cast<uintptr_t>(&xs[n % kLwRing][r0 * kWave])));
+            const uint32_t dst = uint32_t(reinterpret_cast<uintptr_t>(&xs[slot][r0 * kWave]));
+            const size_t row0 = n * B + size_t(r0);
+            if (row0 + 4 <= frames) {
+                glds16_s(uniform_ptr(x + row0 * lanes + size_t(blockIdx.x) * kWave), dma_off, dst);
+            } else {
+                size_t row = row0 + size_t(lid / 16);
+                row = row < frames ? row : frames - 1;
+                glds16(x + row * lanes + size_t(blockIdx.x) * kWave + size_t(lid % 16) * 4, dst);
+            }
         }
     };
     // LaneMajor input by DMA: a pair of batches = one whole 128-byte line per lane.  Instruction j of a pair fetches the lines
     // of lanes j, j + 8, ... (8 threads per line) so that every line is requested once, by one instruction; thread t takes
-    // piece (t % 8) ^ j, which leaves lane l's piece k at slot row (l % 8) 8 + l / 8, offset 16 (k ^ (l % 8)): the arm
-    // threads' ds_read_b128 of their own row are conflict free.  Arm wave r issues instructions 4 r .. 4 r + 3; pieces past
-    // the end of the row (odd number of batches) and pairs past the end re-read frame 0 (never consumed), so that every
-    // pair issues exactly four operations per arm wave.
+    // piece (t % 8) ^ j, which leaves lane l's piece k at slot row (l % 8) 8 + l / 8, offset 16 (k ^ (l % 8)): a thread's
+    // ds_read_b128 of its own row is conflict free.  Arm wave r issues instructions 4 r .. 4 r + 3; pieces past the end of the row
+    // (odd number of batches) and pairs past the end re-read frame 0 (never consumed), so that every pair issues exactly four
+    // operations per arm wave.
     auto dma_lm = [&](size_t pair) {
         if constexpr (LMD) {
 #pragma unroll
@@ -129,16 +207,43 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
         }
     };
     const uint32_t xs_own = uint32_t((lid % 8) * 8 + lid / 8) * 128 + uint32_t(lid % 8) * 16;  // LM DMA: own row, piece k at ^ 16 k
-    auto lo_stage = [&](int buf) {
+#ifdef IDSP_LW_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long t_begin = tlast, rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    int slot_issue = 0, slot_read = 0;  // FM DMA ring positions of the next request (arm waves) / the next batch mixed (read-out waves)
+
+    // ---- read-out waves, first half of an interval: cos / sin (and, with the input in LDS, the mixer) of batch n into `dstb`
+    auto lo_stage = [&](size_t n, int dstb) {
+        int32_t re[C], im[C], xv[C];
+        if constexpr (!MIXR) {
+        } else if constexpr (DMA) {
+#pragma unroll
+            for (int j = 0; j < C; j++) xv[j] = xs[slot_read][(r * C + j) * kWave + lid];
+            slot_read = slot_read + 1 == kLwFmRing ? 0 : slot_read + 1;
+        } else if constexpr (LMD) {
+            static_assert(!LMD || (B == 16 && C % 4 == 0), "a pair of batches is one 128-byte line per lane; a read-out thread takes whole pieces");
+            const char *slot = reinterpret_cast<const char *>(&xs[0][0]) + ((n / 2) % kLwRing) * 8192;
+#pragma unroll
+            for (int v = 0; v < C / 4; v++) {
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(slot + (xs_own ^ uint32_t(((n % 2) * 4 + (r * C) / 4 + v) * 16)));
+                xv[4 * v] = a.x, xv[4 * v + 1] = a.y, xv[4 * v + 2] = a.z, xv[4 * v + 3] = a.w;
+            }
+        }
+        LW_T(0);
 #pragma unroll
         for (int j = 0; j < C; j++) {
-            const int b = r * C + j;
-            lo[buf][b][lid] = cossin_dev(int32_t(phase + inc * uint32_t(b + 1)), lut);
+            const Cplx lo = cossin_wide(phase + inc * uint32_t(r * C + j + 1), cmine);
+            re[j] = MIXR ? __mulhi(lo.re, xv[j]) : lo.re;
+            im[j] = MIXR ? __mulhi(lo.im, xv[j]) : lo.im;
         }
         phase += inc * uint32_t(B);
+        LW_T(1);
+        row_store<C>(&rows[dstb][0][lid * RS + r * C], re);
+        row_store<C>(&rows[dstb][1][lid * RS + r * C], im);
+        LW_T(2);
     };
-    auto element = [&](int buf, int b, int ln) -> Out {
-        const int32_t re = arm[buf][0][b][ln], im = arm[buf][1][b][ln];
+    auto element = [&](int32_t re, int32_t im) -> Out {
         if constexpr (MODE == MODE_IQ)
             return Cplx{re, im};
         else if constexpr (MODE == MODE_ARG)
@@ -146,36 +251,38 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
         else
             return int64_t(uint64_t(int64_t(re) * re) + uint64_t(int64_t(im) * im));  // wraps for (MIN, MIN) as in release
     };
-    // LaneMajor: a read-out thread keeps its pieces of kLwOutGroup batches in registers and stores them together, so that the
-    // wave leaves kLwOutGroup * 16 frames (512 bytes of Complex<i32>) per lane in one burst of store instructions
-    // instead of one 128-byte line per lane and batch (run length per lane is what the LaneMajor rate follows, see
-    // stream_lane_major_staged)
+    // LaneMajor: a read-out thread keeps its pieces of kLwOutGroup batches in registers and stores them together (kept as a
+    // knob: measured equal at 1 and 4, the form is not bound by its output run length)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int GV = int(sizeof(Out)) * C / 16;  // 16-byte vectors a read-out thread writes per batch (LaneMajor)
     u32x4 held[LM ? kLwOutGroup : 1][LM ? GV : 1];
+    // ---- read-out waves, second half: the arm outputs of the batch that starts at frame f0 (buffer srcb) become output elements.
     // `slot` (static): position of the batch inside its output group; `flush`: last batch of the call
-    auto out_stage = [&](size_t f0, int buf, int nb, auto full, auto slot_tag, bool flush) {
+    auto out_stage = [&](size_t f0, int srcb, int nb, auto full, auto slot_tag, bool flush) {
         if constexpr (LM) {
-            // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the 16 frames of one lane, so that one store
-            // instruction leaves 8 * sizeof(Out) contiguous bytes per lane instead of two (four) pieces at different times
-            static_assert((sizeof(Out) * C) % 16 == 0, "a thread's piece of a batch is whole 16-byte vectors");
+            // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the B frames of one lane, so that one store
+            // instruction leaves B * sizeof(Out) contiguous bytes per lane
+            static_assert(!LM || (sizeof(Out) * C) % 16 == 0, "a thread's piece of a batch is whole 16-byte vectors");
             const int ll = r * (kWave / P) + lid / P, part = lid % P;
             const size_t gl = size_t(blockIdx.x) * kWave + size_t(ll);
             constexpr int slot = decltype(slot_tag)::value;
             constexpr int OW = int(sizeof(Out)) / 4;
-            uint32_t w[C * OW];
+            int32_t re[C], im[C];
+            row_load<C>(&rows[srcb][0][ll * RS + part * C], re);
+            row_load<C>(&rows[srcb][1][ll * RS + part * C], im);
+            uint32_t wd[C * OW];
 #pragma unroll
             for (int j = 0; j < C; j++) {
-                const Out e = element(buf, part * C + j, ll);
+                const Out e = element(re[j], im[j]);
                 if constexpr (OW == 1) {
-                    w[j] = __builtin_bit_cast(uint32_t, e);
+                    wd[j] = __builtin_bit_cast(uint32_t, e);
                 } else {
                     const uint64_t u = __builtin_bit_cast(uint64_t, e);
-                    w[2 * j] = uint32_t(u), w[2 * j + 1] = uint32_t(u >> 32);
+                    wd[2 * j] = uint32_t(u), wd[2 * j + 1] = uint32_t(u >> 32);
                 }
             }
 #pragma unroll
-            for (int v = 0; v < GV; v++) held[slot][v] = u32x4{w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]};
+            for (int v = 0; v < GV; v++) held[slot][v] = u32x4{wd[4 * v], wd[4 * v + 1], wd[4 * v + 2], wd[4 * v + 3]};
             if (slot == kLwOutGroup - 1 || flush) {
                 u32x4 *dst = reinterpret_cast<u32x4 *>(y + gl * frames + (f0 - size_t(slot) * B) + part * C);
 #pragma unroll
@@ -186,106 +293,170 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
                     }
             }
         } else {
+            int32_t re[C], im[C];
+            row_load<C>(&rows[srcb][0][lid * RS + r * C], re);
+            row_load<C>(&rows[srcb][1][lid * RS + r * C], im);
+            LW_T(3);
+            // wave-uniform row base (SGPRs) + this thread's 32-bit byte offset (launcher: lanes * sizeof(Out) < 2^32)
+            char *row = reinterpret_cast<char *>(uniform_ptr(y + (f0 + size_t(r * C)) * lanes));
+            const uint32_t off = lane32 * uint32_t(sizeof(Out));
 #pragma unroll
             for (int j = 0; j < C; j++) {
-                const int b = r * C + j;
-                if ((decltype(full)::value || b < nb) && active) {
-                    Out *row = y + (f0 + b) * lanes;
-                    nt_store<true>(row + lane32, element(buf, b, lid));  // 8-byte elements leave as one 2-word vector
-                }
+                if ((decltype(full)::value || r * C + j < nb) && active)
+                    nt_store<true>(reinterpret_cast<Out *>(row + size_t(off)), element(re[j], im[j]));  // 8-byte elements leave as one 2-word vector
+                row += lanes * sizeof(Out);
             }
+            LW_T(4);
         }
     };
-    auto iter = [&](size_t n, int nb, auto full, auto first, auto slot_tag) {
+    // ---- arm waves: batch n (nb frames of it) through this arm's lowpass chain, in place in buffer `buf`
+    auto arm_stage = [&](size_t n, int buf, int nb, auto full) {
         const size_t f0 = n * B;
-        const int buf = int(n & 1);
-        if (arm_wave) {
-            int32_t xv[B];
-            if constexpr (DMA) {
-                dma(n + kLwAhead);
+        int32_t xv[MIXR ? 1 : B];
+        if constexpr (DMA) {
+            dma(n + kLwFmAhead, slot_issue);
+            slot_issue = slot_issue + 1 == kLwFmRing ? 0 : slot_issue + 1;
+            if constexpr (!MIXR) {
 #pragma unroll
-                for (int b = 0; b < B; b++) xv[b] = xs[n % kLwRing][b * kWave + lid];
-            } else if constexpr (LMD) {
-                static_assert(B == 16, "a pair of batches is one 128-byte line per lane");
-                if (n % 2 == 0) dma_lm(n / 2 + kLwAhead);
+                for (int b = 0; b < B; b++) xv[b] = xs[slot_read][b * kWave + lid];
+                slot_read = slot_read + 1 == kLwFmRing ? 0 : slot_read + 1;
+            }
+        } else if constexpr (LMD) {
+            if (n % 2 == 0) dma_lm(n / 2 + kLwAhead);
+            if constexpr (!MIXR) {
                 const char *slot = reinterpret_cast<const char *>(&xs[0][0]) + ((n / 2) % kLwRing) * 8192;
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     const i32x4 a = *reinterpret_cast<const i32x4 *>(slot + (xs_own ^ uint32_t(((n % 2) * 4 + v) * 16)));
                     xv[4 * v] = a.x, xv[4 * v + 1] = a.y, xv[4 * v + 2] = a.z, xv[4 * v + 3] = a.w;
                 }
-            } else {
-#pragma unroll
-                for (int b = 0; b < B; b++) xv[b] = xn[b];
-                if (f0 + 2 * B <= frames)
-                    fetch(f0 + B, std::true_type{});
-                else if (f0 + B < frames)
-                    fetch(f0 + B, std::false_type{});
-            }
-            const int32_t *lo_mine = reinterpret_cast<const int32_t *>(&lo[buf][0][lid]) + r;  // this arm's LO component
-#pragma unroll
-            for (int b = 0; b < B; b++)
-                if (decltype(full)::value || b < nb) arm[buf][r][b][lid] = bank.step(prm, __mulhi(lo_mine[b * kWave * 2], xv[b]));
-            if constexpr (DMA) wait_vmcnt<(kLwAhead - 1) * (B / 8)>();  // batch n + 1 has landed
-            if constexpr (LMD) {
-                if (n % 2 == 1) wait_vmcnt<(kLwAhead - 1) * 4>();  // the pair of batches n + 1, n + 2 has landed
             }
         } else {
-            lo_stage(buf ^ 1);
-            if constexpr (!decltype(first)::value) out_stage(f0 - B, buf ^ 1, B, std::true_type{}, slot_tag, false);
+#pragma unroll
+            for (int b = 0; b < B; b++) xv[b] = xn[b];
+            if (f0 + 2 * B <= frames)
+                fetch(f0 + B, std::true_type{});
+            else if (f0 + B < frames)
+                fetch(f0 + B, std::false_type{});
         }
-        __syncthreads();
+        LW_T(0);
+        int32_t v[B];
+        int32_t *row = &rows[buf][r][lid * RS];
+        row_load<B>(row, v);
+        LW_T(1);
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (decltype(full)::value || b < nb) {
+                if constexpr (MIXR)
+                    v[b] = bank.step(prm, v[b]);
+                else
+                    v[b] = bank.step(prm, __mulhi(v[b], xv[b]));
+            }
+        }
+        LW_T(2);
+        row_store<B>(row, v);
+        LW_T(3);
+        // the read-out waves mixed batch n + 1 during this interval; the next interval needs batch n + 2 in LDS
+        // (mixer in the read-out waves: they need batch n + 2 during the next interval; in the arm waves: batch n + 1)
+        constexpr int kEarly = MIXR ? 2 : 1;
+        if constexpr (DMA) wait_vmcnt<(kLwFmAhead - kEarly) * (B / 8)>();  // batches up to n + kEarly have landed, the later ones may be in flight
+        if constexpr (LMD) {
+            if (n % 2 == 1) wait_vmcnt<(kLwAhead - kEarly) * 4>();  // pairs up to (n + 1) / 2 + kEarly - 1 have landed
+        }
+        LW_T(4);
     };
     if (arm_wave) {
         if constexpr (DMA) {
-            for (int n = 0; n < kLwAhead; n++) dma(size_t(n));
-            wait_vmcnt<(kLwAhead - 1) * (B / 8)>();  // batch 0 has landed
+            for (int n = 0; n < kLwFmAhead; n++) {
+                dma(size_t(n), slot_issue);
+                slot_issue++;
+            }
+            static_assert(kLwFmAhead < kLwFmRing, "the ring holds the batch being mixed and the ones in flight");
+            wait_vmcnt<(kLwFmAhead - (MIXR ? 2 : 1)) * (B / 8)>();  // batch 0 (and 1, if the read-out waves mix) has landed
         } else if constexpr (LMD) {
             for (int n = 0; n < kLwAhead; n++) dma_lm(size_t(n));
-            wait_vmcnt<(kLwAhead - 1) * 4>();  // pair 0 has landed
+            wait_vmcnt<(kLwAhead - (MIXR ? 2 : 1)) * 4>();  // pair 0 (and 1) has landed
         } else if (frames >= size_t(B)) {
             fetch(0, std::true_type{});
         } else {
             fetch(0, std::false_type{});
         }
     }
-    __syncthreads();  // tables
-    if (!arm_wave) lo_stage(0);
+    __syncthreads();  // tables, first input batches
+    if (!arm_wave) lo_stage(0, 0);
     __syncthreads();
     const size_t nfull = frames / B;
     const int tail = int(frames % B);
+    const size_t nbatch = nfull + (tail ? 1 : 0);
     using Slot0 = std::integral_constant<int, 0>;
+    int cur = 0;  // n % 3
+    auto next3 = [](int b) { return b == 2 ? 0 : b + 1; };
+    auto prev3 = [](int b) { return b == 0 ? 2 : b - 1; };
+    // interval n: arm waves batch n; read-out waves LO / mixer of batch n + 1, then the output of batch n - 1
+    // Two workgroups share a CU at the C4 lane counts, and VALU issue is arbitrated by priority, then AGE: the older workgroup's
+    // waves win every conflict, it runs at nearly its solo speed and the younger one crawls until the older has finished —
+    // per-workgroup end times of 285 and 415 us on every CU (tools/exp_lockin_trace.hip), i.e. a third of the launch with half
+    // of each CU idle.  The two swap priority every interval instead (the co-resident workgroups of a CU are blockIdx b and
+    // b + 256: dispatch order), so that both advance at the same average rate.
+#ifndef IDSP_LW_PRIO
+#define IDSP_LW_PRIO 3
+#endif
+    const unsigned prio_class = (blockIdx.x >> 8) & 1u;
+    auto interval = [&](size_t n, int nb, auto full, auto slot_tag) {
+        if constexpr (IDSP_LW_PRIO != 0) {
+            if ((unsigned(n) ^ prio_class) & 1u)
+                __builtin_amdgcn_s_setprio(IDSP_LW_PRIO);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        }
+        if (arm_wave) {
+            arm_stage(n, cur, nb, full);
+        } else {
+            if (n + 1 < nbatch) lo_stage(n + 1, next3(cur));
+            if (n > 0) out_stage((n - 1) * B, prev3(cur), B, std::true_type{}, slot_tag, false);
+        }
+        __syncthreads();
+        LW_T(5);
+        cur = next3(cur);
+    };
     if constexpr (LM) {
-        // whole batches only (launcher): batch n - 1 leaves in iteration n, its group slot (n - 1) % kLwOutGroup is static
-        iter(0, B, std::true_type{}, std::true_type{}, Slot0{});
+        // whole batches only (launcher): batch n - 1 leaves in interval n, its group slot (n - 1) % kLwOutGroup is static
+        interval(0, B, std::true_type{}, Slot0{});
         size_t n = 1;
         while (n < nfull)
             static_for<kLwOutGroup>([&](auto q) {
                 if (n < nfull) {
-                    iter(n, B, std::true_type{}, std::false_type{}, q);
+                    interval(n, B, std::true_type{}, q);
                     n++;
                 }
             });
         if (!arm_wave)
             static_for<kLwOutGroup>([&](auto q) {
-                if (int((nfull - 1) % kLwOutGroup) == decltype(q)::value)
-                    out_stage((nfull - 1) * B, int((nfull - 1) & 1), B, std::true_type{}, q, true);
+                if (int((nfull - 1) % kLwOutGroup) == decltype(q)::value) out_stage((nfull - 1) * B, prev3(cur), B, std::true_type{}, q, true);
             });
     } else {
-        if (nfull) {
-            iter(0, B, std::true_type{}, std::true_type{}, Slot0{});
-            for (size_t n = 1; n < nfull; n++) iter(n, B, std::true_type{}, std::false_type{}, Slot0{});
-        }
+        for (size_t n = 0; n < nfull; n++) interval(n, B, std::true_type{}, Slot0{});
         if (tail) {
-            if (nfull)
-                iter(nfull, tail, std::false_type{}, std::false_type{}, Slot0{});
-            else
-                iter(0, tail, std::false_type{}, std::true_type{}, Slot0{});
-            if (!arm_wave) out_stage(nfull * B, int(nfull & 1), tail, std::false_type{}, Slot0{}, true);
+            interval(nfull, tail, std::false_type{}, Slot0{});
+            if (!arm_wave) out_stage(nfull * B, prev3(cur), tail, std::false_type{}, Slot0{}, true);
         } else if (!arm_wave) {
-            out_stage((nfull - 1) * B, int((nfull - 1) & 1), B, std::true_type{}, Slot0{}, true);
+            out_stage((nfull - 1) * B, prev3(cur), B, std::true_type{}, Slot0{}, true);
         }
     }
+#ifdef IDSP_LW_TRACE
+    if (lid == 0 && blockIdx.x < 4096) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_lw_wg[blockIdx.x][w][0] = rt_begin, g_lw_wg[blockIdx.x][w][1] = __builtin_amdgcn_s_memrealtime();
+        g_lw_wg[blockIdx.x][w][2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+    if (blockIdx.x == 0 && lid == 0) {
+        for (int i = 0; i < 6; i++) g_lw_trace[w][i] = tr[i];
+        g_lw_trace[w][6] = __builtin_readcyclecounter() - t_begin;       // s_memtime ticks of the whole kernel
+        g_lw_trace[w][7] = __builtin_amdgcn_s_memrealtime() - rt_begin;  // 100 MHz ticks of the whole kernel
+    }
+#endif
     if (active && arm_wave) {
         if (r == 0) st[lane] = acc0 + inc * uint32_t(frames);
         bank.store(st, lanes, lane, 2 + (r ? 2 * N * K : 0));
@@ -320,7 +491,9 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
         const char *e = diag_env("IDSP_LOCKIN_B");
         return e ? atoi(e) : 0;
     }();
-    const bool b16 = forced_b == 16 || (forced_b != 8 && lanes <= kSplitMaxLanes);
+    // the 6-wave form keeps 8-frame batches: with 16 (66 KiB of LDS) only ONE 6-wave workgroup runs on a CU at a time — every
+    // second workgroup started after the first had finished (tools/exp_lockin_trace.hip) although the occupancy API promises two
+    const bool b16 = forced_b == 16 || (forced_b != 8 && lanes <= kSplitMaxLanes && waves == 4);
     if (layout == IDSP_LANE_MAJOR) {
         // input by DMA (whole 128-byte lines, each requested once) for the 4-wave I/Q and norm_sqr forms: 0.48 -> 0.43-0.44 ms
         // at 32768 lanes x 4096 frames, 0.94 -> 0.86 at 65536; its 32 KiB ring halves the workgroups a CU can hold, which
