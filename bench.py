@@ -523,11 +523,19 @@ def spawn_command(n: int, argv, script: str | None = None):
 
 
 def spawn(n: int, argv, script: str | None = None, **popen_kw) -> int:
-    """Start n ranks of `script` (default: this file) and wait for them; rank 0 prints the JSON line."""
+    """Start n ranks of `script` (default: this file) and wait for them; rank 0 prints the JSON line.  The ranks' stdout is
+    filtered: JSON lines go to stdout, anything else a library prints there (gloo's connection banner) goes to stderr, so that
+    stdout of `bench.py --gpus N` is the ONE line of the contract."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(spawn_command(n, argv, script), env=env, **popen_kw)
+    if popen_kw:
+        return subprocess.call(spawn_command(n, argv, script), env=env, **popen_kw)
+    proc = subprocess.Popen(spawn_command(n, argv, script), env=env, stdout=subprocess.PIPE, text=True, errors="replace")
+    for ln in proc.stdout:
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def gather_ints(values, dist, device):

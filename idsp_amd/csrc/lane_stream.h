@@ -402,7 +402,32 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     // (a workgroup that owns ADJACENT blocks instead — blocks [w rounds, (w + 1) rounds) — was measured slower: 0.58 vs
     // 0.68 of peak at 2^20 lanes, profiles/r02_exp_c5_matrix6.jsonl: the panel order keeps the concurrently active
     // columns in one contiguous 256 KiB piece of every row)
+    // Order in which a persistent workgroup visits its column panels.  All workgroups advance through the frames in
+    // lockstep, so with the plain order (0) the whole launch touches the same few rows of ONE 256 KiB panel at any instant.
+    // Order 3 — the upper half of the grid starts half way through its panels — keeps two panels active: over nine
+    // placements of the output buffer 0.71-0.77 against 0.68-0.72 at 131072 lanes, 0.67-0.71 against 0.65-0.67 at 262144,
+    // 0.61-0.72 against 0.64-0.70 at 2^20 (profiles/r03_exp_c5_order.jsonl; tools/exp_c5_place.hip builds every order).
+    // Single-round launches (C2) are the same walk in every order.
+#ifndef IDSP_LDS_ORDER
+#define IDSP_LDS_ORDER 3
+#endif
+#if IDSP_LDS_ORDER == 0
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+#else
+    // tools/exp_c5_place.hip: other orders in which a persistent workgroup visits its column panels (all workgroups advance
+    // through the frames in lockstep, so at any instant the launch touches the same few rows of ONE panel; these spread it
+    // over several).  1: rotated by XCD (blockIdx % 8); 2: rotated by groups of 32 adjacent workgroups; 3: the upper half of
+    // the grid starts half way; 4: odd workgroups walk the panels backwards.
+    const size_t rounds_ = (nblocks + gridDim.x - 1) / gridDim.x;
+    for (size_t k_ = 0; k_ < rounds_; k_++) {
+    size_t rr_ = k_;
+    if (IDSP_LDS_ORDER == 1) rr_ = (k_ + (blockIdx.x & 7) * ((rounds_ + 7) / 8)) % rounds_;
+    if (IDSP_LDS_ORDER == 2) rr_ = (k_ + (blockIdx.x >> 5) * ((rounds_ + 7) / 8)) % rounds_;
+    if (IDSP_LDS_ORDER == 3) rr_ = (k_ + (blockIdx.x >= gridDim.x / 2 ? rounds_ / 2 : 0)) % rounds_;
+    if (IDSP_LDS_ORDER == 4) rr_ = (blockIdx.x & 1) ? rounds_ - 1 - k_ : k_;
+    const size_t blk = blockIdx.x + rr_ * gridDim.x;
+    if (blk >= nblocks) continue;
+#endif
     const size_t lane0 = blk * kBlockLanes;
     const size_t avail = lanes - lane0;  // lanes of this block that exist (>= 4)
     const bool ragged_block = LPT == 1 && OW == 1 && avail < size_t(kFmBlock);

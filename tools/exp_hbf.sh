@@ -5,7 +5,7 @@
 # through gpurun:  bash tools/exp_hbf.sh build ; gpurun -- 'bash tools/exp_hbf.sh run'
 set -u
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
-VARIANTS="CH2048:-DIDSP_HBF_CH=2048 CH512:-DIDSP_HBF_CH=512 NOSTAGES:-DIDSP_EXP_HBF_NOSTAGES NOLOAD:-DIDSP_EXP_HBF_NOLOAD SKIP0:-DIDSP_EXP_HBF_SKIP=1 SKIP1:-DIDSP_EXP_HBF_SKIP=2 SKIP2:-DIDSP_EXP_HBF_SKIP=4 SKIP3:-DIDSP_EXP_HBF_SKIP=8 SKIP123:-DIDSP_EXP_HBF_SKIP=14"
+VARIANTS=${VARIANTS:-"CH2048:-DIDSP_HBF_CH=2048 CH512:-DIDSP_HBF_CH=512 NOSTAGES:-DIDSP_EXP_HBF_NOSTAGES NOLOAD:-DIDSP_EXP_HBF_NOLOAD SKIP0:-DIDSP_EXP_HBF_SKIP=1 SKIP1:-DIDSP_EXP_HBF_SKIP=2 SKIP2:-DIDSP_EXP_HBF_SKIP=4 SKIP3:-DIDSP_EXP_HBF_SKIP=8 SKIP123:-DIDSP_EXP_HBF_SKIP=14"}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero -fwrapv -Wall -Wno-unused-function -Iinclude"
 if [ "${1:-run}" = build ]; then
   mkdir -p build/exp_hbf
