@@ -150,7 +150,7 @@ constexpr int kFmBlock = 256;  // 4 waves: one per SIMD of a CU, 1 KiB row segme
 template <class P, int U>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const int xcd_contiguous)
 {
     using In = typename P::In;
     using Out = typename P::Out;
@@ -160,7 +160,15 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
         P::fill_shared(ptab, threadIdx.x, int(blockDim.x));
         __syncthreads();
     }
-    const size_t lane = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    // xcd_contiguous (rows that do not start on 64-byte boundaries, see stream_frame_major_lds XCDC): workgroup blockIdx runs
+    // on XCD blockIdx % 8; give XCD j the j-th contiguous eighth of the lane blocks so that the lines two neighbouring blocks
+    // share are fetched and written through one L2
+    size_t wg = blockIdx.x;
+    if (xcd_contiguous) {
+        const size_t q = gridDim.x / 8, r = gridDim.x % 8, j = blockIdx.x % 8;
+        wg = j * q + (j < r ? j : r) + blockIdx.x / 8;
+    }
+    const size_t lane = wg * blockDim.x + threadIdx.x;
     if (lane >= lanes) return;
 
     P p;
@@ -358,7 +366,18 @@ __device__ __forceinline__ void static_for(F &&f)
 // of the output buffer it ranges 0.61-0.78 / 0.62-0.77 (mean 0.68 / 0.67) where the persistent one-lane form ranges
 // 0.69-0.75 / 0.65-0.69 (mean 0.72 / 0.68) — profiles/r02_exp_c5_place.jsonl, tools/exp_c5_place.hip.  The template
 // parameter stays for those tools and for IDSP_DIAG=1 IDSP_LDS_LPT experiments on processors that opt in.
-template <class P, int NB = LdsRingOf<P>::value, int LPT = 1, bool RUN = LdsRunOf<P>::value>
+// XCDC (round 3): rows that do not start on 64-byte boundaries — dense rows of 65000 or 65532 lanes, odd pitches.  The 1 KiB
+// row segments of adjacent lane blocks then share the 64-byte pieces at their boundaries, and with consecutive blocks dealt
+// round-robin to the 8 XCDs (each with its own L2) both halves of every shared piece are fetched — and partially written —
+// through two different L2s: 0.58-0.64 of the HBM peak against 0.77 on aligned rows (tools/exp_fm_pitch.py: same lanes, same
+// kernel, pitch 65536 + {4, 8, 16, 32} lanes -> 0.59 / 0.64 / 0.76 / 0.75).  XCDC gives every XCD a CONTIGUOUS eighth of the
+// lane blocks, so that neighbours meet in one L2: 65000 dense lanes 0.62 -> 0.71, pitch 65540 0.59 -> 0.67, aligned rows
+// 0.78 -> 0.77 (tools/exp_fm_misaligned.hip, profiles/r03_exp_fm_misaligned.jsonl) — used for misaligned rows only.
+// Built, bit-exact and removed again: rotating the piece -> thread assignment per row so that every 16-lane quad of a
+// `dwordx4` request starts on a 64-byte boundary (the LDS-DMA destination is fixed by the hardware lane, so the row sits
+// rotated in LDS and the owning thread reads its column through the rotation) ran at 0.56 on EVERY pitch, aligned ones
+// included: the straddling quads were not the cost.
+template <class P, int NB = LdsRingOf<P>::value, int LPT = 1, bool RUN = LdsRunOf<P>::value, bool XCDC = false>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
@@ -425,7 +444,11 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     if (IDSP_LDS_ORDER == 2) rr_ = (k_ + (blockIdx.x >> 5) * ((rounds_ + 7) / 8)) % rounds_;
     if (IDSP_LDS_ORDER == 3) rr_ = (k_ + (blockIdx.x >= gridDim.x / 2 ? rounds_ / 2 : 0)) % rounds_;
     if (IDSP_LDS_ORDER == 4) rr_ = (blockIdx.x & 1) ? rounds_ - 1 - k_ : k_;
-    const size_t blk = blockIdx.x + rr_ * gridDim.x;
+    // XCDC: workgroups are dealt to the XCDs round-robin (blockIdx % 8); give XCD j the j-th contiguous eighth of the blocks
+    // (XCD j hosts the workgroups blockIdx = j, j + 8, ...: grid / 8 of them, one more on the first grid % 8 XCDs)
+    const size_t q_ = gridDim.x / 8, r_ = gridDim.x % 8, j_ = blockIdx.x % 8;
+    const size_t wg_ = XCDC ? j_ * q_ + (j_ < r_ ? j_ : r_) + blockIdx.x / 8 : blockIdx.x;
+    const size_t blk = wg_ + rr_ * gridDim.x;
     if (blk >= nblocks) continue;
 #endif
     const size_t lane0 = blk * kBlockLanes;
@@ -1285,6 +1308,20 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 if constexpr (kMaxLpt >= 2) {
                     if (lpt == 2) go(std::integral_constant<int, 2>{}, No{});
                 }
+                // rows that do not start on 64-byte boundaries (dense 65000-lane tensors, odd pitches): adjacent lane blocks on one XCD
+                // (IDSP_DIAG=1 IDSP_LDS_NO_XCDC=1: the plain block order, 0.58-0.64 of the peak on such rows instead of 0.67-0.71)
+                static const bool no_rot = diag_env("IDSP_LDS_NO_XCDC") != nullptr;
+                const bool misaligned = (xl * 4) % 64 != 0 || (yl * ow * 4) % 64 != 0 || reinterpret_cast<uintptr_t>(x) % 64 != 0 || reinterpret_cast<uintptr_t>(y) % 64 != 0;
+                {
+                    if (lpt == 1 && misaligned && !no_rot) {
+                        constexpr size_t bytes = (size_t(7) * kLdsT * kFmBlock + 2 * kLdsT * kFmBlock * ow + P::LDS_WORDS) * 4;
+                        if (int e = ensure_dyn_lds<&stream_frame_major_lds<P, 7, 1, false, true>>(bytes)) return e;
+                        note_kernel("stream_frame_major_lds[XCD-contiguous blocks]", typeid(P).name());
+                        hipLaunchKernelGGL((stream_frame_major_lds<P, 7, 1, false, true>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s, prm, st, x, y,
+                                           lanes, frames, xl, yl);
+                        return launch_status();
+                    }
+                }
                 if (lpt == 1) {
                     if (persistent && LdsRingOf<P>::value != 7)
                         go(std::integral_constant<int, 1>{}, Yes{});
@@ -1300,11 +1337,16 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         const unsigned block = waves < 1024 ? unsigned(kWave) : unsigned(kFmBlock);
         const unsigned grid = unsigned((lanes + block - 1) / block);
         constexpr int kDeep = MaxU<P>::value, kShallow = kDeep < 8 ? kDeep : 8;
-        note_kernel("stream_frame_major", typeid(P).name());
+        // XCD-contiguous lane blocks for rows off the 64-byte grid: what helps the LDS-DMA kernel HURTS this one — 65537 dense lanes
+        // 0.81 ms against 0.69 with the plain order (profiles/r03_perf_ragged_xcdc.jsonl) — so it is a diagnostic switch only
+        // (IDSP_DIAG=1 IDSP_FM_XCDC=1)
+        static const bool want_xcdc = diag_env("IDSP_FM_XCDC") != nullptr;
+        const int xcdc = want_xcdc && grid >= 64;
+        note_kernel(xcdc ? "stream_frame_major[XCD-contiguous blocks]" : "stream_frame_major", typeid(P).name());
         if (waves <= 2048)
-            hipLaunchKernelGGL((stream_frame_major<P, kDeep>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl);
+            hipLaunchKernelGGL((stream_frame_major<P, kDeep>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl, xcdc);
         else
-            hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl);
+            hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl, xcdc);
     }
     return launch_status();
 }

@@ -1,7 +1,8 @@
 """FRAME_MAJOR lane counts that are not multiples of 256 on the LDS-DMA kernel (`stream_frame_major_lds`,
 idsp_amd/csrc/lane_stream.h): the kernel's last 256-lane block may be ragged when the lane count is a multiple of 4
 (whole 16-byte pieces) — threads whose piece lies beyond the last lane re-request and re-store an in-range thread's
-piece.  The reference takes any N in `Lanes<C>` (dsp-process/src/compose.rs:468); round 2 dropped such shapes to the
+piece; rows that do not start on 64-byte boundaries (what dense rows of such lane counts are) take the form of the kernel
+that gives every XCD a contiguous eighth of the lane blocks.  The reference takes any N in `Lanes<C>` (dsp-process/src/compose.rs:468); round 2 dropped such shapes to the
 register-window kernel.  Against the oracle bit for bit (outputs and state), out of place and in place, dense rows and a
 lane block of a wider tensor whose neighbouring lanes must stay untouched; the kernel taken is asserted through
 `idsp_last_kernel()`.  Lane counts that are not multiples of 4 (rows without 16-byte alignment) keep the other kernels."""
@@ -34,14 +35,18 @@ def test_default_dispatch_takes_the_lds_kernel_on_ragged_lane_counts(gpu):
     rng = np.random.default_rng(301)
     cs = lds_cases(rng)
     # (lanes, frames, pitch, lane offset)
-    shapes = [(65000, 19, 65000, 0), (49156, 70, 49156, 0), (65532, 9, 65536, 4), (100000, 33, 100000, 0), (65000, 130, 65540, 260)]
+    shapes = [(65000, 19, 65000, 0), (49156, 70, 49156, 0), (65532, 9, 65536, 4), (100000, 33, 100000, 0), (65000, 130, 65540, 260), (65000, 20, 65024, 0),
+              (65536, 41, 65544, 0)]
     for i, (lanes, frames, pitch, off) in enumerate(shapes):
         for j, (op, cfg, n, words, dt) in enumerate(cs):
             if (i + j) % 3 and lanes > 65000:
                 continue  # the big shapes on a third of the entries
             inplace = bool((i + j) & 1)
             FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, inplace, off=off)
-            assert kernel_of(gpu).startswith("stream_frame_major_lds<"), (op, lanes, kernel_of(gpu))
+            k = kernel_of(gpu)
+            # rows off the 64-byte grid (dense 65000 / 100000 lanes, a base 16 bytes into a row) take the XCD-contiguous block order
+            aligned = (pitch * 4) % 64 == 0 and (off * 4) % 64 == 0
+            assert k.startswith("stream_frame_major_lds<" if aligned else "stream_frame_major_lds[XCD-contiguous blocks]<"), (op, lanes, pitch, off, k)
 
 
 def test_lane_counts_that_are_not_multiples_of_four_keep_the_register_window_kernel(gpu):
@@ -61,6 +66,7 @@ def test_small_ragged_shapes_inner(gpu):
     rng = np.random.default_rng(303)
     cs = lds_cases(rng)
     tails = [4, 8, 60, 64, 68, 128, 200, 252]
+    seen = set()
     for k, tail in enumerate(tails):
         for blocks in (0, 1, 5):
             lanes = blocks * 256 + tail
@@ -71,7 +77,9 @@ def test_small_ragged_shapes_inner(gpu):
                 pad = int(rng.choice([0, 4, 64]))
                 off = int(rng.choice([0, 4]))
                 FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, lanes + pad + off, bool((j + k + blocks) & 1), off=off)
-                assert kernel_of(gpu).startswith("stream_frame_major_lds<"), (op, lanes, kernel_of(gpu))
+                assert kernel_of(gpu).startswith("stream_frame_major_lds"), (op, lanes, kernel_of(gpu))
+                seen.add(kernel_of(gpu).split("<")[0])
+    assert seen == {"stream_frame_major_lds", "stream_frame_major_lds[XCD-contiguous blocks]"}, seen
 
 
 @pytest.mark.parametrize("grid", ["0", "3"])

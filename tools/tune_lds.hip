@@ -57,7 +57,7 @@ float run_regwin(const typename P::Params &prm, uint32_t *st, const typename P::
     std::vector<float> ts;
     for (int i = 0; i < 50; i++) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((stream_frame_major<P, U>), dim3(kLanes / kFmBlock), dim3(kFmBlock), 0, 0, prm, st, x, y, kLanes, kFrames, kLanes, kLanes);
+        hipLaunchKernelGGL((stream_frame_major<P, U>), dim3(kLanes / kFmBlock), dim3(kFmBlock), 0, 0, prm, st, x, y, kLanes, kFrames, kLanes, kLanes, 0);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;
