@@ -25,10 +25,11 @@ and, outside the timed region, the 8-byte output-checksum all-reduce of SURVEY.m
 
 Timing: W untimed warm-up steps, then further untimed steps until --settle-ms of wall time have passed
 (the first launches after an idle gap run at a lower clock), then EXACTLY K timed steps between barrier +
-synchronize pairs; `value` comes from that wall-clock interval (max over ranks).  Every timed step is also
-bracketed by HIP events on the launch stream: `roofline` prices the MEDIAN of those kernel durations
-against HBM (8 B of algorithmic traffic per sample + the state planes once each way), and reports the
-minimum and the mean beside it.  x and y are two plain, separate allocations.
+synchronize pairs; `value` comes from that wall-clock interval (max over ranks).  The K launches are also
+bracketed by ONE pair of HIP events on the launch stream: `roofline` prices that interval / K — the average
+launch duration over the timed region — against HBM (8 B of algorithmic traffic per sample + the state
+planes once each way); per-launch median / min come from further launches with their own event pairs,
+after the timed region.  x and y are two plain, separate allocations.
 
 Integrity (`integrity`): after the timed region every rank zeroes its state, runs ONE more step and sums
 the 32-bit words of its output and of its written-back state (wrapping 64-bit sums).  The y sums meet in
@@ -269,14 +270,27 @@ class HipEngine:
         self.torch.cuda.synchronize()
 
     def timed_steps(self, k: int):
-        """k launches, each between two HIP events recorded on the launch stream itself; returns a
-        function that yields the k kernel durations in ms once the stream has been synchronised."""
+        """The timed region: k back-to-back launches between ONE pair of HIP events recorded on the launch stream itself;
+        returns a function that yields [average ms per launch] once the stream has been synchronised.  (Round 2 recorded an
+        event pair around EVERY launch inside the timed region: the records cost 2.5-3.4 % of the step —
+        tools/exp_bench_gap.py: 0.3555 ms per step with them, 0.3458 without, kernel median 0.3457 — so `value` read lower
+        than the engine's back-to-back rate.  The per-launch figures now come from probe_steps(), outside the timed region.)"""
+        a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        a.record(self.stream)
+        for _ in range(k):
+            self.step()
+        b.record(self.stream)
+        return lambda: [a.elapsed_time(b) / max(k, 1)]
+
+    def probe_steps(self, k: int):
+        """k further launches (untimed), each between its own event pair: per-launch durations in ms."""
         ev = [(self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)) for _ in range(k)]
         for a, b in ev:
             a.record(self.stream)
             self.step()
             b.record(self.stream)
-        return lambda: [a.elapsed_time(b) for a, b in ev]
+        self.sync()
+        return [a.elapsed_time(b) for a, b in ev]
 
     def verify(self, sample_lanes: int = 0):
         """Zero the state, run one step, return [sum of y's words, sum of the state words] as wrapping i64 —
@@ -499,9 +513,9 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": kernel, "kernel_ms": round(med, 4), "kernel_ms_min": round(min(kern_ms), 4) if kern_ms else None,
-            "kernel_ms_mean": round(sum(kern_ms) / len(kern_ms), 4) if kern_ms else None,
-            "kernel_ms_stat": "median of the per-step HIP-event durations (rank 0)", "algorithmic_bytes": alg_bytes,
+            "kernel": kernel, "kernel_ms": round(med, 4),
+            "kernel_ms_stat": "average launch duration: one HIP-event pair on the launch stream around the K timed launches, / K (rank 0)",
+            "algorithmic_bytes": alg_bytes,
         },
     }
 
@@ -565,11 +579,12 @@ def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend
     engine = engine_factory(cfg_name, cfg, lane_lo, lanes_rank, frames, args.layout, rank, local)
     rdev = engine.reduce_device(backend)
     elapsed, kern_ms, untimed = run_timed(engine, steps, warmup, settle_ms, dist)
+    per_launch = engine.probe_steps(min(steps, 50)) if hasattr(engine, "probe_steps") else list(kern_ms)  # outside the timed region
     t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     if dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
-    med_us = int(round(statistics.median(kern_ms) * 1e3)) if kern_ms else 0
+    med_us = int(round(statistics.median(per_launch) * 1e3)) if per_launch else 0
     sample = C5_CPU_LANES if cfg_name == "c5" and world == 1 and lanes_rank > C5_CPU_LANES else 0
     sums = engine.verify(sample)
     y_sum_all = allreduce_checksum(sums[0], device=rdev)  # the 8-byte checksum all-reduce
@@ -579,6 +594,9 @@ def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend
     a = argparse.Namespace(**{**vars(args), "steps": steps, "warmup": warmup, "settle_ms": settle_ms,
                               "lanes": lanes_override, "frames": frames_override})
     line = report(cfg_name, cfg, a, world, lanes_rank, frames, elapsed_max, kern_ms, untimed, engine.kernel_name(), total_lanes)
+    if per_launch:
+        line["roofline"]["per_launch_ms"] = {"median": round(statistics.median(per_launch), 4), "min": round(min(per_launch), 4),
+                                             "launches": len(per_launch), "note": "separate event pair per launch, after the timed region"}
     overridden = bool(lanes_override or frames_override)
     exp = [expected_for(cfg_name, args.layout, r, pr[3], pr[4], overridden) for r, pr in enumerate(per_rank)]
     match = [None if e is None else (e[0] == pr[0] and e[1] == pr[1]) for e, pr in zip(exp, per_rank)]
