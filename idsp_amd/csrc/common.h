@@ -39,6 +39,39 @@ inline const char *diag_env(const char *name)
     return on ? getenv(name) : nullptr;
 }
 
+// true when IDSP_DIAG=1: dispatch may be overridden from the environment (then nothing assumes which kernel a shape takes)
+inline bool diag_on() { return diag_env("IDSP_DIAG") != nullptr; }
+
+// A second stream per (thread, device) with the two events that fork it off the caller's stream and join it back: a launch
+// can put an independent piece of a call beside the main kernel (lane_stream.h: the lanes beyond the last whole round of
+// workgroups).  Created on first use, kept for the life of the thread; NULL if the runtime refuses.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+inline SideStream *side_stream()
+{
+    constexpr int kMaxDev = 64;
+    static thread_local SideStream table[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    SideStream &e = table[dev];
+    if (!e.stream) {
+        hipStream_t s = nullptr;
+        hipEvent_t f = nullptr, j = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        // both streams are on ONE device: no system-scope fence at the event (it costs the back-to-back launch overlap)
+        constexpr unsigned kFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+        if (hipEventCreateWithFlags(&f, kFlags) != hipSuccess || hipEventCreateWithFlags(&j, kFlags) != hipSuccess) {
+            if (f) (void)hipEventDestroy(f);
+            (void)hipStreamDestroy(s);
+            return nullptr;
+        }
+        e.stream = s, e.fork = f, e.join = j;
+    }
+    return &e;
+}
+
 // Name of the kernel the most recent launch on this thread dispatched to (idsp_last_kernel()).
 void note_kernel(const char *kernel, const char *detail = nullptr);
 

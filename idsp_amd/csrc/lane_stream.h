@@ -380,8 +380,10 @@ __device__ __forceinline__ void static_for(F &&f)
 template <class P, int NB = LdsRingOf<P>::value, int LPT = 1, bool RUN = LdsRunOf<P>::value, bool XCDC = false>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes)
 {
+    // slanes: pitch of the state (and per-lane coefficient) planes, in lanes — `lanes` unless this launch is a lane block of
+    // a larger call (launch_stream splits a call into whole rounds here + a remainder on the staged kernel)
     using In = typename P::In;
     using Out = typename P::Out;
     static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4, "LDS path: one 4-byte input per lane and frame");
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const int lid4 = ragged_block && size_t(lid * 4) >= avail ? int(size_t(lid * 4) % avail) : lid * 4;  // first lane of this thread's piece
     const bool lane_ok = !ragged_block || size_t(tid) < avail;
 #pragma unroll
-    for (int s = 0; s < LPT; s++) p[s].load(prm, st, lanes, lane_ok ? lane0 + size_t(s) * kFmBlock + tid : lanes - 1);
+    for (int s = 0; s < LPT; s++) p[s].load(prm, st, slanes, lane_ok ? lane0 + size_t(s) * kFmBlock + tid : lanes - 1);
     // The state loads must have landed HERE, in a way the compiler's wait-count pass sees: it cannot see the DMA
     // requests of glds16(), and if it first needs a state register inside the steady-state loop it protects that use
     // with `s_waitcnt vmcnt(0)` on every iteration — which drains the whole prefetch ring each tile (0.52 instead of
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     for (; i < ntiles; i++) slow_iter();
 #pragma unroll
     for (int s = 0; s < LPT; s++)
-        if (lane_ok) p[s].store(prm, st, lanes, lane0 + size_t(s) * kFmBlock + tid);
+        if (lane_ok) p[s].store(prm, st, slanes, lane0 + size_t(s) * kFmBlock + tid);
     // No barrier needed here: the next block's first lds_barrier() (after each wave's lgkmcnt wait) orders this
     // block's last output-tile reads before the compute() that overwrites the tile, and its first DMA rows only
     // touch input slots whose last readers passed the barrier after the final compute().
@@ -989,7 +991,7 @@ struct FmStagedOf<P, std::enable_if_t<P::HAS_IN && P::IN_DIV == 1 && sizeof(type
 template <class P, int LW>
 __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes)
 {
     using In = typename P::In;
     using Out = typename P::Out;
@@ -1020,7 +1022,7 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
         lds_wave_sync();
         p.set_shared(ptab);
     }
-    if (active) p.load(prm, st, lanes, lane0 + lid);
+    if (active) p.load(prm, st, slanes, lane0 + lid);
 
     // mover role: in instruction j, row j RPI + mrow of the tile, piece mpc of the row piece; addresses = wave-uniform base
     // (SGPRs, see uniform_ptr) + 32-bit thread offset
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
         lds_wave_sync();
         store(nfull, Part{}, ntail);
     }
-    if (active) p.store(prm, st, lanes, lane0 + lid);
+    if (active) p.store(prm, st, slanes, lane0 + lid);
 }
 
 // --------------------------------------------------------------------- launch
@@ -1143,13 +1145,32 @@ struct Pitch {
     size_t x = 0, y = 0;
 };
 
+// Parameters of a lane block that starts `first` lanes into the call: per-lane coefficient planes (ByLaneParams::coef) move
+// with the lanes, everything else is shared
+template <class T, class = void>
+struct HasCoefPlanes : std::false_type {};
+template <class T>
+struct HasCoefPlanes<T, std::void_t<decltype(std::declval<T>().coef)>> : std::true_type {};
+template <class Params>
+inline Params shift_lanes(Params p, size_t first, size_t elem)
+{
+    if constexpr (HasCoefPlanes<Params>::value) p.coef = static_cast<const char *>(p.coef) + first * elem;
+    return p;
+}
+
+// Largest remainder (in lanes) that launch_stream runs beside the whole rounds on a second stream (tools/exp_split_streams.py:
+// 73728 lanes 0.58 -> 0.69 of the HBM peak with an 8192-lane remainder, 81920 0.59 -> 0.63 with 16384, no gain from 24576 up)
+constexpr size_t kSplitTailMax = 20480;
+
 template <class P>
 int launch_stream(const typename P::Params &prm, void *state, const typename P::In *x,
-                  typename P::Out *y, size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch = {})
+                  typename P::Out *y, size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch = {}, size_t state_pitch = 0)
 {
     if (lanes == 0) return IDSP_OK;
     uint32_t *st = static_cast<uint32_t *>(state);
+    const size_t sp = state_pitch ? state_pitch : lanes;  // lanes between the state planes (a lane block of a larger call keeps the call's)
     if (layout == IDSP_LANE_MAJOR) {
+        if (sp != lanes) return fail(IDSP_EINVAL, "internal: lane block with a state pitch on a LaneMajor kernel");
         const size_t xl = pitch.x ? pitch.x : frames, yl = pitch.y ? pitch.y : frames;
         const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
         if constexpr (LmStagedOf<P>::value) {
@@ -1200,6 +1221,33 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
     } else {
         const size_t xl = pitch.x ? pitch.x : lanes / P::IN_DIV, yl = pitch.y ? pitch.y : lanes;
         const size_t waves = (lanes + kWave - 1) / kWave;
+        // Whole rounds + remainder (round 3).  The LDS-DMA kernel runs one 256-lane block per CU and round; 65540 lanes are 257
+        // blocks — one CU with two workgroups, both at half speed — and 73728 lanes 288: 0.58 of the HBM peak where 65536 run at
+        // 0.78.  The lanes beyond the last whole round of 256 blocks therefore run BESIDE the whole rounds, on a second stream,
+        // on the staged single-wave kernel (its waves spread over all CUs and fit next to the LDS-DMA workgroups): 69632 lanes
+        // 0.57 -> 0.65, 73728 0.58 -> 0.69, 81920 0.59 -> 0.63, 147456 0.59 -> 0.65; no gain from a 24576-lane remainder up
+        // (tools/exp_split_streams.py, profiles/r03_exp_split_streams.jsonl).  Both pieces are lane blocks of the caller's
+        // tensors (row pitches xl / yl, state and coefficient planes at the call's pitch).
+        if constexpr (FmStagedOf<P>::value && P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4 && P::COST <= 120) {
+            const size_t head = lanes / (size_t(256) * kFmBlock) * (size_t(256) * kFmBlock), tail = lanes - head;
+            if (sp == lanes && head && tail && tail <= kSplitTailMax && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() &&
+                reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && yl % 4 == 0 &&
+                xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
+                if (SideStream *ss = side_stream()) {
+                    IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
+                    IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
+                    int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, lanes);
+                    if (rc == IDSP_OK)
+                        rc = launch_stream<P>(shift_lanes(prm, head, sizeof(typename P::In)), st + head, x + head, y + head, tail, frames, layout, ss->stream,
+                                              Pitch{xl, yl}, lanes);
+                    // join even after a failed launch: the caller's stream must not run ahead of whatever the side stream holds
+                    IDSP_HIP_TRY(hipEventRecord(ss->join, ss->stream));
+                    IDSP_HIP_TRY(hipStreamWaitEvent(s, ss->join, 0));
+                    if (rc == IDSP_OK) note_kernel("stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)", typeid(P).name());
+                    return rc;
+                }
+            }
+        }
         if constexpr (FmStagedOf<P>::value) {
             // Few lanes (the chip is not full and every FrameMajor kernel below runs at its per-lane latency): the staged
             // single-wave kernel.  Measured against the register-window and the LDS-DMA kernel (tools/tune_fm_small.hip,
@@ -1225,7 +1273,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     note_kernel(LW == 64 ? "stream_frame_major_staged[64 lanes/wave]" : LW == 32 ? "stream_frame_major_staged[32 lanes/wave]" : "stream_frame_major_staged[16 lanes/wave]",
                                 typeid(P).name());
                     hipLaunchKernelGGL((stream_frame_major_staged<P, LW>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
-                                       lanes, frames, xl, yl);
+                                       lanes, frames, xl, yl, sp);
                     return launch_status();
                 };
                 if constexpr (!heavy) {
@@ -1298,7 +1346,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     note_kernel(L == 1 ? "stream_frame_major_lds" : L == 2 ? "stream_frame_major_lds[2 lanes/thread]" : "stream_frame_major_lds[4 lanes/thread]",
                                 typeid(P).name());
                     hipLaunchKernelGGL((stream_frame_major_lds<P, NB, L, RUN>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s,
-                                       prm, st, x, y, lanes, frames, xl, yl);
+                                       prm, st, x, y, lanes, frames, xl, yl, sp);
                 };
                 using Yes = std::true_type;
                 using No = std::false_type;
@@ -1318,7 +1366,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                         if (int e = ensure_dyn_lds<&stream_frame_major_lds<P, 7, 1, false, true>>(bytes)) return e;
                         note_kernel("stream_frame_major_lds[XCD-contiguous blocks]", typeid(P).name());
                         hipLaunchKernelGGL((stream_frame_major_lds<P, 7, 1, false, true>), dim3(unsigned(grid)), dim3(kFmBlock), bytes, s, prm, st, x, y,
-                                           lanes, frames, xl, yl);
+                                           lanes, frames, xl, yl, sp);
                         return launch_status();
                     }
                 }
@@ -1332,6 +1380,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 return launch_status();
             }
         }
+        if (sp != lanes) return fail(IDSP_EINVAL, "internal: lane block with a state pitch on the register-window kernel");
         // A CU's L1 moves ~10 B/cycle, so a launch must reach all 256 CUs: below 1024 waves (= 256
         // workgroups of 4) use one wave per workgroup (16384 lanes in 256-thread blocks would run on 64 CUs).
         const unsigned block = waves < 1024 ? unsigned(kWave) : unsigned(kFmBlock);

@@ -42,7 +42,7 @@ float run(const P::Params &prm, uint32_t *st, const int32_t *x, int32_t *y, size
     std::vector<float> ts;
     for (int i = 0; i < iters + 40; i++) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, LPT, EXP_RUN>), dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, pitch, pitch);
+        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, LPT, EXP_RUN>), dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, pitch, pitch, lanes);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;

@@ -28,7 +28,7 @@ float run(const P::Params &prm, uint32_t *st, const float *x, float *y, size_t l
     std::vector<float> ts;
     for (int i = 0; i < 14; i++) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, 1, false>), dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, lanes, lanes);
+        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, 1, false>), dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, lanes, lanes, lanes);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;

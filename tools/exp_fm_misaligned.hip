@@ -32,7 +32,7 @@ float run(const P::Params &prm, uint32_t *st, const int32_t *x, int32_t *y, size
     std::vector<float> ts;
     for (int i = 0; i < 40; i++) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, pitch, pitch);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kFmBlock), bytes, 0, prm, st, x, y, lanes, frames, pitch, pitch, lanes);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;

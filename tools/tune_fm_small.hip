@@ -51,7 +51,7 @@ void one(const char *name, const typename P::Params &prm, const Bufs &b, const S
     char *yy = b.y;
     auto launch = [&]() {
         hipLaunchKernelGGL((stream_frame_major_staged<P, LW>), dim3(grid), dim3(kWave), bytes, 0, prm, b.st, reinterpret_cast<const In *>(inplace ? yy : b.x),
-                           reinterpret_cast<Out *>(yy), sh.lanes, sh.frames, sh.pitch, sh.pitch, 0);
+                           reinterpret_cast<Out *>(yy), sh.lanes, sh.frames, sh.pitch, sh.pitch, sh.lanes);
     };
     CK(hipMemset(b.st, 0, sh.lanes * 256));
     if (inplace) CK(hipMemcpy(yy, b.x, n, hipMemcpyDeviceToDevice)); else CK(hipMemset(yy, 0xEE, n));
@@ -95,7 +95,7 @@ void sweep(const char *name, const typename P::Params &prm, const Bufs &b, const
                 CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_lds<P, NB, 1, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
                 auto lds = [&]() {
                     hipLaunchKernelGGL((stream_frame_major_lds<P, NB, 1, RUN>), dim3(unsigned(sh.lanes / kFmBlock)), dim3(kFmBlock), bytes, 0, prm, b.stref,
-                                       reinterpret_cast<const In *>(b.x), reinterpret_cast<Out *>(b.yref), sh.lanes, sh.frames, sh.pitch, sh.pitch, 0);
+                                       reinterpret_cast<const In *>(b.x), reinterpret_cast<Out *>(b.yref), sh.lanes, sh.frames, sh.pitch, sh.pitch, sh.lanes);
                 };
                 tlds = timeit(lds);
             }

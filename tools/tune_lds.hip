@@ -35,7 +35,7 @@ float run1(const typename P::Params &prm, uint32_t *st, const typename P::In *x,
     std::vector<float> ts;
     for (int i = 0; i < 50; i++) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, 1, RUN>), dim3(kLanes / kFmBlock), dim3(kFmBlock), bytes, 0, prm, st, x, y, kLanes, kFrames, kLanes, kLanes);
+        hipLaunchKernelGGL((stream_frame_major_lds<P, NB, 1, RUN>), dim3(kLanes / kFmBlock), dim3(kFmBlock), bytes, 0, prm, st, x, y, kLanes, kFrames, kLanes, kLanes, kLanes);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;
