@@ -590,7 +590,24 @@ int run_chain_n(CfgFill fill, size_t first, void *state, const typename Sec::T *
     return launch_stream<Chain<Sec, N>>(prm, st, x, y, lanes, frames, layout, s, pitch);
 }
 
-// n sections in passes of <= kMaxChain: the first pass reads x, later passes
+// Sections first .. first + NA + NB - 1 on the two-wave kernel: wave 0 runs Chain<Sec, NA>, wave 1 Chain<Sec, NB> one tile behind
+template <class Sec, int NA, int NB, class CfgFill>
+int run_chain_duo(CfgFill fill, size_t first, void *state, const typename Sec::T *x, typename Sec::T *y, size_t lanes, size_t frames,
+                  hipStream_t s, Pitch pitch)
+{
+    typename Chain<Sec, NA>::Params pa;
+    typename Chain<Sec, NB>::Params pb;
+    for (int k = 0; k < NA; k++) fill(pa.sec[k], first + k);
+    for (int k = 0; k < NB; k++) fill(pb.sec[k], first + NA + k);
+    uint32_t *st = static_cast<uint32_t *>(state) + first * Sec::W * lanes;
+    return launch_duo<Chain<Sec, NA>, Chain<Sec, NB>>(pa, pb, st, st + size_t(NA) * Sec::W * lanes, x, y, lanes, frames, s, pitch);
+}
+// section types that have the two-wave instantiations (4-byte samples)
+template <class Sec>
+struct DuoSec : std::integral_constant<bool, sizeof(typename Sec::T) == 4> {};
+constexpr int kMaxChainDuo = 8;
+
+// n sections in passes of <= kMaxChain (<= kMaxChainDuo on the two-wave kernel): the first pass reads x, later passes
 // run in place on y — literally the reference's slice composition.
 template <class Sec, class CfgFill>
 int run_chain(CfgFill fill, size_t n, void *state, const typename Sec::T *x, typename Sec::T *y,
@@ -602,6 +619,25 @@ int run_chain(CfgFill fill, size_t n, void *state, const typename Sec::T *x, typ
     size_t done = 0;
     const T *src = x;
     while (done < n) {
+        if constexpr (DuoSec<Sec>::value) {
+            const size_t md = n - done < size_t(kMaxChainDuo) ? n - done : size_t(kMaxChainDuo);
+            // (four sections: +9 % for plain i32 DF1, +20 % for the f32 forms, -1 % / -5 % for the clamp / wide forms, which stay)
+            if (duo_wanted(md, lanes, layout) && (md >= 5 || (!Sec::kClamp && Sec::W <= 4))) {
+                int rc;
+                switch (md) {
+                    case 4: rc = run_chain_duo<Sec, 2, 2>(fill, done, state, src, y, lanes, frames, s, pitch); break;
+                    case 5: rc = run_chain_duo<Sec, 3, 2>(fill, done, state, src, y, lanes, frames, s, pitch); break;
+                    case 6: rc = run_chain_duo<Sec, 3, 3>(fill, done, state, src, y, lanes, frames, s, pitch); break;
+                    case 7: rc = run_chain_duo<Sec, 4, 3>(fill, done, state, src, y, lanes, frames, s, pitch); break;
+                    default: rc = run_chain_duo<Sec, 4, 4>(fill, done, state, src, y, lanes, frames, s, pitch); break;
+                }
+                if (rc) return rc;
+                done += md;
+                src = y;
+                pitch.x = pitch.y;
+                continue;
+            }
+        }
         const size_t m = n - done < size_t(kMaxChain) ? n - done : size_t(kMaxChain);
         int rc;
         switch (m) {
@@ -671,6 +707,20 @@ int run_cascade_n(CfgFill fill, void *state, const T *x, T *y, size_t lanes, siz
     return launch_stream<CascadeDf1<T, N>>(prm, state, x, y, lanes, frames, layout, s, pitch);
 }
 
+// `Cascade` of NA + NB sections on the two-wave kernel.  Section k's input history is section k - 1's output history, so wave 1 is
+// the same processor type started 2 NA values into the state record: its "x history" is y[NA - 1]'s, which it keeps up to date
+// from the samples wave 0 hands over (both waves write that pair back: the same values).
+template <class T, int NA, int NB, class CfgFill>
+int run_cascade_duo(CfgFill fill, void *state, const T *x, T *y, size_t lanes, size_t frames, hipStream_t s, Pitch pitch)
+{
+    typename CascadeDf1<T, NA>::Params pa;
+    typename CascadeDf1<T, NB>::Params pb;
+    for (int k = 0; k < NA; k++) fill(pa.sec[k], size_t(k));
+    for (int k = 0; k < NB; k++) fill(pb.sec[k], size_t(NA + k));
+    uint32_t *st = static_cast<uint32_t *>(state);
+    return launch_duo<CascadeDf1<T, NA>, CascadeDf1<T, NB>>(pa, pb, st, st + size_t(2 * NA) * (sizeof(T) / 4) * lanes, x, y, lanes, frames, s, pitch);
+}
+
 template <class T, class CfgFill>
 int run_cascade(CfgFill fill, size_t n, void *state, const T *x, T *y, size_t lanes, size_t frames, int layout,
                 hipStream_t s, Pitch pitch = {})
@@ -678,6 +728,16 @@ int run_cascade(CfgFill fill, size_t n, void *state, const T *x, T *y, size_t la
     if (int rc = check_pitch(x, y, lanes, frames, layout, pitch)) return rc;
     if (n < 1 || n > size_t(kMaxCascade)) return fail(IDSP_EINVAL, "cascade sections n = %zu not in 1..%d", n, kMaxCascade);
     if (lanes == 0 || frames == 0) return IDSP_OK;
+    if constexpr (sizeof(T) == 4) {
+        if (n >= 5 && duo_wanted(n, lanes, layout)) {  // (4 sections stay on the LDS-DMA kernel: 0.69 against 0.62)
+            switch (n) {
+                case 5: return run_cascade_duo<T, 3, 2>(fill, state, x, y, lanes, frames, s, pitch);
+                case 6: return run_cascade_duo<T, 3, 3>(fill, state, x, y, lanes, frames, s, pitch);
+                case 7: return run_cascade_duo<T, 4, 3>(fill, state, x, y, lanes, frames, s, pitch);
+                default: return run_cascade_duo<T, 4, 4>(fill, state, x, y, lanes, frames, s, pitch);
+            }
+        }
+    }
     switch (n) {
         case 1: return run_cascade_n<T, 1>(fill, state, x, y, lanes, frames, layout, s, pitch);
         case 2: return run_cascade_n<T, 2>(fill, state, x, y, lanes, frames, layout, s, pitch);

@@ -1122,6 +1122,92 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
     if (active) p.store(prm, st, slanes, lane0 + lid);
 }
 
+// ------------------------------------------------------------- FRAME_MAJOR, two waves per 64 lanes
+// A serial chain of sections split over TWO waves (round 3).  A VALU-bound processor at one wave per SIMD — 65536 lanes are
+// 1024 waves — runs at the issue rate of a single wave, and for the i32 sections that is one v_mad_i64_i32 per ~10 cycles
+// where two waves on the SIMD get one per 5 (tools/ubench_valu.hip): a 4-section i32 chain sits at 0.58 of the HBM peak,
+// the 8-section cascade at 0.47, both far from memory-bound.  Here a workgroup of two waves owns 64 lanes: wave 0 runs the
+// first part of the chain (processor PA) on the input and leaves its output in an LDS tile of T frames, wave 1 runs the
+// rest (PB) one tile behind and writes y; one workgroup barrier per tile, tiles double-buffered.  Twice the waves per SIMD
+// and every lane still one thread per wave — and 8 sections are ONE pass over HBM instead of two.  Results are those of
+// the single-wave kernels: both halves run the same per-sample functors on the same sample sequences.
+// In place (y == x): wave 0 reads frame f at least a tile before wave 1 writes it.
+template <class PA, class PB, int T = 32>
+__global__ __launch_bounds__(2 * kWave) void stream_frame_major_duo(
+    const typename PA::Params prmA, const typename PB::Params prmB, uint32_t *stA, uint32_t *stB, const typename PA::In *x,
+    typename PB::Out *y, const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+{
+    using In = typename PA::In;
+    using Mid = typename PA::Out;
+    using Out = typename PB::Out;
+    static_assert(std::is_same<Mid, typename PB::In>::value && PA::LDS_WORDS == 0 && PB::LDS_WORDS == 0 && PA::IN_DIV == 1 && PB::IN_DIV == 1,
+                  "PB continues PA's sample stream; table-free processors");
+    __shared__ Mid tile[2][T][kWave];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave), lid = int(threadIdx.x) % kWave;
+    const size_t lane = size_t(blockIdx.x) * kWave + lid;
+    const bool active = lane < lanes;
+    const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
+    const size_t nfull = frames / T;
+    const int ntail = int(frames - nfull * T);  // frames of the last, partial tile
+    if (wave == 0) {
+        PA p;
+        p.load(prmA, stA, lanes, la);
+        const In *xp = x + la;
+        In cur[T], nxt[T];
+        // whole tiles: no per-frame predicates (wave-uniform runtime tests per frame fragment the loop into hundreds of blocks)
+        auto fetch = [&](size_t k, In (&dst)[T], auto full) __attribute__((always_inline)) {
+#pragma unroll
+            for (int f = 0; f < T; f++)
+                if (decltype(full)::value || f < ntail) dst[f] = nt_load<true>(xp + (k * T + f) * xl);
+        };
+        if (nfull)
+            fetch(0, cur, std::true_type{});
+        else
+            fetch(0, cur, std::false_type{});
+        for (size_t k = 0; k < nfull; k++) {
+            if (k + 1 < nfull)
+                fetch(k + 1, nxt, std::true_type{});
+            else if (ntail)
+                fetch(k + 1, nxt, std::false_type{});
+#pragma unroll
+            for (int f = 0; f < T; f++) tile[k & 1][f][lid] = p.step(prmA, cur[f]);
+#pragma unroll
+            for (int f = 0; f < T; f++) cur[f] = nxt[f];
+            lds_barrier();  // tile k complete; wave 1 has finished tile k - 1 (it may be overwritten two tiles on)
+        }
+        if (ntail) {
+            for (int f = 0; f < ntail; f++) tile[nfull & 1][f][lid] = p.step(prmA, cur[f]);
+            lds_barrier();
+        }
+        lds_barrier();  // pairs with wave 1's last interval
+        if (active) p.store(prmA, stA, lanes, lane);
+    } else {
+        PB p;
+        p.load(prmB, stB, lanes, la);
+        Out *yp = y + la;
+        lds_barrier();  // tile 0
+        for (size_t k = 0; k < nfull; k++) {
+            Mid v[T];
+#pragma unroll
+            for (int f = 0; f < T; f++) v[f] = tile[k & 1][f][lid];
+#pragma unroll
+            for (int f = 0; f < T; f++) {
+                const Out o = p.step(prmB, v[f]);
+                if (active) nt_store<true>(yp + (k * T + f) * yl, o);
+            }
+            lds_barrier();
+        }
+        if (ntail) {
+            for (int f = 0; f < ntail; f++) {
+                const Out o = p.step(prmB, tile[nfull & 1][f][lid]);
+                if (active) nt_store<true>(yp + (nfull * T + f) * yl, o);
+            }
+            lds_barrier();
+        }
+        if (active) p.store(prmB, stB, lanes, lane);
+    }
+}
+
 // --------------------------------------------------------------------- launch
 // Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
 // latency, so go deep; with many resident waves keep the register budget low.
@@ -1398,6 +1484,29 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl, xcdc);
     }
     return launch_status();
+}
+
+// Two-wave launch of a chain split into PA (first sections) and PB (the rest): FRAME_MAJOR only, 4-byte samples
+template <class PA, class PB>
+int launch_duo(const typename PA::Params &pa, const typename PB::Params &pb, uint32_t *stA, uint32_t *stB, const typename PA::In *x,
+               typename PB::Out *y, size_t lanes, size_t frames, hipStream_t s, Pitch pitch)
+{
+    const size_t xl = pitch.x ? pitch.x : lanes, yl = pitch.y ? pitch.y : lanes;
+    note_kernel("stream_frame_major_duo", typeid(PB).name());
+    hipLaunchKernelGGL((stream_frame_major_duo<PA, PB>), dim3(unsigned((lanes + kWave - 1) / kWave)), dim3(2 * kWave), 0, s, pa, pb, stA, stB, x, y, lanes,
+                       frames, xl, yl);
+    return launch_status();
+}
+
+// When a chain of m sections (per launch) goes to the two-wave kernel (IDSP_DIAG=1 IDSP_NO_DUO=1: never).  Measured at 4096 frames
+// (tools/exp_duo.hip, profiles/r03_exp_duo.jsonl): i32 chain of 4 at 65536 lanes 0.483 -> 0.426 ms, at 131072 lanes 0.829 -> 0.909;
+// i32 cascade of 8 at 32768 / 65536 / 131072 lanes 0.583 / 0.661 / 1.250 -> 0.482 / 0.578 / 1.066; and five to eight sections of a
+// plain chain are ONE pass over HBM instead of two.
+inline bool duo_wanted(size_t m, size_t lanes, int layout)
+{
+    static const bool off = diag_env("IDSP_NO_DUO") != nullptr;
+    if (off || layout != IDSP_FRAME_MAJOR || lanes < 40960) return false;
+    return m >= 5 || (m == 4 && lanes <= 98304);
 }
 
 }  // namespace idsp

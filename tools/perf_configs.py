@@ -113,8 +113,8 @@ def biquad(op, dtype, words, lanes, frames, layout, n_sections, iters, tag):
         call(op, C.cast(cfg, C.c_void_p), n_sections, p(st), p(x), p(y), lanes, frames, layout, sptr())
 
     med, mn = timeit(run, iters)
-    # sections beyond 4 run as extra in-place passes: each pass moves 8 B/sample
-    passes = 1 if "cascade" in op else (n_sections + 3) // 4
+    # rate in section-samples is what compares across kernels; "GB/s" prices ONE pass of 8 B/sample per launch of up to 8 sections
+    passes = 1 if "cascade" in op else (n_sections + 7) // 8
     report(f"{tag}:{op} x{n_sections} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample",
            8 * lanes * frames * passes, med, mn)
 
@@ -338,6 +338,19 @@ def main():
         biquad("biquad_i32_df1", torch.int32, 4, 65536, 4096, FM, 4, it, "C2v")
         biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, 4, it, "C2v")
         biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, 8, it, "C2v")
+    if want("multi"):  # chains of 4 .. 8 sections (two-wave kernel on FrameMajor; IDSP_DIAG=1 IDSP_NO_DUO=1 for the single-wave kernels)
+        for n in (4, 5, 6, 8):
+            biquad("biquad_i32_df1", torch.int32, 4, 65536, 4096, FM, n, it, "multi")
+        biquad("biquad_i32_df1_clamp", torch.int32, 4, 65536, 4096, FM, 4, it, "multi")
+        biquad("biquad_i32_wide", torch.int32, 6, 65536, 4096, FM, 4, it, "multi")
+        for n in (4, 8):
+            biquad("biquad_f32_df2t", torch.float32, 2, 65536, 4096, FM, n, it, "multi")
+            biquad("biquad_f32_df1", torch.float32, 4, 65536, 4096, FM, n, it, "multi")
+        for n in (5, 8):
+            biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, n, it, "multi")
+            biquad("cascade_f32_df1", torch.float32, 4, 65536, 4096, FM, n, it, "multi")
+        biquad("biquad_i32_df1", torch.int32, 4, 131072, 4096, FM, 8, it, "multi")
+        biquad("biquad_i32_df1", torch.int32, 4, 49152, 4096, FM, 4, it, "multi")
     if want("bylane"):
         for layout in (FM, LM):
             biquad_bylane("biquad_i32_df1", torch.int32, 4, 5, 65536, 4096, layout, 1, it, "C2b")
