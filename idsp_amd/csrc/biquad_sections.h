@@ -675,6 +675,22 @@ int run_chain_bylane(const void *coef, int frac, size_t n, void *state, const ty
     size_t done = 0;
     const T *src = x;
     while (done < n) {
+        if constexpr (sizeof(T) == 4) {
+            // three or four sections of a bank in one pass on the two-wave kernel (two sections per wave; coefficient and state
+            // planes of the second wave start two sections further into the records)
+            const size_t md = n - done < size_t(2 * kMaxChainByLane) ? n - done : size_t(2 * kMaxChainByLane);
+            if (md >= 3 && duo_wanted(5, lanes, layout)) {
+                ByLaneParams pa{static_cast<const T *>(coef) + done * CV * lanes, frac}, pb{static_cast<const T *>(coef) + (done + 2) * CV * lanes, frac};
+                uint32_t *sa = static_cast<uint32_t *>(state) + done * Sec::W * lanes, *sb = sa + 2 * Sec::W * lanes;
+                const int rc = md == 3 ? launch_duo<ChainByLane<Sec, 2>, ChainByLane<Sec, 1>>(pa, pb, sa, sb, src, y, lanes, frames, s, pitch)
+                                       : launch_duo<ChainByLane<Sec, 2>, ChainByLane<Sec, 2>>(pa, pb, sa, sb, src, y, lanes, frames, s, pitch);
+                if (rc) return rc;
+                done += md;
+                src = y;
+                pitch.x = pitch.y;
+                continue;
+            }
+        }
         const size_t m = n - done < size_t(kMaxChainByLane) ? n - done : size_t(kMaxChainByLane);
         ByLaneParams prm{static_cast<const T *>(coef) + done * CV * lanes, frac};
         uint32_t *st = static_cast<uint32_t *>(state) + done * Sec::W * lanes;

@@ -83,3 +83,29 @@ def test_cascades_of_five_to_eight_sections(gpu, op, dt, mk):
             assert np.array_equal(yv[:, off:off + lanes].cpu().numpy().view(np.uint32), want.view(np.uint32)), (op, n, lanes)
             assert np.array_equal(sg.cpu().numpy().view(np.uint32), so), (op, n, "state")
             assert (yv[:, :off] == SENT).all() and (yv[:, off + lanes:] == SENT).all()
+
+
+def test_bylane_banks_of_three_to_six_sections(gpu):
+    """`ByLane` banks (dsp-process/src/compose.rs:363-390): three or four sections per pass on the two-wave kernel, the second
+    wave's coefficient and state planes starting two sections further into the records."""
+    from tests import _bylane_cases as B
+    from tests._backends import GpuBackend, OracleBackend
+
+    ob, gb = OracleBackend(), GpuBackend()
+    rng = np.random.default_rng(504)
+    for op, dtype, words, clamp in B.OPS:
+        if np.dtype(dtype).itemsize != 4:
+            continue
+        for n, lanes, frames in ((3, 40960, 37), (4, 41001, 32), (6, 40960, 70)):
+            if (n + len(op)) % 2:
+                continue  # half of the (entry, shape) pairs
+            frac = 29 if dtype == np.int32 else None
+            coef = B.coef_planes(rng, dtype, n, lanes, clamp, frac or 0)
+            x = B.samples(rng, dtype, lanes * frames)
+            init = B.init_state(rng, dtype, words * n, lanes)
+            so, sg = init.copy(), init.copy()
+            rco, yo = ob.bylane(op, coef, frac, n, so, x.copy(), lanes, frames, B.FM)
+            rcg, yg = gb.bylane(op, coef, frac, n, sg, x.copy(), lanes, frames, B.FM)
+            assert rco == 0 and rcg == 0, H.engine().err()
+            assert kernel_of(gpu).startswith("stream_frame_major_duo<") == (n != 6), (op, n, kernel_of(gpu))  # 6 = 4 (two waves) + 2
+            assert np.array_equal(B.bits(yo), B.bits(yg)) and np.array_equal(so, sg), (op, n, lanes)

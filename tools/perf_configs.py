@@ -210,7 +210,7 @@ def biquad_bylane(op, dtype, words, cv, lanes, frames, layout, n_sections, iters
 
     med, mn = timeit(run, iters)
     esz = x.element_size()
-    passes = (n_sections + 1) // 2
+    passes = (n_sections + 3) // 4  # FrameMajor from 40960 lanes: three or four sections per pass on the two-wave kernel (else two)
     report(f"{tag}:{op}_bylane x{n_sections} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample",
            2 * esz * lanes * frames * passes + coef.numel() * esz, med, mn)
 
@@ -351,6 +351,9 @@ def main():
             biquad("cascade_f32_df1", torch.float32, 4, 65536, 4096, FM, n, it, "multi")
         biquad("biquad_i32_df1", torch.int32, 4, 131072, 4096, FM, 8, it, "multi")
         biquad("biquad_i32_df1", torch.int32, 4, 49152, 4096, FM, 4, it, "multi")
+        biquad_bylane("biquad_i32_df1", torch.int32, 4, 5, 65536, 4096, FM, 4, it, "multi")
+        biquad_bylane("biquad_f32_df2t", torch.float32, 2, 5, 65536, 4096, FM, 4, it, "multi")
+        biquad_bylane("biquad_i32_df1_clamp", torch.int32, 4, 8, 65536, 4096, FM, 3, it, "multi")
     if want("bylane"):
         for layout in (FM, LM):
             biquad_bylane("biquad_i32_df1", torch.int32, 4, 5, 65536, 4096, layout, 1, it, "C2b")
