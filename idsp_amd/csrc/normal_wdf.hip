@@ -127,9 +127,48 @@ int wdf_launch_n(const idsp_wdf *c, uint32_t *st, const int32_t *x, int32_t *y, 
     return launch_stream<WdfChain<K, NMAX>>(p, st, x, y, lanes, frames, layout, s);
 }
 
+template <int K, int NMAX>
+WdfParamsT<NMAX> wdf_params(const idsp_wdf *c)
+{
+    WdfParamsT<NMAX> p{};
+    for (int k = 0; k < K; k++) {
+        p.n[k] = c[k].n;
+        uint32_t m = c[k].m;
+        for (int i = 0; i < NMAX; i++, m >>= 4) p.ad[k][i] = i < c[k].n ? adaptor_of(m & 0xf, c[k].a[i]) : adaptor_of(0, 0);
+    }
+    return p;
+}
+
+// K sections over two waves per 64 lanes (lane_stream.h, stream_frame_major_duo): the first KA on wave 0, the rest on wave 1,
+// whose state planes start behind the first KA sections' words.  ~80 VALU instructions per sample for the 7th-order chain of the
+// reference's embedded bench: 0.81 -> 0.70 ms at 65536 lanes x 4096 frames (profiles/r03_wdf_duo.log).
+template <int KA, int KB, int NMAX>
+int wdf_launch_duo_n(const idsp_wdf *c, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, hipStream_t s)
+{
+    size_t wa = 0;
+    for (int k = 0; k < KA; k++) wa += size_t(c[k].n);
+    return launch_duo<WdfChain<KA, NMAX>, WdfChain<KB, NMAX>>(wdf_params<KA, NMAX>(c), wdf_params<KB, NMAX>(c + KA), st, st + wa * lanes, x, y, lanes, frames, s,
+                                                               Pitch{});
+}
+template <int KA, int KB>
+int wdf_launch_duo(const idsp_wdf *c, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, hipStream_t s)
+{
+    int nmax = 0;
+    for (int k = 0; k < KA + KB; k++) nmax = c[k].n > nmax ? c[k].n : nmax;
+    if (nmax <= 2) return wdf_launch_duo_n<KA, KB, 2>(c, st, x, y, lanes, frames, s);
+    if (nmax <= 4) return wdf_launch_duo_n<KA, KB, 4>(c, st, x, y, lanes, frames, s);
+    return 1;  // sections of order 5 .. 8: the two-wave form would index its state through scratch; the caller keeps one wave
+}
+
 template <int K>
 int wdf_launch(const idsp_wdf *c, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s)
 {
+    if constexpr (K >= 2) {
+        if (duo_wanted(5, lanes, layout)) {
+            const int rc = wdf_launch_duo<(K + 1) / 2, K / 2>(c, st, x, y, lanes, frames, s);
+            if (rc <= 0) return rc;
+        }
+    }
     int nmax = 0;
     for (int k = 0; k < K; k++) nmax = c[k].n > nmax ? c[k].n : nmax;
     if (nmax <= 2) return wdf_launch_n<K, 2>(c, st, x, y, lanes, frames, layout, s);

@@ -109,3 +109,33 @@ def test_bylane_banks_of_three_to_six_sections(gpu):
             assert rco == 0 and rcg == 0, H.engine().err()
             assert kernel_of(gpu).startswith("stream_frame_major_duo<") == (n != 6), (op, n, kernel_of(gpu))  # 6 = 4 (two waves) + 2
             assert np.array_equal(B.bits(yo), B.bits(yg)) and np.array_equal(so, sg), (op, n, lanes)
+
+
+def test_wdf_chains_of_two_to_four_sections(gpu):
+    """`Wdf` sections in series (src/iir/wdf.rs:178-214 per section; the chain is a slice composition): the first
+    ceil(k/2) sections on wave 0, the rest on wave 1 with its state planes starting after wave 0's `sum n` words."""
+    from tests import _nw_cases as W
+    from tests._backends import GpuBackend, OracleBackend
+
+    ob, gb = OracleBackend(), GpuBackend()
+    rng = np.random.default_rng(505)
+    bench = [W.wdf_section(ob, m, g)[1] for m, g in W.WDF_BENCH]
+    for k, lanes, frames in ((2, 40960, 37), (3, 41001, 32), (4, 40960, 70), (1, 40960, 33), (7, 45056, 40)):
+        low = W.random_wdf(rng, k)
+        for sec in low:  # orders 1 .. 4: the two-wave form
+            sec.n = 1 + sec.n % 4
+            sec.m &= (1 << (4 * sec.n)) - 1
+        for secs in (W.random_wdf(rng, k), low, bench[:k]):
+            cfg = W.wdf_array(secs)
+            words = gb.helper("wdf_state_words", C.cast(cfg, C.c_void_p), k)
+            init = rng.integers(0, 1 << 32, size=(words, lanes), dtype=np.uint64).astype(np.uint32)
+            x = rng.integers(W.I32_MIN, W.I32_MAX, size=lanes * frames, dtype=np.int64, endpoint=True).astype(np.int32)
+            for inplace in (False, True):
+                so, sg = init.copy(), init.copy()
+                rco, yo = ob.stream("wdf_i32", cfg, k, so, x.copy(), lanes, frames, W.FM, inplace=inplace)
+                rcg, yg = gb.stream("wdf_i32", cfg, k, sg, x.copy(), lanes, frames, W.FM, inplace=inplace)
+                assert rco == 0 and rcg == 0, H.engine().err()
+                last = secs[4 * ((k - 1) // 4):]  # the sections of the last pass; orders 5 .. 8 stay on one wave
+                want_duo = len(last) >= 2 and max(s.n for s in last) <= 4
+                assert kernel_of(gpu).startswith("stream_frame_major_duo<") == want_duo, (k, kernel_of(gpu))
+                assert np.array_equal(yo, yg) and np.array_equal(so, sg), (k, lanes, inplace)
