@@ -28,7 +28,7 @@ int fail(int code, const char *fmt, ...)
 
 namespace {
 struct LastKernel {
-    const char *kernel = nullptr, *detail = nullptr;
+    const char *kernel = nullptr, *detail = nullptr, *also = nullptr;
     char text[768] = {0};
 };
 LastKernel &last_kernel()
@@ -44,7 +44,9 @@ void note_kernel(const char *kernel, const char *detail)
     LastKernel &k = last_kernel();
     k.kernel = kernel;
     k.detail = detail;
+    k.also = nullptr;
 }
+void note_kernel_also(const char *also) { last_kernel().also = also; }
 
 namespace {
 
@@ -105,10 +107,10 @@ const char *idsp_last_kernel(void)
         // `detail` is typeid(Processor).name(): demangle it for the reader
         int status = 0;
         char *dm = abi::__cxa_demangle(k.detail, nullptr, nullptr, &status);
-        snprintf(k.text, sizeof(k.text), "%s<%s>", k.kernel, status == 0 && dm ? dm : k.detail);
+        snprintf(k.text, sizeof(k.text), "%s<%s>%s", k.kernel, status == 0 && dm ? dm : k.detail, k.also ? k.also : "");
         free(dm);
     } else {
-        snprintf(k.text, sizeof(k.text), "%s", k.kernel);
+        snprintf(k.text, sizeof(k.text), "%s%s", k.kernel, k.also ? k.also : "");
     }
     return k.text;
 }

@@ -74,6 +74,8 @@ inline SideStream *side_stream()
 
 // Name of the kernel the most recent launch on this thread dispatched to (idsp_last_kernel()).
 void note_kernel(const char *kernel, const char *detail = nullptr);
+// a second kernel the same call ran beside it (appended to the text; cleared by the next note_kernel())
+void note_kernel_also(const char *also);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

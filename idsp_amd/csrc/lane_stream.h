@@ -150,10 +150,12 @@ constexpr int kFmBlock = 256;  // 4 waves: one per SIMD of a CU, 1 KiB row segme
 template <class P, int U>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const int xcd_contiguous)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const int xcd_contiguous, const size_t slanes_ = 0)
 {
     using In = typename P::In;
     using Out = typename P::Out;
+    // slanes: pitch of the state (and per-lane coefficient) planes in lanes; 0 = `lanes` (not a lane block of a larger call)
+    const size_t slanes = slanes_ ? slanes_ : lanes;
     __shared__ uint32_t ptab[P::LDS_WORDS ? P::LDS_WORDS : 1];
     // launched with 256-thread workgroups when that still gives every CU one, else with single waves
     if constexpr (P::LDS_WORDS > 0) {
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
 
     P p;
     if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
-    p.load(prm, st, lanes, lane);
+    p.load(prm, st, slanes, lane);
 
 #ifdef IDSP_NO_NT
     constexpr bool kNT = false;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major(
             yp += yl;
         }
     }
-    p.store(prm, st, lanes, lane);
+    p.store(prm, st, slanes, lane);
 }
 
 // ------------------------------------------------- FRAME_MAJOR through LDS (DMA)
@@ -991,7 +993,7 @@ struct FmStagedOf<P, std::enable_if_t<P::HAS_IN && P::IN_DIV == 1 && sizeof(type
 template <class P, int LW>
 __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes, const int xcd_contiguous = 0)
 {
     using In = typename P::In;
     using Out = typename P::Out;
@@ -1012,7 +1014,14 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
     uint32_t *ptab = smem + kFmStagedTile / 4;  // [P::LDS_WORDS]
     const int lid = threadIdx.x;
 
-    const size_t lane0 = size_t(blockIdx.x) * LW;
+    // xcd_contiguous (rows off the 64-byte grid): XCD j = blockIdx % 8 takes the j-th contiguous eighth of the lane blocks, so that the
+    // 128-byte lines two neighbouring waves share are fetched and written through one L2 (see stream_frame_major_lds, XCDC)
+    size_t wg = blockIdx.x;
+    if (xcd_contiguous) {
+        const size_t q = gridDim.x / 8, r = gridDim.x % 8, j = blockIdx.x % 8;
+        wg = j * q + (j < r ? j : r) + blockIdx.x / 8;
+    }
+    const size_t lane0 = wg * LW;
     const size_t nrows = lanes - lane0 < size_t(LW) ? lanes - lane0 : size_t(LW);  // lanes of this wave (a multiple of 4 / W)
     const bool active = size_t(lid) < nrows;
 
@@ -1208,6 +1217,82 @@ __global__ __launch_bounds__(2 * kWave) void stream_frame_major_duo(
     }
 }
 
+// ------------------------------------------------------------- FRAME_MAJOR, one to three lanes
+// The last lanes % 4 lanes of a call whose rows do not hold a whole number of 16-byte pieces (launch_stream runs them beside the
+// rest on a second stream).  One thread per lane on the register-window kernel is a chain of frames at ~90 ns each — the load
+// latency over the ring depth: 0.36-0.42 ms for 4096 frames, longer than the whole 65536-lane body beside it and three times
+// a 16384-lane body.  Here ONE wave moves the samples of 256 frames per tile with all 64 threads (thread t: frames t, t + 64,
+// t + 128, t + 192 of each lane), hands them over through LDS, threads 0 .. n - 1 walk their lane's 256 samples from there
+// (the next tile's loads in flight), and all 64 threads store the results.
+template <class P>
+__global__ __launch_bounds__(kWave) void stream_frame_major_few(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const int n, const size_t frames, const size_t xl, const size_t yl, const size_t slanes)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4 && sizeof(Out) == 4, "one 4-byte sample in, one out");
+    constexpr int K = 4, TF = K * kWave, ML = 3;
+    __shared__ uint32_t tin[TF][4], tout[TF][4];
+    __shared__ uint32_t ptab[P::LDS_WORDS ? P::LDS_WORDS : 1];
+    const int t = threadIdx.x;
+    if constexpr (P::LDS_WORDS > 0) {
+        P::fill_shared(ptab, t, kWave);
+        lds_wave_sync();
+    }
+    P p;
+    if constexpr (P::LDS_WORDS > 0) p.set_shared(ptab);
+    const bool own = t < n;
+    if (own) p.load(prm, st, slanes, size_t(t));
+    uint32_t cur[K][ML] = {};
+    const size_t ntiles = (frames + TF - 1) / TF;
+    auto fetch = [&](size_t tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const size_t f = tile * TF + size_t(k) * kWave + t;
+            if (f < frames) {
+#pragma unroll
+                for (int j = 0; j < ML; j++)
+                    if (j < n) cur[k][j] = __builtin_bit_cast(uint32_t, x[f * xl + j]);
+            }
+        }
+    };
+    fetch(0);
+    for (size_t i = 0; i < ntiles; i++) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int j = 0; j < ML; j++) tin[k * kWave + t][j] = cur[k][j];
+        lds_wave_sync();
+        if (i + 1 < ntiles) fetch(i + 1);
+        if (own) {
+            const size_t left = frames - i * TF;
+            const int nf = left < size_t(TF) ? int(left) : TF;
+            int f = 0;
+            for (; f + 8 <= nf; f += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = tin[f + u][t];
+#pragma unroll
+                for (int u = 0; u < 8; u++) tout[f + u][t] = __builtin_bit_cast(uint32_t, step1(p, prm, __builtin_bit_cast(In, v[u])));
+            }
+            for (; f < nf; f++) tout[f][t] = __builtin_bit_cast(uint32_t, step1(p, prm, __builtin_bit_cast(In, tin[f][t])));
+        }
+        lds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const size_t f = i * TF + size_t(k) * kWave + t;
+            if (f < frames) {
+#pragma unroll
+                for (int j = 0; j < ML; j++)
+                    if (j < n) y[f * yl + j] = __builtin_bit_cast(Out, tout[k * kWave + t][j]);
+            }
+        }
+        lds_wave_sync();
+    }
+    if (own) p.store(prm, st, slanes, size_t(t));
+}
+
 // --------------------------------------------------------------------- launch
 // Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
 // latency, so go deep; with many resident waves keep the register budget low.
@@ -1314,18 +1399,51 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         // 0.57 -> 0.65, 73728 0.58 -> 0.69, 81920 0.59 -> 0.63, 147456 0.59 -> 0.65; no gain from a 24576-lane remainder up
         // (tools/exp_split_streams.py, profiles/r03_exp_split_streams.jsonl).  Both pieces are lane blocks of the caller's
         // tensors (row pitches xl / yl, state and coefficient planes at the call's pitch).
+        // Rows that are only 4-byte aligned (round 3): a dense tensor of 65537 lanes, an odd pitch, a base pointer off the 16-byte grid.
+        // `global_load_lds_dwordx4`, `global_load_dwordx4` and the 16-byte stores only need dword alignment, so the LDS-DMA kernel
+        // and the staged kernel run on such rows as they are (tools/exp_fm_unaligned4.hip, profiles/r03_exp_fm_unaligned4.jsonl: bit for
+        // bit the register-window kernel's output; 65536 lanes at pitch 65537 0.65 of the HBM peak with XCD-contiguous blocks against 0.41
+        // for the register-window kernel's 4-byte accesses).  What they do need is whole 16-byte pieces per row, i.e. a lane count that
+        // is a multiple of 4: the last lanes % 4 lanes run beside the rest on the second stream (stream_frame_major_few).
+        // (IDSP_DIAG=1 IDSP_ALIGN16_ONLY=1: round 2's rule — 16-byte aligned rows or the register-window kernel)
+        static const bool align16_only = diag_env("IDSP_ALIGN16_ONLY") != nullptr;
+        const bool on_grid16 = reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && (xl * sizeof(typename P::In)) % 16 == 0 &&
+                               (yl * sizeof(typename P::Out)) % 16 == 0;
+        const bool rows_ok = on_grid16 || !align16_only;
+        if constexpr (P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4) {
+            static const bool no_few = diag_env("IDSP_NO_FM_FEW") != nullptr;
+            if (lanes <= 3 && frames >= 64 && !no_few) {  // one to three lanes in all: the same kernel, on the caller's stream
+                note_kernel("stream_frame_major_few", typeid(P).name());
+                hipLaunchKernelGGL((stream_frame_major_few<P>), dim3(1), dim3(kWave), 0, s, prm, st, x, y, int(lanes), frames, xl, yl, sp);
+                return launch_status();
+            }
+            const size_t odd = lanes % 4, body = lanes - odd;
+            if (odd && !align16_only && body >= 8192 && frames >= 16 && (FmStagedOf<P>::value || LdsEligibleOf<P>::value)) {
+                if (SideStream *ss = side_stream()) {
+                    IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
+                    IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
+                    hipLaunchKernelGGL((stream_frame_major_few<P>), dim3(1), dim3(kWave), 0, ss->stream, shift_lanes(prm, body, sizeof(typename P::In)), st + body,
+                                       x + body, y + body, int(odd), frames, xl, yl, sp);
+                    int rc = launch_status();
+                    if (rc == IDSP_OK) rc = launch_stream<P>(prm, st, x, y, body, frames, layout, s, Pitch{xl, yl}, sp);
+                    IDSP_HIP_TRY(hipEventRecord(ss->join, ss->stream));
+                    IDSP_HIP_TRY(hipStreamWaitEvent(s, ss->join, 0));
+                    if (rc == IDSP_OK) note_kernel_also(" + stream_frame_major_few (lanes % 4, second stream)");
+                    return rc;
+                }
+            }
+        }
         if constexpr (FmStagedOf<P>::value && P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4 && P::COST <= 120) {
             const size_t head = lanes / (size_t(256) * kFmBlock) * (size_t(256) * kFmBlock), tail = lanes - head;
-            if (sp == lanes && head && tail && tail <= kSplitTailMax && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() &&
-                reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && yl % 4 == 0 &&
+            if (head && tail && tail <= kSplitTailMax && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() && rows_ok &&
                 xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
                 if (SideStream *ss = side_stream()) {
                     IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
                     IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
-                    int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, lanes);
+                    int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, sp);
                     if (rc == IDSP_OK)
                         rc = launch_stream<P>(shift_lanes(prm, head, sizeof(typename P::In)), st + head, x + head, y + head, tail, frames, layout, ss->stream,
-                                              Pitch{xl, yl}, lanes);
+                                              Pitch{xl, yl}, sp);
                     // join even after a failed launch: the caller's stream must not run ahead of whatever the side stream holds
                     IDSP_HIP_TRY(hipEventRecord(ss->join, ss->stream));
                     IDSP_HIP_TRY(hipStreamWaitEvent(s, ss->join, 0));
@@ -1347,19 +1465,24 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             constexpr size_t sz = sizeof(typename P::In);
             constexpr bool heavy = P::COST > 120;
             const bool in_range = heavy ? (lanes >= 12288 && lanes < 40960) : lanes < 49152;
-            if (!no_fm_staged && (forced_flw || in_range) && frames >= 16 && (lanes * sz) % 16 == 0 && (xl * sz) % 16 == 0 &&
-                (yl * sz) % 16 == 0 && xl * sz < (size_t(1) << 28) && yl * sz < (size_t(1) << 28) &&  // 32-bit offsets: up to 15 row pitches + 1 KiB inside a tile (16 lanes/wave)
-               
-                reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0) {
-                const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= 24576 ? 64 : lanes >= 8192 ? 32 : 16;
+            if (!no_fm_staged && (forced_flw || in_range) && frames >= 16 && (lanes * sz) % 16 == 0 && rows_ok &&
+                xl * sz < (size_t(1) << 28) && yl * sz < (size_t(1) << 28)) {  // 32-bit offsets: up to 15 row pitches + 1 KiB inside a tile (16 lanes/wave)
+                // rows off the 64-byte grid: a 32-lane wave's 128-byte row pieces each straddle two lines; whole 256-byte pieces from 12288
+                // lanes (16384 lanes at pitch 16385: 0.19 ms with 64 lanes per wave, 0.27 with 32, 0.23 on the register-window kernel;
+                // 8192 lanes 0.175 / 0.147 / 0.21 — tools/exp_fm_unaligned_small.py, profiles/r03_exp_fm_unaligned_small.jsonl)
+                const bool off64 = (xl * sz) % 64 != 0 || (yl * sz) % 64 != 0 || reinterpret_cast<uintptr_t>(x) % 64 != 0 || reinterpret_cast<uintptr_t>(y) % 64 != 0;
+                const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= (off64 ? 12288 : 24576) ? 64 : lanes >= 8192 ? 32 : 16;
                 auto go = [&](auto lw_tag) {
                     constexpr int LW = decltype(lw_tag)::value;
                     constexpr size_t bytes = size_t(kFmStagedTile) + size_t(P::LDS_WORDS) * 4;
                     if (int rc = ensure_dyn_lds<&stream_frame_major_staged<P, LW>>(bytes)) return rc;
                     note_kernel(LW == 64 ? "stream_frame_major_staged[64 lanes/wave]" : LW == 32 ? "stream_frame_major_staged[32 lanes/wave]" : "stream_frame_major_staged[16 lanes/wave]",
                                 typeid(P).name());
-                    hipLaunchKernelGGL((stream_frame_major_staged<P, LW>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
-                                       lanes, frames, xl, yl, sp);
+                    // rows off the 64-byte grid: XCD-contiguous lane blocks (IDSP_DIAG=1 IDSP_STAGED_NO_XCDC=1: the plain order)
+                    static const bool no_xcdc = diag_env("IDSP_STAGED_NO_XCDC") != nullptr;
+                    const unsigned grid = unsigned((lanes + LW - 1) / LW);
+                    const int xcdc = !no_xcdc && grid >= 64 && off64;
+                    hipLaunchKernelGGL((stream_frame_major_staged<P, LW>), dim3(grid), dim3(kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp, xcdc);
                     return launch_status();
                 };
                 if constexpr (!heavy) {
@@ -1383,8 +1506,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             constexpr size_t ow = sizeof(typename P::Out) / 4;
             // whole 256-lane blocks — or, for one-word outputs, any multiple of 4 lanes: the kernel's last block may be ragged
             // (reference: any N in `Lanes<C>`, dsp-process/src/compose.rs:468)
-            if (!no_lds && eligible && waves >= lds_min_waves() && waves <= lds_max_waves && (lanes % kFmBlock == 0 || (ow == 1 && lanes % 4 == 0)) &&
-                reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && xl % 4 == 0 && (yl * ow) % 4 == 0) {
+            if (!no_lds && eligible && waves >= lds_min_waves() && waves <= lds_max_waves && (lanes % kFmBlock == 0 || (ow == 1 && lanes % 4 == 0)) && rows_ok) {
                 // Grid (profiles/r02_exp_c5_*.jsonl).  Up to 384 workgroups: one per 256-lane block.  Beyond: a persistent
                 // grid of <= 256 workgroups (one per CU) that walks the lane blocks in column panels of equal rounds —
                 // 2^20 lanes: 0.68 of peak (0.61-0.75 by output placement) against 0.66 with 4096 workgroups and 0.615
@@ -1466,7 +1588,6 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 return launch_status();
             }
         }
-        if (sp != lanes) return fail(IDSP_EINVAL, "internal: lane block with a state pitch on the register-window kernel");
         // A CU's L1 moves ~10 B/cycle, so a launch must reach all 256 CUs: below 1024 waves (= 256
         // workgroups of 4) use one wave per workgroup (16384 lanes in 256-thread blocks would run on 64 CUs).
         const unsigned block = waves < 1024 ? unsigned(kWave) : unsigned(kFmBlock);
@@ -1479,9 +1600,9 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         const int xcdc = want_xcdc && grid >= 64;
         note_kernel(xcdc ? "stream_frame_major[XCD-contiguous blocks]" : "stream_frame_major", typeid(P).name());
         if (waves <= 2048)
-            hipLaunchKernelGGL((stream_frame_major<P, kDeep>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl, xcdc);
+            hipLaunchKernelGGL((stream_frame_major<P, kDeep>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl, xcdc, sp);
         else
-            hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl, xcdc);
+            hipLaunchKernelGGL((stream_frame_major<P, kShallow>), dim3(grid), dim3(block), 0, s, prm, st, x, y, lanes, frames, xl, yl, xcdc, sp);
     }
     return launch_status();
 }

@@ -83,14 +83,18 @@ def test_lane_block_of_a_wider_tensor_in_place(gpu):
         assert "stream_frame_major_staged[32 lanes/wave]" in kernel_of(gpu), kernel_of(gpu)
 
 
-def test_unaligned_rows_take_the_other_kernels(gpu):
+def test_rows_off_the_16_byte_grid(gpu):
+    """Round 3: the staged kernel's 16-byte pieces need dword alignment only (tests/test_gpu_rows_off_16_byte_grid.py); lane counts
+    that are not multiples of four still take the register-window kernel below 8192 lanes."""
     rng = np.random.default_rng(93)
     op, cfg, n, words, dt = cases(rng)[0]
-    for lanes, frames, pitch in ((130, 200, 130), (64, 200, 65), (1001, 64, 1001)):
+    for lanes, frames, pitch in ((130, 200, 130), (1001, 64, 1001)):
         run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, False)
         assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
+    run_case(gpu, op, cfg, n, words, dt, rng, 64, 200, 65, False)
+    assert kernel_of(gpu).startswith("stream_frame_major_staged["), kernel_of(gpu)
     run_case(gpu, op, cfg, n, words, dt, rng, 64, 200, 72, False, off=1)  # aligned pitch, base 4 bytes off
-    assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
+    assert kernel_of(gpu).startswith("stream_frame_major_staged["), kernel_of(gpu)
 
 
 def test_row_pitch_beyond_the_32_bit_offsets_of_the_staged_kernel(gpu):

@@ -5,7 +5,7 @@ piece; rows that do not start on 64-byte boundaries (what dense rows of such lan
 that gives every XCD a contiguous eighth of the lane blocks.  The reference takes any N in `Lanes<C>` (dsp-process/src/compose.rs:468); round 2 dropped such shapes to the
 register-window kernel.  Against the oracle bit for bit (outputs and state), out of place and in place, dense rows and a
 lane block of a wider tensor whose neighbouring lanes must stay untouched; the kernel taken is asserted through
-`idsp_last_kernel()`.  Lane counts that are not multiples of 4 (rows without 16-byte alignment) keep the other kernels."""
+`idsp_last_kernel()`.  Lane counts that are not multiples of 4: the last lanes % 4 lanes on a second stream."""
 import os
 import subprocess
 import sys
@@ -49,14 +49,16 @@ def test_default_dispatch_takes_the_lds_kernel_on_ragged_lane_counts(gpu):
             assert k.startswith("stream_frame_major_lds<" if aligned else "stream_frame_major_lds[XCD-contiguous blocks]<"), (op, lanes, pitch, off, k)
 
 
-def test_lane_counts_that_are_not_multiples_of_four_keep_the_register_window_kernel(gpu):
+def test_lane_counts_that_are_not_multiples_of_four_run_their_last_lanes_beside(gpu):
+    """tests/test_gpu_rows_off_16_byte_grid.py holds the matrix; here: the body is this file's ragged LDS-DMA launch"""
     if SMALL:
         pytest.skip("forced small-shape run")
     rng = np.random.default_rng(302)
     op, cfg, n, words, dt = lds_cases(rng)[0]
     for lanes in (65537, 65001):
         FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, 21, lanes, False)
-        assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
+        k = kernel_of(gpu)
+        assert k.startswith("stream_frame_major_lds[XCD-contiguous blocks]<") and k.endswith("(lanes % 4, second stream)"), k
 
 
 def test_small_ragged_shapes_inner(gpu):

@@ -1,0 +1,90 @@
+"""FRAME_MAJOR rows that are only 4-byte aligned (round 3): dense tensors whose lane count is not a multiple of four (row f of a
+65537-lane tensor starts 4 f bytes off the 16-byte grid), odd row pitches, base pointers one or three words into a row.  The
+reference takes any N in `Lanes<C>` and any slice (dsp-process/src/compose.rs:468-476, view.rs:10-17); round 2 ran all of these on
+the register-window kernel's 4-byte accesses (0.39-0.41 of the HBM peak at 65537 lanes).  Now the 16-byte kernels run on such rows
+as they are — `global_load_lds_dwordx4` / `global_load_dwordx4` / 16-byte stores need dword alignment only — and the last
+`lanes % 4` lanes run beside them on a second stream (idsp_amd/csrc/lane_stream.h, launch_stream).  Against the oracle bit for
+bit (outputs, state), out of place and in place, the bytes between the rows untouched, the kernels taken asserted."""
+import numpy as np
+import pytest
+
+from tests import test_gpu_frame_major_staged as FMS
+from tests.test_gpu_pitch import cases
+from tests.test_gpu_ragged_lds_block import kernel_of, lds_cases
+
+pytestmark = pytest.mark.gpu
+ODD = " + stream_frame_major_few (lanes % 4, second stream)"
+
+
+def test_lane_counts_that_are_not_multiples_of_four(gpu):
+    rng = np.random.default_rng(311)
+    cs = lds_cases(rng)
+    # (lanes, frames, pitch, lane offset, kernel of the lanes - lanes % 4 body)
+    shapes = [(65537, 40, 65537, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65539, 17, 65543, 3, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65001, 21, 65001, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (8195, 50, 8195, 0, "stream_frame_major_staged[32 lanes/wave]<"),
+              (32770, 64, 32771, 1, "stream_frame_major_staged[64 lanes/wave]<"),
+              (73731, 24, 73731, 0, "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)<"),
+              (131073, 16, 131073, 0, "stream_frame_major_lds[XCD-contiguous blocks]<")]
+    for i, (lanes, frames, pitch, off, body) in enumerate(shapes):
+        for j, (op, cfg, n, words, dt) in enumerate(cs):
+            if (i + j) % 3:
+                continue
+            FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, bool((i + j) & 1), off=off)
+            k = kernel_of(gpu)
+            assert k.startswith(body) and k.endswith(ODD), (op, lanes, pitch, off, k)
+
+
+def test_whole_pieces_on_rows_off_the_grid(gpu):
+    """lane counts that are multiples of four with odd pitches / odd base offsets: no second stream, 16-byte kernels"""
+    rng = np.random.default_rng(312)
+    cs = lds_cases(rng)
+    shapes = [(65536, 33, 65537, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65536, 20, 65544, 1, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65000, 19, 65003, 2, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (16384, 130, 16387, 0, "stream_frame_major_staged[64 lanes/wave]<"),
+              (4096, 257, 4099, 3, "stream_frame_major_staged[16 lanes/wave]<"),
+              (69632, 18, 69633, 0, "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)<")]
+    for i, (lanes, frames, pitch, off, want) in enumerate(shapes):
+        for j, (op, cfg, n, words, dt) in enumerate(cs):
+            if (i + j) % 3:
+                continue
+            FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, bool((i + j) & 1), off=off)
+            k = kernel_of(gpu)
+            assert k.startswith(want) and not k.endswith(ODD), (op, lanes, pitch, off, k)
+
+
+def test_eight_byte_samples_and_chains_on_odd_pitches(gpu):
+    """f64 entries (8-byte samples: rows 8-byte aligned) and multi-section chains on the staged kernel with an odd pitch"""
+    rng = np.random.default_rng(313)
+    for op, cfg, n, words, dt in cases(rng):
+        if dt != np.float64 and n <= 2:
+            continue
+        FMS.run_case(gpu, op, cfg, n, words, dt, rng, 8192, 37, 8193, False, off=0)
+        FMS.run_case(gpu, op, cfg, n, words, dt, rng, 8192, 37, 8195, True, off=1)
+
+
+def test_few_lanes_keep_the_register_window_kernel(gpu):
+    rng = np.random.default_rng(314)
+    op, cfg, n, words, dt = lds_cases(rng)[0]
+    for lanes, frames, pitch in ((130, 200, 130), (1001, 64, 1001), (8193, 12, 8193)):  # body below 8192 lanes / fewer than 16 frames
+        FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, False)
+        assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
+
+
+def test_one_to_three_lanes_in_all(gpu):
+    """`stream_frame_major_few` as the whole launch: every 4-byte biquad entry, 1 .. 3 lanes, frame counts around the 256-frame
+    tiles and the 8-frame groups, dense and as a lane block of a wider tensor, in place and out of place."""
+    rng = np.random.default_rng(315)
+    for i, (op, cfg, n, words, dt) in enumerate(cases(rng)):
+        if dt == np.float64:
+            continue
+        for j, (lanes, frames, pitch, off) in enumerate(((1, 64, 1, 0), (2, 255, 2, 0), (3, 256, 3, 0), (3, 1031, 7, 2), (1, 4096, 5, 4), (2, 777, 64, 61))):
+            if (i + j) % 2:
+                continue
+            FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, bool(j & 1), off=off)
+            assert kernel_of(gpu).startswith("stream_frame_major_few<"), (op, kernel_of(gpu))
+    op, cfg, n, words, dt = lds_cases(rng)[0]
+    FMS.run_case(gpu, op, cfg, n, words, dt, rng, 3, 63, 3, False)  # fewer than 64 frames: the register-window kernel
+    assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
