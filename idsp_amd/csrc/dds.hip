@@ -331,6 +331,124 @@ struct FmDiscProc {
     }
 };
 
+// FM discriminator on role waves (round 3, FRAME_MAJOR).  One thread per lane is ~55 VALU instructions per sample on a single
+// wave per SIMD at 65536 lanes (0.44 of the HBM peak, issue-bound) — but only the deemphasis biquad is a recurrence: the
+// discriminator `arg(x[f] * conj(x[f-1])) - carrier` needs nothing but the previous INPUT sample, which is in the buffer (the
+// state's `prev` only for frame 0).  So a workgroup of NF + 1 waves owns 64 lanes: front wave w computes the discriminator of
+// frames [w FPW, (w + 1) FPW) of every tile of T = NF FPW frames (it loads those FPW rows plus the one before them) into an
+// LDS tile, the last wave runs the biquad down the previous tile and stores y; one workgroup barrier per tile, tiles double
+// buffered, whole tiles without per-frame predicates.  Five waves per SIMD instead of one, the same per-sample functions in the
+// same order: results are those of FmDiscProc bit for bit.
+// (registers: left alone the compiler spends 245 VGPRs on hoisted loads and ONE workgroup fits a CU — 1.01 ms at the C2 shape,
+// slower than the stream kernel; four workgroups per CU need <= 96)
+#ifndef IDSP_FMD_WPE
+#define IDSP_FMD_WPE 5
+#endif
+template <int NF>
+__global__ __launch_bounds__(kWave *(NF + 1)) __attribute__((amdgpu_waves_per_eu(IDSP_FMD_WPE, IDSP_FMD_WPE))) void fm_disc_waves_kernel(const FmDiscProc::Params prm, uint32_t *st, const cplx_bits *x, int32_t *y,
+                                                                        const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+{
+    constexpr int FPW = 8, T = NF * FPW;
+    __shared__ int32_t tile[2][T][kWave];
+    __shared__ uint32_t tab[32];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave), lid = int(threadIdx.x) % kWave;
+    if (threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
+    __syncthreads();
+    const size_t lane = size_t(blockIdx.x) * kWave + lid;
+    const bool active = lane < lanes;
+    const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
+    const size_t nfull = frames / T;
+    const int ntail = int(frames - nfull * T);
+    if (wave < NF) {
+        const cplx_bits *xp = x + la;
+        const uint32_t has_prev0 = st[la];
+        const cplx_bits prev0 = {int32_t(st[lanes + la]), int32_t(st[2 * lanes + la])};
+        const int j0 = wave * FPW;  // first frame of this wave inside a tile
+        // z = x * conj(prev), d = arg(z) - carrier (FmDiscProc::step, examples/fm_disc.rs:33-41)
+        auto disc = [&](cplx_bits c, cplx_bits pv) __attribute__((always_inline)) {
+            const int32_t cim = int32_t(0u - uint32_t(pv.y));
+            const int64_t re = int64_t(uint64_t(int64_t(c.x) * pv.x) - uint64_t(int64_t(c.y) * cim));
+            const int64_t im = int64_t(uint64_t(int64_t(c.x) * cim) + uint64_t(int64_t(c.y) * pv.x));
+            return int32_t(uint32_t(atan2_dev(int32_t(im >> 32), int32_t(re >> 32), tab)) - uint32_t(prm.carrier));
+        };
+        cplx_bits cur[FPW + 1], nxt[FPW + 1];  // [0]: the frame before this wave's first
+        auto fetch = [&](size_t k, cplx_bits(&dst)[FPW + 1], auto full) __attribute__((always_inline)) {
+            const size_t f0 = k * T + j0;
+#pragma unroll
+            for (int j = 0; j <= FPW; j++) {
+                if (j == 0 && f0 == 0) {
+                    dst[0] = prev0;  // frame -1 is the state's `prev`
+                } else if (decltype(full)::value || j0 + j - 1 < ntail) {
+                    dst[j] = nt_load<true>(xp + (f0 + j - 1) * xl);
+                }
+            }
+        };
+        if (nfull)
+            fetch(0, cur, std::true_type{});
+        else
+            fetch(0, cur, std::false_type{});
+        for (size_t k = 0; k < nfull; k++) {
+            if (k + 1 < nfull)
+                fetch(k + 1, nxt, std::true_type{});
+            else if (ntail)
+                fetch(k + 1, nxt, std::false_type{});
+#pragma unroll
+            for (int j = 0; j < FPW; j++) {
+                int32_t d = disc(cur[j + 1], cur[j]);
+                if (j == 0 && k == 0 && wave == 0) d = has_prev0 ? d : 0;  // `prev` was None: 0 (fm_disc.rs:33-35)
+                tile[k & 1][j0 + j][lid] = d;
+            }
+#pragma unroll
+            for (int j = 0; j <= FPW; j++) cur[j] = nxt[j];
+            lds_barrier();  // tile k complete; the biquad wave has finished tile k - 1
+        }
+        if (ntail) {
+            for (int j = 0; j < FPW && j0 + j < ntail; j++) {
+                int32_t d = disc(cur[j + 1], cur[j]);
+                if (j == 0 && nfull == 0 && wave == 0) d = has_prev0 ? d : 0;
+                tile[nfull & 1][j0 + j][lid] = d;
+            }
+            lds_barrier();
+        }
+        lds_barrier();  // pairs with the biquad wave's last interval
+        if (wave == 0 && active) {
+            const cplx_bits last = xp[(frames - 1) * xl];
+            st[lane] = 1u;
+            st[lanes + lane] = uint32_t(last.x);
+            st[2 * lanes + lane] = uint32_t(last.y);
+        }
+    } else {
+        uint32_t s[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) s[w] = st[size_t(3 + w) * lanes + la];
+        int32_t *yp = y + la;
+        lds_barrier();  // tile 0
+        for (size_t k = 0; k < nfull; k++) {
+            int32_t v[T];
+#pragma unroll
+            for (int f = 0; f < T; f++) v[f] = tile[k & 1][f][lid];
+#pragma unroll
+            for (int f = 0; f < T; f++) {
+                // (no `if (active)`: an idle thread of the last workgroup shadows lane `lanes - 1` — same input, same state, the
+                // same value to the same address — and a predicate per store is a branch per sample in the ISA)
+                nt_store<true>(yp + (k * T + f) * yl, bq::Df1I32<false>::step(prm.sec, s, v[f]));
+            }
+            lds_barrier();
+        }
+        if (ntail) {
+            for (int f = 0; f < ntail; f++) {
+                const int32_t o = bq::Df1I32<false>::step(prm.sec, s, tile[nfull & 1][f][lid]);
+                if (active) nt_store<true>(yp + (nfull * T + f) * yl, o);
+            }
+            lds_barrier();
+        }
+        if (active) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) st[size_t(3 + w) * lanes + lane] = s[w];
+        }
+    }
+}
+
 // Lock-in with the polar read-out fused on the same thread: `Lockin::process(..)` (src/lockin.rs:30-39)
 // followed by `Complex::<i32>::arg()` (src/complex.rs:254-256, MODE 0, i32) or `norm_sqr()`
 // (src/complex.rs:214-217, MODE 1, i64 with the wrapping sum of a release build).  Saves the 8 byte/sample
@@ -344,9 +462,9 @@ struct LockinPolarProc {
     static constexpr int LDS_WORDS = kLut + (MODE == 0 ? 32 : 0);  // cossin table, atan2 reciprocal table
     static constexpr int IN_DIV = 1;
     static constexpr bool LM_ONE_FORM = true;  // stream fall-back of the multi-wave kernel: one LaneMajor form is enough
-    // four cascaded second-order arms + atan2 next to the staged kernel's 128 staging registers: 116 B of scratch per
-    // thread (tools/check_scratch.py) — that one stays on the tile kernel
-    static constexpr bool LM_STAGED = !(MODE == 0 && N * K >= 8);
+    // three or four cascaded second-order arms + atan2 next to the staged kernel's 128 staging registers: 12 / 116 B of scratch per
+    // thread (tools/check_scratch.py) — those stay on the tile kernel
+    static constexpr bool LM_STAGED = !(MODE == 0 && N * K >= 6);
     static constexpr int COST = 110 + 80 * N * K + (MODE == 0 ? 80 : 10);
     using Params = LpParams;
     const uint32_t *lut;
@@ -518,6 +636,25 @@ int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int
     for (int i = 0; i < 5; i++) p.sec.ba[i] = cfg->deemph.ba[i];
     p.sec.frac = cfg->deemph.frac;
     p.sec.u = 0, p.sec.mn = INT32_MIN, p.sec.mx = INT32_MAX;
+    // FRAME_MAJOR: the discriminator on four front waves, the deemphasis biquad on a fifth (IDSP_DIAG=1 IDSP_FM_DISC_WAVES=0: the
+    // one-thread-per-lane stream kernel; = 3: three front waves)
+    // Up to 81920 lanes: beyond, the stream kernel has two waves per SIMD itself and fewer instructions per sample (no LDS hand-over,
+    // no second read of the previous row): 131072 lanes 1.40 ms against 1.52 (profiles/r03_perf_fm_disc.jsonl)
+    static const size_t forced = diag_size("IDSP_FM_DISC_WAVES", ~size_t(0));
+    const size_t nf = forced != ~size_t(0) ? forced : lanes <= 81920 ? 4 : 0;
+    if (layout == IDSP_FRAME_MAJOR && nf && frames >= 8) {
+        const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
+        if (nf == 3) {
+            note_kernel("fm_disc_waves_kernel<3>");
+            hipLaunchKernelGGL((fm_disc_waves_kernel<3>), dim3(grid), dim3(kWave * 4), 0, as_stream(stream), p, static_cast<uint32_t *>(state),
+                               reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, lanes, lanes);
+        } else {
+            note_kernel("fm_disc_waves_kernel<4>");
+            hipLaunchKernelGGL((fm_disc_waves_kernel<4>), dim3(grid), dim3(kWave * 5), 0, as_stream(stream), p, static_cast<uint32_t *>(state),
+                               reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, lanes, lanes);
+        }
+        return launch_status();
+    }
     return launch_stream<FmDiscProc>(p, state, reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, layout, as_stream(stream));
 }
 

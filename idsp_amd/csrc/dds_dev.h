@@ -177,28 +177,32 @@ __device__ __forceinline__ int32_t pair_swap(int32_t v) { return __builtin_amdgc
 // src/atan2.rs:6-82, all integer.  tab[0..16) = reciprocal bases, tab[16..32) = slopes.
 __device__ __forceinline__ uint32_t mul_q31(uint32_t x, uint32_t y) { return uint32_t((uint64_t(x) * uint64_t(y)) >> 31); }
 
+// `i32::saturating_neg` as one instruction (v_sub_i32 ... clamp)
+__device__ __forceinline__ int32_t sat_neg(int32_t v) { return __builtin_elementwise_sub_sat(int32_t(0), v); }
+// leading zero count with the hardware's defined result for 0 (0xffffffff: a shift by it uses the low five bits)
+__device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)
+{
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ int32_t atan2_dev(int32_t y, int32_t x, const uint32_t *tab)
 {
-    uint32_t k = 0;
-    if (y < 0) {
-        y = y == INT32_MIN ? INT32_MAX : -y;  // saturating_neg
-        k ^= 0xffffffffu;
-    }
-    if (x < 0) {
-        x = x == INT32_MIN ? INT32_MAX : -x;
-        k ^= 0x7fffffffu;
-    }
-    if (y > x) {
-        const int32_t t = y;
-        y = x;
-        x = t;
-        k ^= 0x3fffffffu;
-    }
-    // divi(y, x), y <= x: normalise x to [1, 2) in Q1.31, LUT reciprocal seed + one Newton step
-    uint32_t q = 0;
-    if (x != 0) {
-        const int shift = __builtin_clz(uint32_t(x));
-        const uint32_t yn = uint32_t(y) << shift, xn = uint32_t(x) << shift;
+    // octant unmap mask (src/atan2.rs:66-82): y < 0 -> ^ !0, x < 0 -> ^ i32::MAX, y > x -> ^ (i32::MAX >> 1); |v| with
+    // saturation is max(v, saturating_neg(v)).  Branch-free: 13 instructions where the three `if`s compiled to 20 with 64-bit
+    // compares on the halves of the products they came from (round 3, ISA of fm_disc_waves_kernel).
+    uint32_t k = uint32_t(y >> 31) ^ (uint32_t(x >> 31) >> 1);
+    y = y > sat_neg(y) ? y : sat_neg(y);
+    x = x > sat_neg(x) ? x : sat_neg(x);
+    if (y > x) k ^= 0x3fffffffu;
+    const int32_t lo = y < x ? y : x, hi = y < x ? x : y;
+    // divi(lo, hi), lo <= hi: normalise hi to [1, 2) in Q1.31, LUT reciprocal seed + one Newton step.  hi == 0 (then lo == 0) needs
+    // no branch: the shift count is 31, every operand 0 and q = 0 as in the reference's early return.
+    uint32_t q;
+    {
+        const uint32_t shift = ffbh_u32(uint32_t(hi)) & 31u;
+        const uint32_t yn = uint32_t(lo) << shift, xn = uint32_t(hi) << shift;
         constexpr int kFrac = 31 - kAtan2DiviDepth;
         const uint32_t rem = xn & ((1u << kFrac) - 1u);
         const uint32_t idx = (xn << 1) >> (1 + kFrac);

@@ -343,6 +343,21 @@ __device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint3
                  : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
                  : "memory");
 }
+// plain (cacheable) form: rows off the 64-byte grid, where neighbouring workgroups share lines (XCDC)
+__device__ __forceinline__ void glds16_plain(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                 : "memory");
+}
+#ifndef IDSP_XCDC_LOAD_NT
+#define IDSP_XCDC_LOAD_NT 1
+#endif
+#ifndef IDSP_XCDC_STORE_NT
+#define IDSP_XCDC_STORE_NT 1
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
@@ -492,7 +507,10 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
             const int g = wave + 4 * j;
             if (FULL || g < ns) {
                 const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * kFmBlock : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid4;
-                glds16(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
+                if constexpr (XCDC && !IDSP_XCDC_LOAD_NT)
+                    glds16_plain(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
+                else
+                    glds16(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
             }
         }
         if constexpr (RUN) xq += xstep;
@@ -511,7 +529,10 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
                     const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid4);
                     uint32_t *dst = RUN ? yq + (size_t(g / LPT) * yl + (g % LPT) * kFmBlock) * OW + h * kFmBlock
                                         : yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid4;
-                    __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst));
+                    if constexpr (XCDC && !IDSP_XCDC_STORE_NT)
+                        *reinterpret_cast<u32x4 *>(dst) = v4;
+                    else
+                        __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst));
                 }
             }
         }
@@ -1201,8 +1222,9 @@ __global__ __launch_bounds__(2 * kWave) void stream_frame_major_duo(
             for (int f = 0; f < T; f++) v[f] = tile[k & 1][f][lid];
 #pragma unroll
             for (int f = 0; f < T; f++) {
-                const Out o = p.step(prmB, v[f]);
-                if (active) nt_store<true>(yp + (k * T + f) * yl, o);
+                // (no `if (active)`: an idle thread of the last workgroup shadows lane `lanes - 1` — same input, same state, the same
+                // value to the same address — and a predicate per store is a branch per sample in the ISA)
+                nt_store<true>(yp + (k * T + f) * yl, p.step(prmB, v[f]));
             }
             lds_barrier();
         }

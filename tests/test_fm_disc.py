@@ -1,6 +1,10 @@
 """FM discriminator graph (examples/fm_disc.rs:25-50): CPU oracle vs the Python restatement, and the HIP
 path vs the oracle (bit-exact incl. state, continuation, both layouts).  The reference's own test of the
 graph (corr / gain / rms bounds) is in tests/_kat_cases.py::case_fm_disc_tracks_known_modulation."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -11,6 +15,7 @@ from tests._backends import GpuBackend, OracleBackend
 
 FM, LM = H.FM, H.LM
 I32_MIN, I32_MAX = -(1 << 31), (1 << 31) - 1
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _cfg(rng):
@@ -70,3 +75,40 @@ def test_fm_disc_gpu_parity(gpu, layout):
     bad = _cfg(rng)
     bad.deemph.frac = 32
     assert gb.cfgcall("fm_disc_i32", bad, np.zeros((7, 1), np.uint32), np.zeros(2, np.int32), (1,), np.int32, 1, 1, LM)[0] == -1
+
+
+FORCED_WAVES = os.environ.get("IDSP_FM_DISC_WAVES") if os.environ.get("IDSP_DIAG") == "1" else None
+
+
+@pytest.mark.gpu
+def test_fm_disc_role_waves_frame_major(gpu):
+    """`fm_disc_waves_kernel` (idsp_amd/csrc/dds.hip): the discriminator of a tile's frames on four front waves, the deemphasis
+    biquad on a fifth.  Frame counts around the 32-frame tiles and the 8-frame wave shares, lanes around the 64-lane workgroups,
+    continuation across calls (the state's `prev` feeds frame 0), lanes that start without a previous sample."""
+    ob, gb = OracleBackend(), GpuBackend()
+    rng = np.random.default_rng(72)
+    for lanes, frames in [(64, 8), (1, 9), (130, 31), (64, 32), (65, 33), (200, 63), (128, 64), (70, 95), (64, 129), (4096, 70), (40960, 35)]:
+        cfg = _cfg(rng)
+        init = np.zeros((7, lanes), np.uint32)
+        init[0, ::3] = 1
+        init[1:] = rng.integers(0, 1 << 32, size=(6, lanes), dtype=np.uint64).astype(np.uint32)
+        so, sg = init.copy(), init.copy()
+        for part in range(2):
+            x = _x(rng, lanes * frames)
+            rco, yo = ob.cfgcall("fm_disc_i32", cfg, so, x, (lanes * frames,), np.int32, lanes, frames, FM)
+            rcg, yg = gb.cfgcall("fm_disc_i32", cfg, sg, x, (lanes * frames,), np.int32, lanes, frames, FM)
+            assert rco == 0 and rcg == 0, H.engine().err()
+            k = gpu.fn["last_kernel"]().decode()
+            assert k.startswith("stream_frame_major" if FORCED_WAVES == "0" else f"fm_disc_waves_kernel<{FORCED_WAVES or 4}>"), k
+            assert np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames, part)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", ["3", "0"])
+def test_fm_disc_other_forms(gpu, waves):
+    """three front waves, and the one-thread-per-lane stream kernel the role waves replaced (diagnostic switch, own process)"""
+    if FORCED_WAVES is not None:
+        pytest.skip("already inside a forced run")
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_FM_DISC_WAVES=waves)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_fm_disc.py", "-m", "gpu", "-x", "-q"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

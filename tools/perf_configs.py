@@ -412,8 +412,12 @@ def main():
         dds(65536, 4096, FM, it, "dds")
         cossin(1 << 27, it, "cossin")
         atan2(1 << 27, it, "atan2")
+    if want("c4") or want("fm"):
         fm_disc(65536, 4096, FM, it, "fm")
         fm_disc(65536, 4096, LM, it, "fm")
+        if sel and "fm" in sel:
+            for lanes in (8192, 16384, 32768, 131072):
+                fm_disc(lanes, 4096, FM, it, "fm")
 
 
 if __name__ == "__main__":
