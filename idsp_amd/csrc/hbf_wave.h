@@ -485,7 +485,14 @@ __global__ __launch_bounds__(kW) IDSP_HBF_WPE_ATTR void hbf_dec_wave(uint32_t *s
 // at 16 lanes.  Two workgroup barriers per chunk; with 16 lanes (one workgroup per CU in lockstep) the
 // barriers cost what the traffic saved (1.45 ms), 4 lanes per workgroup (4 independent workgroups per CU)
 // measured best: 1.23-1.29 ms vs 1.37-1.46 ms for the wave-per-lane kernel at C3.
-constexpr int kBlkLanes = 4;
+// Round 3 (tools/exp_hbf.sh with VARIANTS=BLK8/BLK2/..., profiles/r03_exp_hbf_blk.jsonl): 8 lanes per workgroup 1.85 ms, 2 lanes
+// 1.11, 4 lanes 1.08 on the same box; padding the per-lane LDS regions so that the cooperative stage-0 writes of the four
+// lanes fall 16 banks apart (they are 4 apart: 2116 words per region) changed nothing (1.0818 ms both ways) — the
+// bank-conflict cycles of profiles/r03_c3_pmc.csv are not what bounds this kernel.
+#ifndef IDSP_HBF_BLK_LANES
+#define IDSP_HBF_BLK_LANES 4
+#endif
+constexpr int kBlkLanes = IDSP_HBF_BLK_LANES;
 
 template <class C>
 __global__ __launch_bounds__(kBlkLanes *kW) void hbf_dec_block_fm(uint32_t *st, const float *x, float *y, const size_t lanes,
