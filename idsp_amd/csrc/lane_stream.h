@@ -463,6 +463,16 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     if (IDSP_LDS_ORDER == 2) rr_ = (k_ + (blockIdx.x >> 5) * ((rounds_ + 7) / 8)) % rounds_;
     if (IDSP_LDS_ORDER == 3) rr_ = (k_ + (blockIdx.x >= gridDim.x / 2 ? rounds_ / 2 : 0)) % rounds_;
     if (IDSP_LDS_ORDER == 4) rr_ = (blockIdx.x & 1) ? rounds_ - 1 - k_ : k_;
+    // 5: as 3 with an ODD panel offset from 8 rounds up; 6: four quarter grids at offsets g (rounds / 4) + g; 7: eight groups at g (rounds / 8) + g
+    if (IDSP_LDS_ORDER == 5) rr_ = (k_ + (blockIdx.x >= gridDim.x / 2 ? rounds_ / 2 + (rounds_ >= 8 ? 1 : 0) : 0)) % rounds_;
+    if (IDSP_LDS_ORDER == 6) {
+        const size_t g_ = size_t(blockIdx.x) * 4 / gridDim.x;
+        rr_ = rounds_ >= 4 ? (k_ + g_ * (rounds_ / 4) + (rounds_ >= 8 ? g_ : 0)) % rounds_ : (k_ + (g_ >= 2 ? rounds_ / 2 : 0)) % rounds_;
+    }
+    if (IDSP_LDS_ORDER == 7) {
+        const size_t g_ = size_t(blockIdx.x) * 8 / gridDim.x;
+        rr_ = rounds_ >= 8 ? (k_ + g_ * (rounds_ / 8) + (rounds_ >= 16 ? g_ : 0)) % rounds_ : (k_ + (g_ >= 4 ? rounds_ / 2 : 0)) % rounds_;
+    }
     // XCDC: workgroups are dealt to the XCDs round-robin (blockIdx % 8); give XCD j the j-th contiguous eighth of the blocks
     // (XCD j hosts the workgroups blockIdx = j, j + 8, ...: grid / 8 of them, one more on the first grid % 8 XCDs)
     const size_t q_ = gridDim.x / 8, r_ = gridDim.x % 8, j_ = blockIdx.x % 8;
