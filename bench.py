@@ -635,7 +635,9 @@ def rank_main(args, engine_factory=HipEngine):
     backend = os.environ.get("IDSP_BENCH_BACKEND") or ("gloo" if shared else "nccl")
     dist = None
     rccl_ranks = 1
-    if world > 1:
+    # IDSP_BENCH_FORCE_DIST=1: join a process group even as the only rank (under torchrun with one process) — the way to run the
+    # RCCL code path (init with device_id, device-tensor reductions, barriers) on a one-GPU box
+    if world > 1 or os.environ.get("IDSP_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         if backend == "nccl":
