@@ -88,3 +88,30 @@ def test_one_to_three_lanes_in_all(gpu):
     op, cfg, n, words, dt = lds_cases(rng)[0]
     FMS.run_case(gpu, op, cfg, n, words, dt, rng, 3, 63, 3, False)  # fewer than 64 frames: the register-window kernel
     assert kernel_of(gpu).startswith("stream_frame_major<"), kernel_of(gpu)
+
+
+def test_bylane_banks_on_lane_counts_that_are_not_multiples_of_four(gpu):
+    """`ByLane` banks (dsp-process/src/compose.rs:363-390): the last lanes % 4 lanes read THEIR columns of the coefficient and
+    state planes (plane pitch = the call's lane count) on the few-lanes kernel."""
+    from tests import _bylane_cases as B
+    from tests._backends import GpuBackend, OracleBackend
+
+    ob, gb = OracleBackend(), GpuBackend()
+    rng = np.random.default_rng(316)
+    for i, (op, dtype, words, clamp) in enumerate(B.OPS):
+        if np.dtype(dtype).itemsize != 4:
+            continue
+        for n, lanes, frames in ((1, 8195, 37), (2, 65537, 18), (1, 3, 300), (2, 41003, 33)):
+            if (i + lanes) % 2:
+                continue
+            frac = 29 if dtype == np.int32 else None
+            coef = B.coef_planes(rng, dtype, n, lanes, clamp, frac or 0)
+            x = B.samples(rng, dtype, lanes * frames)
+            init = B.init_state(rng, dtype, words * n, lanes)
+            so, sg = init.copy(), init.copy()
+            rco, yo = ob.bylane(op, coef, frac, n, so, x.copy(), lanes, frames, B.FM)
+            rcg, yg = gb.bylane(op, coef, frac, n, sg, x.copy(), lanes, frames, B.FM)
+            assert rco == 0 and rcg == 0, (op, gpu.err())
+            k = kernel_of(gpu)
+            assert k.endswith(ODD) or k.startswith("stream_frame_major_few<"), (op, n, lanes, k)
+            assert np.array_equal(B.bits(yo), B.bits(yg)) and np.array_equal(so, sg), (op, n, lanes)
