@@ -114,13 +114,13 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     // chains and nothing else (14 VALU instructions per frame for [Lowpass<2>; 2]); with register prefetch the input lives in
     // the arm waves' registers, so the rows carry cos / sin and the arm multiplies.
 #ifndef IDSP_LW_MIXR
-#define IDSP_LW_MIXR 0
+#define IDSP_LW_MIXR 1
 #endif
     constexpr bool MIXR = IDSP_LW_MIXR && (DMA || LMD);
     constexpr int P = W - 2, C = B / P;  // read-out waves; each takes frames r C .. r C + C - 1 of a batch
     constexpr int RS = B + 4;            // row pitch in words
     static_assert(B % P == 0 && B % 8 == 0 && (C == 2 || C % 4 == 0), "batch splits evenly over the read-out waves, into 4-row DMA groups per arm wave, into vectors");
-    __shared__ __attribute__((aligned(16))) uint32_t ctab[kCosWideWords];
+    __shared__ __attribute__((aligned(16))) uint32_t ctab[kCosCircleWords];
     __shared__ uint32_t tab[32];
     // rows[buffer][I / Q][lane]: batch n lives in buffer n % 3 — written by the read-out waves (LO or mixed samples) during
     // interval n - 1, turned into the arm outputs IN PLACE by the arm waves during interval n, read back by the read-out waves
@@ -129,15 +129,39 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     // FM DMA: [slot][frame][lane]; LM DMA: kLwRing slots of 64 lanes x 128 bytes (two batches), rows permuted and pieces swizzled
     __shared__ __attribute__((aligned(16))) int32_t xs[DMA ? kLwFmRing : LMD ? 2 * kLwRing : 1][B * kWave];
     // wave-uniform role, pinned to SGPRs: everything derived from it (row pointers of the output, LDS slots) is scalar
-    const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave), lid = int(threadIdx.x) % kWave;
+    // Roles by SIMD.  The waves of a workgroup land on the four SIMDs of its CU one each (in the order 0, 2, 1, 3 from a start
+    // that moves from workgroup to workgroup: HW_ID dumps of tools/exp_lockin_trace.hip), and with the octant logic of cossin in
+    // the table an arm wave issues more than twice what a read-out wave does (~290 against ~125 instructions per 16-frame
+    // interval, and its chain is latency-bound on top).  With roles by wave index the arm waves of the two workgroups that share a
+    // CU at the C4 lane counts (blockIdx b and b + 256: dispatch order) always met on one SIMD.  So the role follows the SIMD the
+    // wave finds itself on: even classes put their arms on SIMDs 0 and 1, odd classes on 2 and 3.  If the four waves are not on
+    // four different SIMDs (never observed) the wave index decides, as in the 6-wave form.
+#ifndef IDSP_LW_ROT
+#define IDSP_LW_ROT 1
+#endif
+    __shared__ uint32_t wave_simd[4];
+    const unsigned prio_class = (blockIdx.x >> 8) & 1u;
+    const int lid = int(threadIdx.x) % kWave;
+    int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave);
+    if constexpr (IDSP_LW_ROT && W == 4) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const uint32_t simd = (hw >> 4) & 3u;
+        if (lid == 0) wave_simd[w] = simd;
+        __syncthreads();
+        const uint32_t seen = (1u << wave_simd[0]) | (1u << wave_simd[1]) | (1u << wave_simd[2]) | (1u << wave_simd[3]);
+        // SIMDs 0 / 2 and 1 / 3 for the arms: with both arm waves on SIMDs 0 and 1 a workgroup alone on its CU ran 7 % slower than
+        // with the hardware's own order (IDSP_LW_ROT=2 is that pairing)
+        const uint32_t pos = IDSP_LW_ROT == 2 ? simd : ((simd & 1u) << 1) | (simd >> 1);
+        if (__builtin_amdgcn_readfirstlane(int(seen)) == 0xF) w = int(pos ^ (prio_class << 1));
+    }
     const bool arm_wave = w < 2;
     const int r = arm_wave ? w : w - 2;  // arm waves: I / Q; read-out waves: frame group
     const size_t lane = size_t(blockIdx.x) * kWave + lid;
     const bool active = lane < lanes;
     const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
-    fill_cossin_wide(ctab, threadIdx.x, W * kWave);
+    fill_cossin_circle(ctab, threadIdx.x, W * kWave);
     if (MODE == MODE_ARG && threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
-    const char *const cmine = cossin_wide_base(ctab, lid);
     const uint32_t acc0 = st[la], inc = st[lanes + la];
     LpBank<N, K> bank;
     if (arm_wave) bank.load(st, lanes, la, 2 + (r ? 2 * N * K : 0));
@@ -231,9 +255,18 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
             }
         }
         LW_T(0);
+        // all table reads of the batch first, behind one wait (see lockin_stages_kernel)
+        uint32_t pj[C];
+        CosCircleEntry ent[C];
 #pragma unroll
         for (int j = 0; j < C; j++) {
-            const Cplx lo = cossin_wide(phase + inc * uint32_t(r * C + j + 1), cmine);
+            pj[j] = phase + inc * uint32_t(r * C + j + 1);
+            ent[j] = cossin_circle_fetch(pj[j], ctab);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            const Cplx lo = cossin_circle_finish(pj[j], ent[j]);
             re[j] = MIXR ? __mulhi(lo.re, xv[j]) : lo.re;
             im[j] = MIXR ? __mulhi(lo.im, xv[j]) : lo.im;
         }
@@ -401,7 +434,6 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #ifndef IDSP_LW_PRIO
 #define IDSP_LW_PRIO 3
 #endif
-    const unsigned prio_class = (blockIdx.x >> 8) & 1u;
     auto interval = [&](size_t n, int nb, auto full, auto slot_tag) {
         if constexpr (IDSP_LW_PRIO != 0) {
             if ((unsigned(n) ^ prio_class) & 1u)
@@ -463,6 +495,203 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One wave per cascade STAGE (round 3, later).  What bounds lockin_waves_kernel at the C4 shape is not the number of instructions
+// but how fast ONE wave issues a dependent chain: an arm wave runs `[Lowpass<N>; 2]` at ~10 cycles per instruction (a SIMD
+// could issue one every 4-5 with three or four waves to pick from), two workgroups per CU are two waves per SIMD, and an
+// interval of 16 frames takes 1.4 us where the instruction count needs 0.8.  Here the two stages of each arm are two waves one
+// batch apart (stage 1 of batch n - 1 beside stage 0 of batch n: half the chain per wave), the read-out waves also apply the
+// mixer, R = 4 read-out waves per lane group take four frames of a batch each, and G = 1 or 2 lane groups of 64 share one workgroup,
+// its cossin table and its barrier (two 6- or 8-wave workgroups do not share a CU on this hardware whatever the occupancy API says:
+// the second starts when the first has ended).  With G = 2: 8 arm-stage waves + 8 read-out waves on a CU, four per SIMD — by the
+// hardware's round-robin placement every SIMD gets two arm-stage waves (~135 instructions per interval each) and two read-out waves.  A batch lives in one of three
+// row buffers: mixed by the read-out waves during interval n - 1, stage 0 in place during n, stage 1 in place during n + 1,
+// turned into output elements during n + 2 (and overwritten with batch n + 3 by the wave that just read it).  Input by LDS-DMA as in the kernel above: every arm-stage wave moves 4 of the 16 rows
+// of a batch, four batches ahead.  FrameMajor, whole 16-frame batches, whole 64 G-lane blocks, K = 2 (the launcher falls back to
+// the kernel above for everything else).
+constexpr int kLsB = 16, kLsRing = 5, kLsAhead = 4;
+
+template <int N, int MODE, int G, int R = 2>
+__global__ __launch_bounds__((4 + R) * G *kWave) void lockin_stages_kernel(const LpParams prm, uint32_t *st, const int32_t *x,
+                                                                      typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames)
+{
+    using Out = typename LwOut<MODE>::type;
+    constexpr int B = kLsB, RS = B + 4, C = B / R, W = (4 + R) * G;  // R read-out waves per lane group, C frames of a batch each
+    __shared__ __attribute__((aligned(16))) uint32_t ctab[kCosCircleWords];
+    __shared__ uint32_t tab[32];
+    __shared__ __attribute__((aligned(16))) int32_t rows[G][3][2][kWave * RS];
+    __shared__ __attribute__((aligned(16))) int32_t xs[G][kLsRing][B * kWave];
+    const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave), lid = int(threadIdx.x) % kWave;
+    // arm-stage waves: wv = 4 g + 2 r + k (lane group, I / Q, stage); read-out waves: wv = 4 G + R g + h (lane group, part of the batch)
+    const bool arm_wave = wv < 4 * G;
+    const int g = arm_wave ? wv >> 2 : (wv - 4 * G) / R;
+    const int r = (wv >> 1) & 1, k = wv & 1, q = wv & 3, h = arm_wave ? 0 : (wv - 4 * G) % R;
+    const size_t lane0 = (size_t(blockIdx.x) * G + size_t(g)) * kWave, lane = lane0 + size_t(lid);
+    fill_cossin_circle(ctab, threadIdx.x, W * kWave);
+    if (MODE == MODE_ARG && threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
+    int64_t s[N];
+    uint32_t acc0 = 0, inc = 0;
+    const int word0 = 2 + r * 4 * N + k * 2 * N;  // this stage's LowpassState<N> inside [acc, step, I arm [K][N] i64, Q arm]
+    if (arm_wave) {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            s[j] = int64_t(uint64_t(st[size_t(word0 + 2 * j) * lanes + lane]) | (uint64_t(st[size_t(word0 + 2 * j + 1) * lanes + lane]) << 32));
+    } else {
+        acc0 = st[lane], inc = st[lanes + lane];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see lockin_waves_kernel
+    const uint32_t lane32 = uint32_t(lane);
+    // read-out wave h evaluates the LO of frames C h + 1 .. C h + C past the accumulator; `ph` = accumulator + C h steps
+    uint32_t ph = acc0 + inc * uint32_t(h * C);
+    const uint32_t inc_rest = inc * uint32_t(B - C);
+    const uint32_t dma_off = uint32_t(lid / 16) * uint32_t(lanes) * 4u + uint32_t(lid % 16) * 16u;
+    int slot_issue = 0, slot_read = 0;
+    auto dma = [&](size_t n) {
+        const int r0 = 4 * q;  // this wave's 4 rows of the batch
+        const uint32_t dst = uint32_t(reinterpret_cast<uintptr_t>(&xs[g][slot_issue][r0 * kWave]));
+        const size_t row0 = n * B + size_t(r0);
+        if (row0 + 4 <= frames) {
+            glds16_s(uniform_ptr(x + row0 * lanes + lane0), dma_off, dst);
+        } else {  // past the end: never consumed, but every interval issues exactly one request per arm-stage wave
+            size_t row = row0 + size_t(lid / 16);
+            row = row < frames ? row : frames - 1;
+            glds16(x + row * lanes + lane0 + size_t(lid % 16) * 4, dst);
+        }
+        slot_issue = slot_issue + 1 == kLsRing ? 0 : slot_issue + 1;
+    };
+    auto lo_stage = [&](int dstb) {
+        int32_t xv[C], re[C], im[C];
+#pragma unroll
+        for (int j = 0; j < C; j++) xv[j] = xs[g][slot_read][(h * C + j) * kWave + lid];
+        slot_read = slot_read + 1 == kLsRing ? 0 : slot_read + 1;
+        // all table reads of the batch first, behind one wait: an evaluation is two LDS reads and nine VALU instructions, and
+        // evaluated one after the other each pays the LDS round trip
+        uint32_t pj[C];
+        CosCircleEntry ent[C];
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            ph += inc;
+            pj[j] = ph;
+            ent[j] = cossin_circle_fetch(ph, ctab);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            const Cplx lo = cossin_circle_finish(pj[j], ent[j]);
+            re[j] = __mulhi(lo.re, xv[j]);  // src/lockin.rs:34-37
+            im[j] = __mulhi(lo.im, xv[j]);
+        }
+        ph += inc_rest;
+        row_store<C>(&rows[g][dstb][0][lid * RS + h * C], re);
+        row_store<C>(&rows[g][dstb][1][lid * RS + h * C], im);
+    };
+    auto element = [&](int32_t re, int32_t im) -> Out {
+        if constexpr (MODE == MODE_IQ)
+            return Cplx{re, im};
+        else if constexpr (MODE == MODE_ARG)
+            return atan2_dev(im, re, tab);
+        else
+            return int64_t(uint64_t(int64_t(re) * re) + uint64_t(int64_t(im) * im));
+    };
+    auto out_stage = [&](size_t f0, int srcb) {
+        int32_t re[C], im[C];
+        row_load<C>(&rows[g][srcb][0][lid * RS + h * C], re);
+        row_load<C>(&rows[g][srcb][1][lid * RS + h * C], im);
+        char *row = reinterpret_cast<char *>(uniform_ptr(y + (f0 + size_t(h * C)) * lanes));
+        const uint32_t off = lane32 * uint32_t(sizeof(Out));
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            nt_store<true>(reinterpret_cast<Out *>(row + size_t(off)), element(re[j], im[j]));
+            row += lanes * sizeof(Out);
+        }
+    };
+    auto arm_stage = [&](int buf) {
+        int32_t v[B];
+        int32_t *row = &rows[g][buf][r][lid * RS];
+        row_load<B>(row, v);
+#pragma unroll
+        for (int b = 0; b < B; b++) v[b] = lowpass_step<N>(prm.k[k], s, v[b]);
+        row_store<B>(row, v);
+    };
+    const size_t nb = frames / B;
+    if (arm_wave) {
+        for (int n = 0; n < kLsAhead; n++) dma(size_t(n));
+        wait_vmcnt<kLsAhead - 2>();  // batches 0 and 1 have landed
+    }
+    __syncthreads();  // tables, first input batches
+    if (!arm_wave) lo_stage(0);
+    __syncthreads();
+    // Three row buffers: batch n sits in buffer n % 3.  A read-out wave turns ITS eight frames of batch n - 2 into output elements
+    // and then writes the mixed samples of batch n + 1 over exactly those words (same buffer, no other wave touches them).
+    int cur = 0;  // n % 3
+    auto next3 = [](int b) { return b == 2 ? 0 : b + 1; };
+    auto prev3 = [](int b) { return b == 0 ? 2 : b - 1; };
+    for (size_t n = 0; n < nb + 2; n++) {
+        if (arm_wave) {
+            dma(n + kLsAhead);
+            if (k == 0) {
+                if (n < nb) arm_stage(cur);
+            } else {
+                if (n >= 1 && n <= nb) arm_stage(prev3(cur));
+            }
+            wait_vmcnt<kLsAhead - 2>();  // batches up to n + 2 have landed; the read-out waves mix batch n + 2 during the next interval
+        } else {
+            if (n >= 2) out_stage((n - 2) * B, next3(cur));
+            if (n + 1 < nb) lo_stage(next3(cur));
+        }
+        __syncthreads();
+        cur = next3(cur);
+    }
+    if (arm_wave) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            st[size_t(word0 + 2 * j) * lanes + lane] = uint32_t(uint64_t(s[j]));
+            st[size_t(word0 + 2 * j + 1) * lanes + lane] = uint32_t(uint64_t(s[j]) >> 32);
+        }
+    } else if (h == 0) {
+        st[lane] = acc0 + inc * uint32_t(frames);
+    }
+}
+
+// Which launches the stage-wave kernel takes (0 = none, else lane groups per workgroup): whole 64-lane groups, whole batches,
+// aligned rows, K = 2.  Measured at 4096 frames against the 4- / 6-wave kernel with the same table cossin and roles by SIMD
+// (tools/exp_lockin_stages.hip, profiles/r03_exp_lockin_stages*.jsonl): `Complex<i32>` / `norm_sqr` read-out 0.207 against 0.232 ms
+// up to 16384 lanes (one workgroup per CU or fewer: eight waves per 64 lanes instead of four) but 0.345 against 0.317 at 32768 and
+// 0.64 against 0.57 at 49152, so those take it up to 16384 lanes; the `arg` read-out (atan2 on the read-out waves) 0.337 / 0.465 /
+// 0.93 against 0.384 / 0.51 / 1.16 ms at 16384 / 32768 / 65536 lanes and level at 131072, so it takes it up to 98304 lanes.
+// IDSP_DIAG switches: IDSP_LOCKIN_NO_STAGES=1 never, IDSP_LOCKIN_STAGE_GROUPS=1 / 2 always (when the shape allows).
+inline int lockin_stage_groups(const void *x, size_t lanes, size_t frames, int layout, int cascade, bool heavy_readout)
+{
+    static const bool off = diag_env("IDSP_LOCKIN_NO_STAGES") != nullptr;
+    static const int forced = [] {
+        const char *e = diag_env("IDSP_LOCKIN_STAGE_GROUPS");
+        return e ? atoi(e) : 0;
+    }();
+    if (off || layout != IDSP_FRAME_MAJOR || cascade != 2 || frames == 0 || frames % kLsB != 0 || lanes == 0 || lanes % kWave != 0 ||
+        reinterpret_cast<uintptr_t>(x) % 16 != 0)
+        return 0;
+    const bool pairs = lanes % (2 * kWave) == 0;
+    if (forced == 1 || (forced == 2 && pairs)) return forced;
+    if (lanes <= 16384) return 1;
+    return heavy_readout && pairs && lanes <= 98304 ? 2 : 0;
+}
+
+template <int MODE, int N>
+int launch_lockin_stages(const LpParams &p, void *state, const int32_t *x, void *yv, size_t lanes, size_t frames, int groups, hipStream_t s)
+{
+    using Out = typename LwOut<MODE>::type;
+    uint32_t *st = static_cast<uint32_t *>(state);
+    Out *y = static_cast<Out *>(yv);
+    if (groups == 2) {
+        note_kernel("lockin_stages_kernel[16 waves per 128 lanes]");
+        hipLaunchKernelGGL((lockin_stages_kernel<N, MODE, 2, 4>), dim3(unsigned(lanes / (2 * kWave))), dim3(16 * kWave), 0, s, p, st, x, y, lanes, frames);
+    } else {
+        note_kernel("lockin_stages_kernel[8 waves per 64 lanes]");
+        hipLaunchKernelGGL((lockin_stages_kernel<N, MODE, 1, 4>), dim3(unsigned(lanes / kWave)), dim3(8 * kWave), 0, s, p, st, x, y, lanes, frames);
+    }
+    return launch_status();
+}
+
 template <int MODE, int N, int K, int IN, int B>
 int launch_lockin_waves_in(const LpParams &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
                            size_t frames, int waves, hipStream_t s)
@@ -483,6 +712,10 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
     using Out = typename LwOut<MODE>::type;
     uint32_t *st = static_cast<uint32_t *>(state);
     Out *y = static_cast<Out *>(yv);
+    if constexpr (K == 2) {
+        if (const int groups = lockin_stage_groups(x, lanes, frames, layout, K, MODE == MODE_ARG))
+            return launch_lockin_stages<MODE, N>(p, state, x, yv, lanes, frames, groups, s);
+    }
     static const bool no_dma = diag_env("IDSP_LOCKIN_NO_DMA") != nullptr;
     // 16-frame batches halve the barriers per frame: 0.37 -> 0.35 ms (Complex<i32>), 0.61 -> 0.59 ms (arg) at 32768 lanes x 4096
     // frames, but 1.06 -> 1.19 ms (arg) at 65536 lanes, where the longer intervals cost more than the barriers

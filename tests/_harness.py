@@ -77,6 +77,9 @@ class Engine:
     def err(self):
         return self.fn["last_error"]().decode()
 
+    def last_kernel(self):
+        return self.fn["last_kernel"]().decode()
+
     def stream(self, name, cfg, n, state, x, y, lanes, frames, layout, stream=None):
         return self.fn[name](C.cast(cfg, C.c_void_p) if cfg is not None else None, n, _ptr(state), _ptr(x), _ptr(y),
                              lanes, frames, layout, stream)

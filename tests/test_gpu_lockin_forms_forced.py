@@ -12,13 +12,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FORMS = [dict(IDSP_LOCKIN_WAVES="6", IDSP_LOCKIN_B="16"), dict(IDSP_LOCKIN_WAVES="6", IDSP_LOCKIN_B="8"), dict(IDSP_LOCKIN_WAVES="4", IDSP_LOCKIN_B="8"),
-         dict(IDSP_LOCKIN_WAVES="4", IDSP_LOCKIN_B="16"), dict(IDSP_LOCKIN_NO_DMA="1"), dict(IDSP_LOCKIN_NO_DMA="1", IDSP_LOCKIN_WAVES="6")]
+# IDSP_LOCKIN_NO_STAGES: the stage-wave kernel (tests/test_gpu_lockin_stages.py) would otherwise take the K = 2 shapes of these suites
+_NS = dict(IDSP_LOCKIN_NO_STAGES="1")
+FORMS = [dict(_NS, IDSP_LOCKIN_WAVES="6", IDSP_LOCKIN_B="16"), dict(_NS, IDSP_LOCKIN_WAVES="6", IDSP_LOCKIN_B="8"), dict(_NS, IDSP_LOCKIN_WAVES="4", IDSP_LOCKIN_B="8"),
+         dict(_NS, IDSP_LOCKIN_WAVES="4", IDSP_LOCKIN_B="16"), dict(_NS, IDSP_LOCKIN_NO_DMA="1"), dict(_NS, IDSP_LOCKIN_NO_DMA="1", IDSP_LOCKIN_WAVES="6")]
 
 
-@pytest.mark.parametrize("form", FORMS, ids=lambda f: ",".join(f"{k[12:]}={v}" for k, v in f.items()))
+@pytest.mark.parametrize("form", FORMS, ids=lambda f: ",".join(f"{k[12:]}={v}" for k, v in f.items() if k != "IDSP_LOCKIN_NO_STAGES"))
 def test_lockin_suites_on_a_forced_form(gpu, form):
-    if os.environ.get("IDSP_LOCKIN_WAVES") or os.environ.get("IDSP_LOCKIN_NO_DMA"):
+    if os.environ.get("IDSP_LOCKIN_WAVES") or os.environ.get("IDSP_LOCKIN_NO_DMA") or os.environ.get("IDSP_LOCKIN_NO_STAGES"):
         pytest.skip("already inside a forced run")
     env = dict(os.environ, IDSP_DIAG="1", **form)
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_lockin_fuzz.py", "tests/test_gpu_parity.py", "-m", "gpu", "-x", "-q", "-k", "lockin"],

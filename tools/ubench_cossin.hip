@@ -200,6 +200,16 @@ struct V6 : V2 {
     }
 };
 
+// ---- V7: the octant logic in the table (dds_dev.h cossin_circle): 1024 x 24-byte entries indexed by the top ten phase
+//          bits, each output component the high word of one v_mad_i64_i32 ----------------------------------------------
+struct V7 {
+    static constexpr int kLdsWords = kCosCircleWords;
+    static __device__ void fill(uint32_t *sh, int tid, int n) { fill_cossin_circle(sh, tid, n); }
+    const uint32_t *tab;
+    __device__ void init(const uint32_t *sh, int) { tab = sh; }
+    __device__ __forceinline__ Cplx eval(uint32_t phase) const { return cossin_circle(phase, tab); }
+};
+
 template <class V>
 __global__ __launch_bounds__(256) void k_time(uint32_t *out, uint32_t seed)
 {
@@ -241,8 +251,10 @@ int run(const char *name, uint32_t *out, Cplx *va, Cplx *vb, int cus, double ghz
     // exactness: 2^24 phases at an odd stride (every octant, every table entry, every interpolation offset class) + the edges
     const uint32_t n = 1u << 24;
     size_t bad = 0;
-    for (uint32_t start : {0u, 0x1fffff00u, 0x3fffff00u, 0x7fffff00u, 0xffffff00u, 12345u}) {
-        const uint32_t stride = start == 12345u ? 257u : 1u, cnt = start == 12345u ? n : 512u;
+    for (uint32_t start : {0u, 0x1fffff00u, 0x3fffff00u, 0x5fffff00u, 0x7fffff00u, 0x9fffff00u, 0xbfffff00u, 0xdfffff00u, 0xffffff00u, 0x003fff00u,
+                           0x203fff00u, 12345u, 777u, 99u}) {
+        const bool sweep = start == 12345u || start == 777u || start == 99u;
+        const uint32_t stride = start == 12345u ? 257u : start == 777u ? 255u : start == 99u ? 65521u : 1u, cnt = sweep ? n : 512u;
         hipLaunchKernelGGL((k_values<V0>), dim3(1024), dim3(256), size_t(V0::kLdsWords) * 4, 0, va, start, stride, cnt);
         hipLaunchKernelGGL((k_values<V>), dim3(1024), dim3(256), lds, 0, vb, start, stride, cnt);
         CHK(hipDeviceSynchronize());
@@ -296,5 +308,6 @@ int main()
     run<V4>("V4 8 B pre-shifted entries x32, mul_hi", out, va, vb, cus, ghz);
     run<V5>("V5 = V2 + v_bitop3 selects, xor masks", out, va, vb, cus, ghz);
     run<V6>("V6 = V5 with masks from the octant word", out, va, vb, cus, ghz);
+    run<V7>("V7 octant logic in a 24 KiB table, 2 mad64", out, va, vb, cus, ghz);
     return 0;
 }
