@@ -38,6 +38,9 @@ constexpr int kLwRing = 3, kLwAhead = 2;
 #define IDSP_LW_OUT_GROUP 1
 #endif
 constexpr int kLwOutGroup = IDSP_LW_OUT_GROUP;  // LaneMajor: batches a read-out thread stores together
+#ifndef IDSP_LW_LM_LINES
+#define IDSP_LW_LM_LINES 1  // LaneMajor, 8-byte elements: whole 128-byte lines per store instruction
+#endif
 
 template <int MODE>
 struct LwOut {
@@ -292,7 +295,25 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     // ---- read-out waves, second half: the arm outputs of the batch that starts at frame f0 (buffer srcb) become output elements.
     // `slot` (static): position of the batch inside its output group; `flush`: last batch of the call
     auto out_stage = [&](size_t f0, int srcb, int nb, auto full, auto slot_tag, bool flush) {
-        if constexpr (LM) {
+        if constexpr (LM && sizeof(Out) == 8 && P == 2 && B == 16 && kLwOutGroup == 1 && IDSP_LW_LM_LINES) {
+            // Whole 128-byte lines per store instruction (round 3, later): a batch of 8-byte elements is one line per lane.  Read-out
+            // wave r takes lanes 32 r .. 32 r + 31; in instruction v thread t holds frames 2 (t % 8), 2 (t % 8) + 1 of lane
+            // 32 r + 8 v + t / 8, so the 8 threads of a lane write its line and one instruction writes 8 whole lines (the form below
+            // leaves two 16-byte pieces in each of 32 lines per instruction).  The arm outputs come out of the rows as 8-byte reads.
+            const int piece = lid % 8;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int ll = r * 32 + v * 8 + lid / 8;
+                const size_t gl = size_t(blockIdx.x) * kWave + size_t(ll);
+                int32_t re[2], im[2];
+                row_load<2>(&rows[srcb][0][ll * RS + 2 * piece], re);
+                row_load<2>(&rows[srcb][1][ll * RS + 2 * piece], im);
+                const uint64_t u0 = __builtin_bit_cast(uint64_t, element(re[0], im[0])), u1 = __builtin_bit_cast(uint64_t, element(re[1], im[1]));
+                if (gl < lanes)
+                    __builtin_nontemporal_store(u32x4{uint32_t(u0), uint32_t(u0 >> 32), uint32_t(u1), uint32_t(u1 >> 32)},
+                                                reinterpret_cast<u32x4 *>(y + gl * frames + f0) + piece);
+            }
+        } else if constexpr (LM) {
             // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the B frames of one lane, so that one store
             // instruction leaves B * sizeof(Out) contiguous bytes per lane
             static_assert(!LM || (sizeof(Out) * C) % 16 == 0, "a thread's piece of a batch is whole 16-byte vectors");
