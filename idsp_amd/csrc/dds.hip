@@ -57,11 +57,34 @@ struct LowpassProc {
 };
 
 // Accu (src/accu.rs:34-41, pre-increment) -> Complex::from_angle (src/complex.rs:237-240)
-struct DdsProc {
+// CIRCLE: cossin through the full-circle table (dds_dev.h cossin_circle: 9 VALU + 2 LDS instructions instead of ~28 + 1, 24 KiB of LDS
+// per workgroup, filled at the start of every workgroup) — taken by FrameMajor calls of 256 frames or more (idsp_dds_i32); the 512-byte
+// table otherwise (short calls, LaneMajor — its staged kernel needs the LDS for the 32 KiB tile slot of every wave — and the one-thread-per-lane form).
+template <bool CIRCLE>
+struct CosTab {
+    static constexpr int WORDS = CIRCLE ? kCosCircleWords : (1 << kCossinDepth);
+    static __device__ __forceinline__ void fill(uint32_t *sh, int tid, int n)
+    {
+        if constexpr (CIRCLE)
+            fill_cossin_circle(sh, tid, n);
+        else
+            fill_cossin(sh, tid, n);
+    }
+    static __device__ __forceinline__ Cplx eval(uint32_t ph, const uint32_t *t)
+    {
+        if constexpr (CIRCLE)
+            return cossin_circle(ph, t);
+        else
+            return cossin_dev(int32_t(ph), t);
+    }
+};
+
+template <bool CIRCLE>
+struct DdsProcT {
     using In = int32_t;  // unused
     using Out = Cplx;
     static constexpr bool HAS_IN = false;
-    static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int LDS_WORDS = CosTab<CIRCLE>::WORDS;
     static constexpr int IN_DIV = 1;
     static constexpr int COST = 100;
     struct Params {
@@ -69,7 +92,7 @@ struct DdsProc {
     };
     const uint32_t *lut;
     uint32_t acc, inc;
-    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { CosTab<CIRCLE>::fill(sh, tid, n); }
     __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
     __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
     {
@@ -80,9 +103,10 @@ struct DdsProc {
     __device__ __forceinline__ Out step(const Params &, In)
     {
         acc += inc;
-        return cossin_dev(int32_t(acc), lut);
+        return CosTab<CIRCLE>::eval(acc, lut);
     }
 };
+using DdsProc = DdsProcT<false>;
 
 // src/lockin.rs:30-39 -> :17-27.  Mixer `x * Q32<32>` =
 // ((q as i64 * x as i64) >> 32) as i32 (dsp-fixedpoint/src/lib.rs:449-456).
@@ -189,11 +213,12 @@ struct LockinSplitProc {
     __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo) { return b.step(p, __mulhi(lo, x)); }
 };
 
-struct DdsSplitProc {
+template <bool CIRCLE>
+struct DdsSplitProcT {
     using In = int32_t;  // unused
     using Out = int32_t;
     static constexpr bool HAS_IN = false;
-    static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int LDS_WORDS = CosTab<CIRCLE>::WORDS;
     static constexpr int IN_DIV = 2;
     static constexpr int COST = 100;
     struct Params {
@@ -202,7 +227,7 @@ struct DdsSplitProc {
     const uint32_t *lut;
     uint32_t acc, inc;
     bool q;
-    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { CosTab<CIRCLE>::fill(sh, tid, n); }
     __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
     __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t vlanes, size_t vlane)
     {
@@ -219,7 +244,7 @@ struct DdsSplitProc {
     __device__ __forceinline__ Pre pre(const Params &)
     {
         acc += inc;
-        const Cplx c = cossin_dev(int32_t(acc), lut);
+        const Cplx c = CosTab<CIRCLE>::eval(acc, lut);
         return q ? c.im : c.re;
     }
     __device__ __forceinline__ void pre_batch(const Params &, Pre (&out)[BATCH])
@@ -227,7 +252,7 @@ struct DdsSplitProc {
 #pragma unroll
         for (int j = 0; j < BATCH / 2; j++) {
             const uint32_t ph = acc + inc * uint32_t(2 * j + 1) + (q ? inc : 0u);
-            const Cplx c = cossin_dev(int32_t(ph), lut);
+            const Cplx c = CosTab<CIRCLE>::eval(ph, lut);
             const int32_t mine = q ? c.im : c.re, other = q ? c.re : c.im;
             const int32_t recv = pair_swap(other);
             out[2 * j] = q ? recv : mine;
@@ -237,6 +262,7 @@ struct DdsSplitProc {
     }
     __device__ __forceinline__ Out step(const Params &, In, const Pre &v) { return v; }
 };
+using DdsSplitProc = DdsSplitProcT<false>;
 
 typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
@@ -569,11 +595,19 @@ int idsp_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int lay
     if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return fail(IDSP_EINVAL, "bad layout %d", layout);
     if (lanes && (!state || (frames && !out))) return fail(IDSP_EINVAL, "state or out is NULL");
     if (lanes == 0) return IDSP_OK;
+    static const bool no_circle = diag_env("IDSP_DDS_NO_CIRCLE") != nullptr;
+    const bool circle = !no_circle && layout == IDSP_FRAME_MAJOR && frames >= 256;
     if (lanes <= kSplitMaxLanes) {
         DdsSplitProc::Params ps{0};
+        if (circle) {
+            DdsSplitProcT<true>::Params pc{0};
+            return launch_stream<DdsSplitProcT<true>>(pc, state, static_cast<const int32_t *>(nullptr), out, 2 * lanes, frames, layout, as_stream(stream));
+        }
         return launch_stream<DdsSplitProc>(ps, state, static_cast<const int32_t *>(nullptr), out, 2 * lanes, frames, layout,
                                            as_stream(stream));
     }
+    // one thread per lane (above kSplitMaxLanes) keeps the 512-byte table: four table evaluations per frame step and CU are LDS-bound
+    // on the random 24-byte entries (65536 lanes x 4096: 0.36 -> 0.46 ms with the big table; 32768 lanes on the split form 0.204 -> 0.164)
     DdsProc::Params p{0};
     return launch_stream<DdsProc>(p, state, static_cast<const int32_t *>(nullptr), reinterpret_cast<Cplx *>(out), lanes,
                                   frames, layout, as_stream(stream));

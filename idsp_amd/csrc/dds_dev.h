@@ -111,20 +111,26 @@ __device__ __forceinline__ Cplx cossin_wide(uint32_t x, const char *mine)
     return Cplx{int32_t(re), int32_t(im)};
 }
 
-// The same function once more, with the whole octant logic in the table (round 3, later; tools/ubench_cossin.hip and
-// /tests compare it with the two above): 9 VALU + 2 LDS instructions per evaluation where cossin_wide takes 23 + 1.
+// The same function once more, with the whole octant logic in the table (round 3, later; tools/ubench_cossin.hip compares it
+// with the two above on the GPU, tests/test_gpu_* through every caller): 9 VALU + 1 LDS instruction per evaluation where
+// cossin_wide takes 23 + 1.
 // cossin.rs:50-66 makes each output component one of c', s', -c', -s' with c' = (c << 14) - ((s * dphi) >> 7) and
 // s' = (s << 15) + ((c * dphi) >> 8), which of them being a function of the top three phase bits alone.  Every one of the
-// four is  A + floor(B * d16 / 2^32)  or  A - floor(B * d16 / 2^32)  with d16 = dphi << 16, and
-// -floor(v / 2^32) = floor((-v + 2^32 - 1) / 2^32), so each is the HIGH WORD of ONE v_mad_i64_i32:
-//     hi32(B' * d16 + (A' << 32 | K)),   K = 0 (term added) or 0xffffffff (term subtracted: B' = -B),
-// wrapping exactly like the reference's `wrapping_neg`.  The table is indexed by the top TEN phase bits (octant and table
-// index as they stand: the index reversal `phase = !phase` of odd octants, cossin.rs:27-29, is folded in as well) and holds
-// {K_re, A_re, K_im, A_im, B_re, B_im} per entry: 1024 x 24 bytes.  What is left on the VALU is dphi (the reflection of
-// the low bits in odd octants, the multiply by PI/4, the truncation to 16 fractional bits), the entry address and the two
-// multiply-adds.  Random 24-byte entries do meet in banks; the lock-in's read-out waves have the LDS slack for it.
+// four is  A + floor(P / 2^32)  or  A - floor(P / 2^32)  with P = B * (dphi << 16), and -floor(P / 2^32) = floor((-P + 2^32 - 1) / 2^32),
+// so each is the HIGH WORD of ONE v_mad_i64_i32:  hi32(B' * d + (A' << 32 | L)),  B' = +-B, A' = +-A, and L any low word that
+// carries exactly when the term is subtracted and P is not a whole multiple of 2^32.  With the product written as
+// Bh * d17 (Bh = B' / 2: B is (s << 9) or (c << 8), even; d17 = dphi << 17) P is a whole multiple of 2^24 and |Bh| < 2^24, so
+// L = Bh ITSELF does it: added term, 0 < Bh < 2^24 never carries; subtracted term, Bh as an unsigned word lies in
+// [2^32 - 2^24, 2^32) and carries iff P mod 2^32 >= 2^24 iff P mod 2^32 != 0.  (Wrapping exactly like the reference's `wrapping_neg`.)
+// The multiply-add reads Bh twice — as the multiplier and as the low half of the addend pair {Bh, A'} — so a table entry is
+// {Bh_re, A_re, Bh_im, A_im}: 16 bytes, one ds_read_b128 whose result registers ARE the two addend pairs.  The table is indexed
+// by the top TEN phase bits (octant and table index as they stand: the index reversal `phase = !phase` of odd octants,
+// cossin.rs:27-29, is folded in): 1024 x 16 bytes.  What is left on the VALU is dphi (the reflection of the low bits in odd
+// octants, the multiply by PI/4 — doubled, so that the truncation mask leaves dphi << 17 —), the entry address and the two
+// multiply-adds.  Random entries do meet in banks; see the callers for where that matters.
+// (First version, same round: {K, A} pairs with K = 0 / 0xffffffff and B beside them, 24-byte entries, two LDS reads.)
 constexpr int kCosCircleEntries = 1 << (kCossinDepth + 3);
-constexpr int kCosCircleWords = kCosCircleEntries * 6;  // 24 KiB
+constexpr int kCosCircleWords = kCosCircleEntries * 4;  // 16 KiB
 __device__ __forceinline__ void fill_cossin_circle(uint32_t *sh, int tid, int nthreads)
 {
     for (int e = tid; e < kCosCircleEntries; e += nthreads) {
@@ -134,37 +140,32 @@ __device__ __forceinline__ void fill_cossin_circle(uint32_t *sh, int tid, int nt
         const uint32_t c = (lookup & 0xffffu) + (1u << 16), s = lookup >> 16;
         // octant ^= octant >> 1 (cossin.rs:59): bit 29 swaps, bit 30 negates cos, bit 31 negates sin — after the swap
         const uint32_t sw = x29 ^ x30, neg[2] = {x30 ^ x31, x31};
-        uint32_t *o = sh + e * 6;
+        uint32_t *o = sh + e * 4;
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {  // 0: re, 1: im
             const bool is_sin = (comp == 1) != (sw != 0);
-            const uint32_t a = is_sin ? s << 15 : c << 14, b = is_sin ? c << 8 : s << 9;
+            const uint32_t a = is_sin ? s << 15 : c << 14, bh = is_sin ? c << 7 : s << 8;
             const bool sub = is_sin == (neg[comp] != 0);  // c' subtracts its term, s' adds it; negation flips that
-            o[2 * comp] = sub ? 0xffffffffu : 0u;
+            o[2 * comp] = sub ? 0u - bh : bh;
             o[2 * comp + 1] = neg[comp] ? 0u - a : a;
-            o[4 + comp] = sub ? 0u - b : b;
         }
     }
 }
 // split in two so that a caller with several phases in hand can issue all table reads before the first multiply-add (the
-// compiler keeps each evaluation's reads behind the previous evaluation's s_waitcnt otherwise)
-struct CosCircleEntry {
-    uint32_t k_re, a_re, k_im, a_im, b_re, b_im;
-};
+// compiler keeps each evaluation's read behind the previous evaluation's s_waitcnt otherwise)
+typedef uint32_t CosCircleEntry __attribute__((ext_vector_type(4)));  // {Bh_re, A_re, Bh_im, A_im}
 __device__ __forceinline__ CosCircleEntry cossin_circle_fetch(uint32_t x, const uint32_t *tab)
 {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 *e = reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(tab) + (x >> (32 - kCossinDepth - 3)) * 24u);
-    const u32x2 kre = e[0], kim = e[1], b = e[2];
-    return CosCircleEntry{kre.x, kre.y, kim.x, kim.y, b.x, b.y};
+    static_assert(kCossinDepth == 7, "entry byte offset = phase bits 22..31 << 4");
+    return *reinterpret_cast<const CosCircleEntry *>(reinterpret_cast<const char *>(tab) + ((x >> 18) & 0x3ff0u));
 }
 __device__ __forceinline__ Cplx cossin_circle_finish(uint32_t x, const CosCircleEntry &e)
 {
     const uint32_t xx = x ^ uint32_t(__builtin_amdgcn_sbfe(int32_t(x), 29, 1));  // low bits reflected in odd octants
-    const int32_t t = int32_t(__builtin_amdgcn_ubfe(xx, 7, 15)) * 51471 - 16384 * 51471;
-    const int64_t d16 = int64_t(int32_t(uint32_t(t) & 0xffff0000u));
-    const uint64_t re = uint64_t(int64_t(int32_t(e.b_re)) * d16) + ((uint64_t(e.a_re) << 32) | e.k_re);
-    const uint64_t im = uint64_t(int64_t(int32_t(e.b_im)) * d16) + ((uint64_t(e.a_im) << 32) | e.k_im);
+    const int32_t t2 = int32_t(__builtin_amdgcn_ubfe(xx, 7, 15)) * (2 * 51471) - 16384 * (2 * 51471);  // 2 (p - 2^14) PI4
+    const int64_t d17 = int64_t(int32_t(uint32_t(t2) & 0xfffe0000u));                                   // dphi << 17
+    const uint64_t re = uint64_t(int64_t(int32_t(e.x)) * d17) + ((uint64_t(e.y) << 32) | e.x);
+    const uint64_t im = uint64_t(int64_t(int32_t(e.z)) * d17) + ((uint64_t(e.w) << 32) | e.z);
     return Cplx{int32_t(uint32_t(re >> 32)), int32_t(uint32_t(im >> 32))};
 }
 __device__ __forceinline__ Cplx cossin_circle(uint32_t x, const uint32_t *tab) { return cossin_circle_finish(x, cossin_circle_fetch(x, tab)); }

@@ -1,8 +1,9 @@
 #!/bin/bash
-# LaneMajor lock-in with whole-line output stores: parity of the lock-in suites, the C4 survey, and the HW_ID dump of the 4-wave kernel
-# with roles by wave index (where the waves of a workgroup land)
-mkdir -p gpurun_out/s gpurun_out/q
-python -m pytest tests -m gpu -x -q -k "lockin or c4 or full_tensor" > gpurun_out/s/pytest_lm.log 2>&1; echo "pytest rc=$?" >> gpurun_out/s/pytest_lm.log
-tail -3 gpurun_out/s/pytest_lm.log
-python tools/perf_configs.py --only c4 2>&1 | grep "C4" | tee gpurun_out/s/perf_c4_lm_lines.jsonl
-LW_DUMP=1 build/exp_lockin_trace_rot0 > gpurun_out/q/exp_lockin_trace_rot0.txt 2>&1; grep -c "wg " gpurun_out/q/exp_lockin_trace_rot0.txt
+# DDS FrameMajor with the full-circle-table cossin: parity of the DDS / cossin suites, then the dds lines of the survey with and without it
+mkdir -p gpurun_out/s
+python -m pytest tests -m gpu -x -q -k "dds or cossin or accu or kat or last_kernel" > gpurun_out/s/pytest_dds.log 2>&1; echo "pytest rc=$?" >> gpurun_out/s/pytest_dds.log
+tail -3 gpurun_out/s/pytest_dds.log
+for v in 0 1; do
+  if [ $v = 1 ]; then export IDSP_DIAG=1 IDSP_DDS_NO_CIRCLE=1; fi
+  python tools/perf_configs.py --only c4 2>&1 | grep '"dds' | sed "s/^/no_circle=$v /"
+done | tee gpurun_out/s/perf_dds_circle.jsonl

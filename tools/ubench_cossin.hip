@@ -200,7 +200,7 @@ struct V6 : V2 {
     }
 };
 
-// ---- V7: the octant logic in the table (dds_dev.h cossin_circle): 1024 x 24-byte entries indexed by the top ten phase
+// ---- V7: the octant logic in the table (dds_dev.h cossin_circle): 1024 x 16-byte entries indexed by the top ten phase
 //          bits, each output component the high word of one v_mad_i64_i32 ----------------------------------------------
 struct V7 {
     static constexpr int kLdsWords = kCosCircleWords;
@@ -308,6 +308,6 @@ int main()
     run<V4>("V4 8 B pre-shifted entries x32, mul_hi", out, va, vb, cus, ghz);
     run<V5>("V5 = V2 + v_bitop3 selects, xor masks", out, va, vb, cus, ghz);
     run<V6>("V6 = V5 with masks from the octant word", out, va, vb, cus, ghz);
-    run<V7>("V7 octant logic in a 24 KiB table, 2 mad64", out, va, vb, cus, ghz);
+    run<V7>("V7 octant logic in a 16 KiB table, 2 mad64", out, va, vb, cus, ghz);
     return 0;
 }
