@@ -606,8 +606,8 @@ int idsp_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int lay
         return launch_stream<DdsSplitProc>(ps, state, static_cast<const int32_t *>(nullptr), out, 2 * lanes, frames, layout,
                                            as_stream(stream));
     }
-    // one thread per lane (above kSplitMaxLanes) keeps the 512-byte table: four table evaluations per frame step and CU are LDS-bound
-    // on the random 24-byte entries (65536 lanes x 4096: 0.36 -> 0.46 ms with the big table; 32768 lanes on the split form 0.204 -> 0.164)
+    // one thread per lane (above kSplitMaxLanes) keeps the 512-byte table: 65536 lanes x 4096 run 0.36-0.37 ms with it and 0.46 with the
+    // full-circle table, 24- or 16-byte entries alike (profiles/r03_perf_dds_circle.jsonl, r03_perf_dds_one_circle.jsonl)
     DdsProc::Params p{0};
     return launch_stream<DdsProc>(p, state, static_cast<const int32_t *>(nullptr), reinterpret_cast<Cplx *>(out), lanes,
                                   frames, layout, as_stream(stream));

@@ -679,7 +679,8 @@ __global__ __launch_bounds__((4 + R) * G *kWave) void lockin_stages_kernel(const
 // (tools/exp_lockin_stages.hip, profiles/r03_exp_lockin_stages*.jsonl): `Complex<i32>` / `norm_sqr` read-out 0.207 against 0.232 ms
 // up to 16384 lanes (one workgroup per CU or fewer: eight waves per 64 lanes instead of four) but 0.345 against 0.317 at 32768 and
 // 0.64 against 0.57 at 49152, so those take it up to 16384 lanes; the `arg` read-out (atan2 on the read-out waves) 0.337 / 0.465 /
-// 0.93 against 0.384 / 0.51 / 1.16 ms at 16384 / 32768 / 65536 lanes and level at 131072, so it takes it up to 98304 lanes.
+// 0.93 against 0.384 / 0.51 / 1.16 ms at 16384 / 32768 / 65536 lanes (16-byte table entries: 0.311 against 0.289 of the HBM peak from 65536 to
+// 196608 lanes), so it takes it at every lane count.
 // IDSP_DIAG switches: IDSP_LOCKIN_NO_STAGES=1 never, IDSP_LOCKIN_STAGE_GROUPS=1 / 2 always (when the shape allows).
 inline int lockin_stage_groups(const void *x, size_t lanes, size_t frames, int layout, int cascade, bool heavy_readout)
 {
@@ -694,7 +695,7 @@ inline int lockin_stage_groups(const void *x, size_t lanes, size_t frames, int l
     const bool pairs = lanes % (2 * kWave) == 0;
     if (forced == 1 || (forced == 2 && pairs)) return forced;
     if (lanes <= 16384) return 1;
-    return heavy_readout && pairs && lanes <= 98304 ? 2 : 0;
+    return heavy_readout && pairs ? 2 : 0;
 }
 
 template <int MODE, int N>
@@ -747,7 +748,10 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
     }();
     // the 6-wave form keeps 8-frame batches: with 16 (66 KiB of LDS) only ONE 6-wave workgroup runs on a CU at a time — every
     // second workgroup started after the first had finished (tools/exp_lockin_trace.hip) although the occupancy API promises two
-    const bool b16 = forced_b == 16 || (forced_b != 8 && lanes <= kSplitMaxLanes && waves == 4);
+    // Four workgroups per CU (49152 < lanes <= 65536) also take 16-frame batches: two co-resident workgroups in two rounds, where the 8-frame
+    // form's three leave a round of one (0.649 against 0.581 of the HBM peak at 65536 lanes; 49152: 0.557 against 0.654, 98304: 0.649 against 0.666,
+    // profiles/r03_exp_lockin_batch_v2.jsonl)
+    const bool b16 = forced_b == 16 || (forced_b != 8 && waves == 4 && (lanes <= kSplitMaxLanes || (lanes > 49152 && lanes <= 65536)));
     if (layout == IDSP_LANE_MAJOR) {
         // input by DMA (whole 128-byte lines, each requested once) for the 4-wave I/Q and norm_sqr forms: 0.48 -> 0.43-0.44 ms
         // at 32768 lanes x 4096 frames, 0.94 -> 0.86 at 65536; its 32 KiB ring halves the workgroups a CU can hold, which

@@ -2,7 +2,7 @@
 read-out waves per 64 lanes, cossin through the full-circle table) against the oracle: every read-out (`Complex<i32>`, `arg`,
 `norm_sqr`), `[Lowpass<1>; 2]` and `[Lowpass<2>; 2]`, arbitrary state, 1 ... 12 batches of 16 frames (the pipeline is four batches
 deep: fewer batches than stages must drain correctly), chunked continuation, one and two lane groups per workgroup.  Default
-dispatch takes the kernel up to 16384 lanes (`arg`: up to 98304); the forced runs put every eligible shape on it with one or two
+dispatch takes the kernel up to 16384 lanes (`arg`: at every lane count); the forced runs put every eligible shape on it with one or two
 groups per workgroup (the switches are read once per process, hence the subprocesses), and `idsp_last_kernel()` proves which kernel
 ran.  Shapes the kernel does not take (ragged lanes, frames off the 16-frame grid, LaneMajor, other cascades) are the fuzz suite's."""
 import os

@@ -96,11 +96,20 @@ int run(size_t lanes, size_t frames)
 
 int main(int argc, char **)
 {
-    if (argc > 2) {  // the 4-wave kernel at lane counts of more than two workgroups per CU (build variants: IDSP_LW_ROT, IDSP_LW_MIXR)
-        run<2, MODE_IQ, 2, 4, 4, 8>(65536, 4096);
+    if (argc > 2) {  // the 4-wave kernel with 8- and 16-frame batches against the stage kernel above two workgroups per CU
         run<2, MODE_IQ, 2, 4, 4, 8>(49152, 4096);
-        run<2, MODE_IQ, 2, 4, 4, 16>(32768, 4096);
+        run<2, MODE_IQ, 2, 4, 4, 16>(49152, 4096);
+        run<2, MODE_IQ, 2, 4, 4, 8>(65536, 4096);
+        run<2, MODE_IQ, 2, 4, 4, 16>(65536, 4096);
+        run<2, MODE_IQ, 2, 4, 4, 8>(98304, 4096);
+        run<2, MODE_IQ, 2, 4, 4, 16>(98304, 4096);
         run<2, MODE_IQ, 2, 4, 4, 8>(131072, 2048);
+        run<2, MODE_IQ, 2, 4, 4, 16>(131072, 2048);
+        run<2, MODE_NORM_SQR, 2, 4, 4, 8>(65536, 4096);
+        run<2, MODE_NORM_SQR, 2, 4, 4, 16>(65536, 4096);
+        run<2, MODE_ARG, 2, 4, 4, 16>(65536, 4096);
+        run<2, MODE_ARG, 2, 4, 4, 16>(131072, 2048);
+        run<2, MODE_ARG, 2, 4, 4, 16>(196608, 2048);
         return 0;
     }
     if (argc > 1) {  // dispatch survey
