@@ -36,6 +36,10 @@ inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t f
     if (layout == IDSP_LANE_MAJOR && !(frames % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0))
         return 0;
     if (forced == 4 || forced == 6) return forced;
+    // FrameMajor up to one workgroup per CU: six waves (four read-out waves) with 16-frame batches — the read-out path is what an interval
+    // waits for there (`[Lowpass<1>; 1]` 0.183 -> 0.156 ms, `[Lowpass<2>; 1]`->arg 0.324 -> 0.283 at 16384 lanes x 4096, profiles/r03_perf_c4small.jsonl;
+    // `[Lowpass<N>; 2]` is the stage-wave kernel's at these lane counts).  Two 6-wave workgroups with 16-frame batches do not share a CU, so not above.
+    if (layout == IDSP_FRAME_MAJOR && lanes <= 16384) return 6;
     // measured at 4096 frames (arg read-out): 6 waves 0.64 ms at 32768 lanes (4 waves: 0.73), 4 waves 1.07 ms at 65536 (6: 1.12)
     return heavy_readout && lanes <= kSplitMaxLanes ? 6 : 4;
 }

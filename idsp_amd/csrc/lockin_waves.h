@@ -751,7 +751,8 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
     // Four workgroups per CU (49152 < lanes <= 65536) also take 16-frame batches: two co-resident workgroups in two rounds, where the 8-frame
     // form's three leave a round of one (0.649 against 0.581 of the HBM peak at 65536 lanes; 49152: 0.557 against 0.654, 98304: 0.649 against 0.666,
     // profiles/r03_exp_lockin_batch_v2.jsonl)
-    const bool b16 = forced_b == 16 || (forced_b != 8 && waves == 4 && (lanes <= kSplitMaxLanes || (lanes > 49152 && lanes <= 65536)));
+    const bool b16 = forced_b == 16 || (forced_b != 8 && ((waves == 4 && (lanes <= kSplitMaxLanes || (lanes > 49152 && lanes <= 65536))) ||
+                                                          (waves == 6 && lanes <= 16384)));  // six waves, one workgroup per CU: dds.hip lockin_waves_for
     if (layout == IDSP_LANE_MAJOR) {
         // input by DMA (whole 128-byte lines, each requested once) for the 4-wave I/Q and norm_sqr forms: 0.48 -> 0.43-0.44 ms
         // at 32768 lanes x 4096 frames, 0.94 -> 0.86 at 65536; its 32 KiB ring halves the workgroups a CU can hold, which

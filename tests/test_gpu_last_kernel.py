@@ -29,7 +29,7 @@ def test_every_family_reports_its_kernel(gpu):
     assert gpu.stream("biquad_i32_df1", cfg, 1, st, x, y, lanes, frames, H.FM) == 0 and name().startswith("stream_frame_major_staged[16 lanes/wave]<")
     lc = H.lockin_cfg([[1 << 20, -(1 << 27)]] * 2)
     assert gpu.cfgcall("lockin_i32_process", lc, st, x, y, lanes, frames, H.FM) == 0 and name().startswith("lockin_stages_kernel[8 waves")
-    assert gpu.cfgcall("lockin_i32_process", lc, st, x, y, lanes, frames - 1, H.FM) == 0 and name().startswith("lockin_waves_kernel[4 waves")
+    assert gpu.cfgcall("lockin_i32_process", lc, st, x, y, lanes, frames - 1, H.FM) == 0 and name().startswith("lockin_waves_kernel[6 waves")
     hc = _abi.HbfCascadeF32()
     assert gpu.fn["hbf_dec_cascade"](0, 4, C.byref(hc)) == 0
     xf = torch.zeros(lanes * 16 * 16, dtype=torch.float32, device=DEV)

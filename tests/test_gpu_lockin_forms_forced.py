@@ -1,6 +1,6 @@
 """Every form of the multi-wave lock-in kernel (idsp_amd/csrc/lockin_waves.h), not only the ones default dispatch picks:
-4 or 6 waves per 64 lanes x 8- or 16-frame batches x LDS-DMA or register-prefetch input.  Default dispatch takes 4 waves /
-16 frames for `Complex<i32>` and `norm_sqr` up to 40960 lanes, 6 waves / 8 frames for `arg`, 4 waves / 8 frames above —
+4 or 6 waves per 64 lanes x 8- or 16-frame batches x LDS-DMA or register-prefetch input.  Default dispatch takes 6 waves /
+16 frames up to 16384 FrameMajor lanes, 4 waves / 16 frames for `Complex<i32>` and `norm_sqr` up to 40960 lanes, 6 waves / 8 frames for `arg`, 4 waves / 8 frames above —
 6 waves with 16-frame batches is reachable through the diagnostic switches only, and so is the register-prefetch input on
 aligned buffers.  Each combination re-runs the randomised lock-in suite and the lock-in parity tests in a process of its
 own (the switches are read once per process) against the oracle."""

@@ -1,9 +1,6 @@
 #!/bin/bash
-# (a) 4-wave lock-in kernel with 8- / 16-frame batches against the stage kernel at 49152 ... 196608 lanes; (b) the one-thread-per-lane DDS on
-# the 16-byte table (IDSP_DDS_ONE_CIRCLE) against the 512-byte table at 65536 / 131072 lanes
+# lock-in at one workgroup per CU or fewer: default dispatch against the 6-wave form with 16- and 8-frame batches
 mkdir -p gpurun_out/s
-timeout 300 build/exp_lockin_stages a b | tee gpurun_out/s/exp_lockin_batch_v2.jsonl | cut -c1-75,100-117,161-250
-for v in 0 1; do
-  if [ $v = 1 ]; then export IDSP_DIAG=1 IDSP_DDS_ONE_CIRCLE=1; fi
-  python tools/perf_configs.py --only c4 2>&1 | grep '"dds' | sed "s/^/one_circle=$v /"
-done | tee gpurun_out/s/perf_dds_one_circle.jsonl
+for f in "default" "IDSP_LOCKIN_WAVES=6 IDSP_LOCKIN_B=16 IDSP_LOCKIN_NO_STAGES=1" "IDSP_LOCKIN_WAVES=6 IDSP_LOCKIN_B=8 IDSP_LOCKIN_NO_STAGES=1" "IDSP_LOCKIN_WAVES=4 IDSP_LOCKIN_NO_STAGES=1"; do
+  if [ "$f" = default ]; then env python tools/perf_configs.py --only c4small 2>&1 | grep C4s | sed "s/^/[$f] /"; else env IDSP_DIAG=1 $f python tools/perf_configs.py --only c4small 2>&1 | grep C4s | sed "s/^/[$f] /"; fi
+done | tee gpurun_out/s/perf_c4small.jsonl | cut -c1-200

@@ -387,6 +387,12 @@ def main():
         for s in (1, 2, 3, 5):
             hbf("dec", s, 16384, 65536 >> s, LM, it, "hbf")
             hbf("int", s, 16384, 65536 >> s, LM, it, "hbf")
+    if want("c4small"):  # lock-in below one workgroup per CU and a quarter of C4's frames: which multi-wave form per [Lowpass<N>; K]
+        for order, cascade in ((1, 1), (2, 1), (1, 2), (2, 2), (2, 4)):
+            for lanes in (4096, 16384):
+                lockin(order, cascade, lanes, 4096, FM, it, "C4s")
+        lockin(2, 2, 16384, 4096, FM, it, "C4s", "arg")
+        lockin(2, 1, 16384, 4096, FM, it, "C4s", "arg")
     if want("nw"):
         biquad("normal_i32_df1", torch.int32, 4, 65536, 4096, FM, 1, it, "nw")
         biquad("normal_f32_df1", torch.float32, 4, 65536, 4096, FM, 1, it, "nw")
