@@ -456,12 +456,21 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #define IDSP_LW_PRIO 3
 #endif
     auto interval = [&](size_t n, int nb, auto full, auto slot_tag) {
+#ifdef IDSP_LW_PRIO_BY_ROLE  // experiment: a fixed priority per role (arm waves IDSP_LW_PRIO_BY_ROLE, read-out waves 0) instead of the alternation
+        if (n == 0) {
+            if (arm_wave)
+                __builtin_amdgcn_s_setprio(IDSP_LW_PRIO_BY_ROLE);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        }
+#else
         if constexpr (IDSP_LW_PRIO != 0) {
             if ((unsigned(n) ^ prio_class) & 1u)
                 __builtin_amdgcn_s_setprio(IDSP_LW_PRIO);
             else
                 __builtin_amdgcn_s_setprio(0);
         }
+#endif
         if (arm_wave) {
             arm_stage(n, cur, nb, full);
         } else {

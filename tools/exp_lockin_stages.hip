@@ -96,6 +96,13 @@ int run(size_t lanes, size_t frames)
 
 int main(int argc, char **)
 {
+    if (argc > 3) {  // C4 and its neighbours on the 4-wave kernel only (build variants: priorities, mixer placement, roles)
+        run<2, MODE_IQ, 2, 4, 4, 16>(32768, 4096);
+        run<2, MODE_IQ, 2, 4, 4, 16>(65536, 4096);
+        run<2, MODE_NORM_SQR, 2, 4, 4, 16>(32768, 4096);
+        run<1, MODE_IQ, 2, 4, 4, 16>(32768, 4096);
+        return 0;
+    }
     if (argc > 2) {  // the 4-wave kernel with 8- and 16-frame batches against the stage kernel above two workgroups per CU
         run<2, MODE_IQ, 2, 4, 4, 8>(49152, 4096);
         run<2, MODE_IQ, 2, 4, 4, 16>(49152, 4096);

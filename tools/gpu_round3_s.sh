@@ -1,6 +1,7 @@
 #!/bin/bash
-# lock-in at one workgroup per CU or fewer: default dispatch against the 6-wave form with 16- and 8-frame batches
+# 4-wave lock-in kernel at C4: alternating priority 3 (base) / arm waves 2, read-out 0 (parm)
 mkdir -p gpurun_out/s
-for f in "default" "IDSP_LOCKIN_WAVES=6 IDSP_LOCKIN_B=16 IDSP_LOCKIN_NO_STAGES=1" "IDSP_LOCKIN_WAVES=6 IDSP_LOCKIN_B=8 IDSP_LOCKIN_NO_STAGES=1" "IDSP_LOCKIN_WAVES=4 IDSP_LOCKIN_NO_STAGES=1"; do
-  if [ "$f" = default ]; then env python tools/perf_configs.py --only c4small 2>&1 | grep C4s | sed "s/^/[$f] /"; else env IDSP_DIAG=1 $f python tools/perf_configs.py --only c4small 2>&1 | grep C4s | sed "s/^/[$f] /"; fi
-done | tee gpurun_out/s/perf_c4small.jsonl | cut -c1-200
+for r in 1 2; do for v in base parm; do echo "== $v"; timeout 200 build/exp_ls_$v a b c | python3 -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print(d['N'], d['mode'], d['lanes'], d['y_mismatches'], d['ms_waves'], d['frac_waves'])"; done; done 2>&1 | tee gpurun_out/s/exp_lockin_prio_v2b.txt
