@@ -398,7 +398,8 @@ def test_atan2_parity_all_octants(bes):
 def test_dds_parity(bes, layout):
     ob, gb = bes
     rng = np.random.default_rng(21 + layout)
-    for lanes, frames in [(1, 1), (64, 31), (65, 32), (100, 33), (7, 200)]:
+    # from 256 FrameMajor frames the two-threads-per-lane form evaluates cossin through the full-circle table (dds.hip: CosTab<true>)
+    for lanes, frames in [(1, 1), (64, 31), (65, 32), (100, 33), (7, 200), (64, 256), (100, 300), (130, 1000), (2049, 257), (1, 4096)]:
         st = rng.integers(0, 1 << 32, size=(2, lanes), dtype=np.uint64).astype(np.uint32)
         so, sg = st.copy(), st.copy()
         _, yo = ob.dds(so, lanes, frames, layout)
