@@ -415,7 +415,16 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
         constexpr int kEarly = MIXR ? 2 : 1;
         if constexpr (DMA) wait_vmcnt<(kLwFmAhead - kEarly) * (B / 8)>();  // batches up to n + kEarly have landed, the later ones may be in flight
         if constexpr (LMD) {
-            if (n % 2 == 1) wait_vmcnt<(kLwAhead - kEarly) * 4>();  // pairs up to (n + 1) / 2 + kEarly - 1 have landed
+            // mixer in the arm waves: batch n + 1 is read during interval n + 1, so at the end of an ODD interval the pair of batch n + 1
+            // must have landed and the youngest request (issued one interval ago) may still fly.  Mixer in the read-out waves: batch
+            // n + 2 is read during interval n + 1, so the same holds at the end of an EVEN interval, the request issued in this very
+            // interval still flying.  (The first version of the read-out mixer waited for vmcnt(0) at odd intervals — every pair only one
+            // interval after its request — and exposed the DMA latency.)
+            if constexpr (MIXR) {
+                if (n % 2 == 0) wait_vmcnt<4>();
+            } else {
+                if (n % 2 == 1) wait_vmcnt<(kLwAhead - 1) * 4>();
+            }
         }
         LW_T(4);
     };

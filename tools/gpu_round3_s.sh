@@ -1,7 +1,6 @@
 #!/bin/bash
-# 4-wave lock-in kernel at C4: alternating priority 3 (base) / arm waves 2, read-out 0 (parm)
+# LaneMajor lock-in: DMA wait at even intervals when the read-out waves mix; parity, then the C4 lines
 mkdir -p gpurun_out/s
-for r in 1 2; do for v in base parm; do echo "== $v"; timeout 200 build/exp_ls_$v a b c | python3 -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print(d['N'], d['mode'], d['lanes'], d['y_mismatches'], d['ms_waves'], d['frac_waves'])"; done; done 2>&1 | tee gpurun_out/s/exp_lockin_prio_v2b.txt
+python -m pytest tests -m gpu -x -q -k "lockin or c4 or full_tensor" > gpurun_out/s/pytest_lmw.log 2>&1; echo "pytest rc=$?" >> gpurun_out/s/pytest_lmw.log
+tail -3 gpurun_out/s/pytest_lmw.log
+python tools/perf_configs.py --only c4 2>&1 | grep "C4" | tee gpurun_out/s/perf_c4_lmwait.jsonl
