@@ -96,3 +96,13 @@ def test_two_groups_at_the_arg_lane_counts(gpu):
     rng = np.random.default_rng(78)
     _one(o, e, rng, "lockin_i32_arg", 1, np.int32, torch.int32, 32768, 64, 2, None, "lockin_stages_kernel[16 waves per 128 lanes]")
     _one(o, e, rng, "lockin_i32_process", 2, np.int32, torch.int32, 32768, 64, 2, None, "lockin_waves_kernel")
+
+
+def test_dds_on_the_small_table_when_forced(gpu):
+    """IDSP_DDS_NO_CIRCLE=1: the DDS parity shapes (which include FrameMajor calls of 256 frames and more) on the 512-byte cossin table."""
+    if os.environ.get("IDSP_DDS_NO_CIRCLE"):
+        pytest.skip("already inside a forced run")
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_DDS_NO_CIRCLE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-x", "-q", "-k", "dds"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
