@@ -69,51 +69,12 @@ __device__ __forceinline__ void fill_cossin(uint32_t *sh, int tid, int nthreads)
     for (int i = tid; i < (1 << kCossinDepth); i += nthreads) sh[i] = d_cossin_table[i];
 }
 
-// The same function on a pre-shifted table (round 3; tools/ubench_cossin.hip measures both, bit for bit equal over 2^24
-// phases and every octant edge: 110 against 130 cycles per wave evaluation at two waves per SIMD).  Entry i holds
-// {c << 14, s << 15, c << 8, s << 9} with c = cos + 2^16, s = sin of build.rs:26-38 — the four values cossin.rs:42-57
-// derives from the packed word with and / or / shift — so both interpolation products are one v_mul_hi_i32 against
-// dphi << 16: ((s << 9) * (dphi << 16)) >> 32 = (s * dphi) >> 7 and ((c << 8) * (dphi << 16)) >> 32 = (c * dphi) >> 8, exact
-// (the products are whole multiples of 2^25 / 2^24 below 2^63).  The octant unmap (cossin.rs:59-66) is branch-free: the
-// swap is one v_bitop3_b32 select per component, the negations are xor / subtract with sign masks.  The table is stored
-// kCosCopies times, entry-major, so that lanes l and l + kCosCopies are the only ones of a ds_read_b128 lane group that
-// can meet in a bank: with the 512-byte table 79 % of the lock-in's LDS cycles were bank conflicts
-// (profiles/r02_c4_pmc.csv).
-constexpr int kCosCopies = 8;
-constexpr int kCosWideWords = (1 << kCossinDepth) * kCosCopies * 4;  // 16 KiB
-__device__ __forceinline__ void fill_cossin_wide(uint32_t *sh, int tid, int nthreads)
-{
-    for (int i = tid; i < (1 << kCossinDepth) * kCosCopies; i += nthreads) {
-        const uint32_t lookup = d_cossin_table[i / kCosCopies];
-        const uint32_t c = (lookup & 0xffffu) + (1u << 16), s = lookup >> 16;
-        uint32_t *e = sh + i * 4;
-        e[0] = c << 14, e[1] = s << 15, e[2] = c << 8, e[3] = s << 9;
-    }
-}
-// `mine` = table + 16 (lane % kCosCopies) bytes: this lane's copy
-__device__ __forceinline__ const char *cossin_wide_base(const uint32_t *sh, int lane) { return reinterpret_cast<const char *>(sh) + (lane % kCosCopies) * 16; }
-__device__ __forceinline__ Cplx cossin_wide(uint32_t x, const char *mine)
-{
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t o = x ^ (x >> 1);  // bit 29: swap, bit 30: negate cos, bit 31: negate sin (cossin.rs:59-66)
-    const uint32_t xx = x ^ uint32_t(__builtin_amdgcn_sbfe(int32_t(x), 29, 1));  // phase = pi/4 - phase in odd octants
-    const u32x4 e = *reinterpret_cast<const u32x4 *>(mine + ((xx >> 15) & uint32_t(0x7f * kCosCopies * 16)));
-    static_assert(kCosCopies == 8, "entry stride 128 bytes: index bits 22..28 land at bits 7..13");
-    // dphi = ((ph & 0x7fff) - 0x4000) * 51471 >> 16, kept as dphi << 16
-    const int32_t t = int32_t(__builtin_amdgcn_ubfe(xx, 7, 15)) * 51471 - 16384 * 51471;
-    const int32_t d16 = int32_t(uint32_t(t) & 0xffff0000u);
-    const uint32_t c = e.x - uint32_t(__mulhi(int32_t(e.w), d16)), s = e.y + uint32_t(__mulhi(int32_t(e.z), d16));
-    const uint32_t msw = uint32_t(__builtin_amdgcn_sbfe(int32_t(o), 29, 1)), mc = uint32_t(__builtin_amdgcn_sbfe(int32_t(o), 30, 1)),
-                   ms = uint32_t(int32_t(o) >> 31);
-    uint32_t re = __builtin_amdgcn_bitop3_b32(msw, s, c, 0xCA), im = __builtin_amdgcn_bitop3_b32(msw, c, s, 0xCA);  // msw ? s : c, msw ? c : s
-    re = (re ^ mc) - mc;
-    im = (im ^ ms) - ms;
-    return Cplx{int32_t(re), int32_t(im)};
-}
-
+// (Round 3 also had `cossin_wide`: the same function on a pre-shifted table {c << 14, s << 15, c << 8, s << 9} stored 8 times against
+// bank conflicts, both interpolation products one v_mul_hi_i32, branch-free unmap — 23 VALU + 1 LDS.  Superseded by the form below and
+// removed; tools/ubench_cossin.hip keeps it as V6 with its timing.)
 // The same function once more, with the whole octant logic in the table (round 3, later; tools/ubench_cossin.hip compares it
 // with the two above on the GPU, tests/test_gpu_* through every caller): 9 VALU + 1 LDS instruction per evaluation where
-// cossin_wide takes 23 + 1.
+// round 3's pre-shifted-table form took 23 + 1.
 // cossin.rs:50-66 makes each output component one of c', s', -c', -s' with c' = (c << 14) - ((s * dphi) >> 7) and
 // s' = (s << 15) + ((c * dphi) >> 8), which of them being a function of the top three phase bits alone.  Every one of the
 // four is  A + floor(P / 2^32)  or  A - floor(P / 2^32)  with P = B * (dphi << 16), and -floor(P / 2^32) = floor((-P + 2^32 - 1) / 2^32),

@@ -548,7 +548,10 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 // turned into output elements during n + 2 (and overwritten with batch n + 3 by the wave that just read it).  Input by LDS-DMA as in the kernel above: every arm-stage wave moves 4 of the 16 rows
 // of a batch, four batches ahead.  FrameMajor, whole 16-frame batches, whole 64 G-lane blocks, K = 2 (the launcher falls back to
 // the kernel above for everything else).
-constexpr int kLsB = 16, kLsRing = 5, kLsAhead = 4;
+#ifndef IDSP_LS_RING
+#define IDSP_LS_RING 5
+#endif
+constexpr int kLsB = 16, kLsRing = IDSP_LS_RING, kLsAhead = IDSP_LS_RING - 1;  // input ring slots / batches requested ahead
 
 template <int N, int MODE, int G, int R = 2>
 __global__ __launch_bounds__((4 + R) * G *kWave) void lockin_stages_kernel(const LpParams prm, uint32_t *st, const int32_t *x,

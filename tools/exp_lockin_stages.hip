@@ -96,6 +96,15 @@ int run(size_t lanes, size_t frames)
 
 int main(int argc, char **)
 {
+    if (argc > 4) {  // one lane group per workgroup at two workgroups per CU: do they share the CU? (build with IDSP_LS_RING=4: 62 KiB of LDS)
+        run<2, MODE_IQ, 1, 4, 4, 16>(16384, 4096);
+        run<2, MODE_IQ, 1, 4, 4, 16>(32768, 4096);
+        run<2, MODE_IQ, 2, 4, 4, 16>(32768, 4096);
+        run<2, MODE_IQ, 1, 4, 4, 16>(65536, 4096);
+        run<2, MODE_ARG, 1, 4, 4, 16>(32768, 4096);
+        run<2, MODE_ARG, 2, 4, 4, 16>(32768, 4096);
+        return 0;
+    }
     if (argc > 3) {  // C4 and its neighbours on the 4-wave kernel only (build variants: priorities, mixer placement, roles)
         run<2, MODE_IQ, 2, 4, 4, 16>(32768, 4096);
         run<2, MODE_IQ, 2, 4, 4, 16>(65536, 4096);
