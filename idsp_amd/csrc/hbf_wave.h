@@ -347,6 +347,10 @@ __global__ __launch_bounds__(kW) IDSP_HBF_WPE_ATTR void hbf_dec_wave(uint32_t *s
     const size_t unit = LM ? size_t(blockIdx.x) : xcd_lane(nunits);
     if (unit >= nunits) return;
     const size_t lane = unit * PK;
+#ifdef IDSP_EXP_HBF_STAGGER  // timing experiment only (tools/exp_hbf.sh): first-generation waves start (blockIdx % 16) x this many ~0.4 us apart,
+                             // so that the lanes in flight do not all sit at the same offset inside their (power-of-two apart) rows
+    for (int i = 0; i < int(blockIdx.x % 16) * (IDSP_EXP_HBF_STAGGER); i++) __builtin_amdgcn_s_sleep(16);
+#endif
     const bool has_b = PK == 2 && lane + 1 < lanes;
     const size_t lane_b = has_b ? lane + 1 : lane;
 
