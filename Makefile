@@ -16,7 +16,7 @@ ORCFLAGS   := -O3 -std=c11 -fPIC -ffp-contract=off -fno-fast-math \
 
 CSRC       := idsp_amd/csrc
 # the translation units that compile longest go first, so that `make -j` does not end on one of them
-HIP_SLOW   := $(addprefix $(CSRC)/,dds.hip normal_wdf.hip cascade.hip biquad_f64.hip cic_int_i64_hi.hip cic_int_i32_hi.hip)
+HIP_SLOW   := $(addprefix $(CSRC)/,dds.hip lockin_stream_iq.hip lockin_stream_arg.hip lockin_stream_norm_sqr.hip normal_wdf.hip cascade.hip biquad_f64.hip cic_int_i64_hi.hip cic_int_i32_hi.hip)
 HIP_SRCS   := $(HIP_SLOW) $(filter-out $(HIP_SLOW),$(wildcard $(CSRC)/*.hip))
 HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 HIP_HDRS   := $(wildcard $(CSRC)/*.h) include/idsp_hip.h

@@ -19,6 +19,12 @@ int lockin_waves_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, 
 int lockin_waves_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames,
                           int layout, int waves, hipStream_t s);
 
+// lockin_stream_{iq,arg,norm_sqr}.hip, lowpass.hip: the stream processors behind the multi-wave kernels (lockin_stream_procs.h)
+int lockin_stream_iq(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, bool split, hipStream_t s);
+int lockin_stream_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s);
+int lockin_stream_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y, size_t lanes, size_t frames, int layout, hipStream_t s);
+int lowpass_stream(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s);
+
 namespace {
 
 // The multi-wave kernels take FrameMajor always and LaneMajor for whole 16-frame batches on 16-byte aligned rows
@@ -45,21 +51,6 @@ inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t f
 }
 
 // ------------------------------------------------------------- processors
-template <int N, int K>
-struct LowpassProc {
-    using In = int32_t;
-    using Out = int32_t;
-    static constexpr bool HAS_IN = true;
-    static constexpr int LDS_WORDS = 0;
-    static constexpr int IN_DIV = 1;
-    static constexpr int COST = 40 * N * K;
-    using Params = LpParams;
-    LpBank<N, K> b;
-    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane) { b.load(st, lanes, lane, 0); }
-    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane) { b.store(st, lanes, lane, 0); }
-    __device__ __forceinline__ Out step(const Params &p, In x) { return b.step(p, x); }
-};
-
 // Accu (src/accu.rs:34-41, pre-increment) -> Complex::from_angle (src/complex.rs:237-240)
 // CIRCLE: cossin through the full-circle table (dds_dev.h cossin_circle: 9 VALU + 2 LDS instructions instead of ~28 + 1, 24 KiB of LDS
 // per workgroup, filled at the start of every workgroup) — taken by FrameMajor calls of 256 frames or more (idsp_dds_i32); the 512-byte
@@ -111,111 +102,6 @@ struct DdsProcT {
     }
 };
 using DdsProc = DdsProcT<false>;
-
-// src/lockin.rs:30-39 -> :17-27.  Mixer `x * Q32<32>` =
-// ((q as i64 * x as i64) >> 32) as i32 (dsp-fixedpoint/src/lib.rs:449-456).
-template <int N, int K>
-struct LockinProc {
-    using In = int32_t;
-    using Out = Cplx;
-    static constexpr bool HAS_IN = true;
-    static constexpr int LDS_WORDS = 1 << kCossinDepth;
-    static constexpr int IN_DIV = 1;
-    static constexpr int COST = 110 + 80 * N * K;
-    using Params = LpParams;
-    const uint32_t *lut;
-    uint32_t acc, inc;
-    LpBank<N, K> bi, bq;
-    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
-    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
-    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
-    {
-        acc = st[lane];
-        inc = st[lanes + lane];
-        bi.load(st, lanes, lane, 2);
-        bq.load(st, lanes, lane, 2 + 2 * N * K);
-    }
-    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
-    {
-        st[lane] = acc;
-        bi.store(st, lanes, lane, 2);
-        bq.store(st, lanes, lane, 2 + 2 * N * K);
-    }
-    static constexpr int BATCH = 4;
-    using Pre = Cplx;
-    __device__ __forceinline__ Pre pre(const Params &)
-    {
-        acc += inc;
-        return cossin_dev(int32_t(acc), lut);
-    }
-    __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo)
-    {
-        const int32_t xi = __mulhi(lo.re, x);
-        const int32_t xq = __mulhi(lo.im, x);
-        return Cplx{bi.step(p, xi), bq.step(p, xq)};
-    }
-};
-
-// I/Q arms on two adjacent threads ("virtual lanes" 2*lane + iq): used when the
-// lane count alone cannot give every SIMD a wave (C4: 32768 lanes = 512 waves).
-// Both threads step the same phase accumulator and evaluate cossin; each runs
-// one arm of the mixer + lowpass cascade and writes one word of Complex<i32>,
-// so a wave still stores 256 contiguous bytes per frame.
-template <int N, int K>
-struct LockinSplitProc {
-    using In = int32_t;
-    using Out = int32_t;
-    static constexpr bool HAS_IN = true;
-    static constexpr int LDS_WORDS = 1 << kCossinDepth;
-    static constexpr int IN_DIV = 2;
-    static constexpr int COST = 70 + 40 * N * K;
-    using Params = LpParams;
-    const uint32_t *lut;
-    uint32_t acc, inc;
-    bool q;
-    LpBank<N, K> b;
-    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
-    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
-    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t vlanes, size_t vlane)
-    {
-        const size_t lanes = vlanes / 2, lane = vlane / 2;
-        q = vlane & 1;
-        acc = st[lane];
-        inc = st[lanes + lane];
-        b.load(st, lanes, lane, 2 + (q ? 2 * N * K : 0));
-    }
-    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t vlanes, size_t vlane)
-    {
-        const size_t lanes = vlanes / 2, lane = vlane / 2;
-        if (!q) st[lane] = acc;
-        b.store(st, lanes, lane, 2 + (q ? 2 * N * K : 0));
-    }
-    static constexpr int BATCH = 4;
-    using Pre = int32_t;  // this arm's LO component
-    __device__ __forceinline__ Pre pre(const Params &)
-    {
-        acc += inc;
-        const Cplx lo = cossin_dev(int32_t(acc), lut);
-        return q ? lo.im : lo.re;
-    }
-    // The two threads of a lane evaluate the LO of alternate frames (thread q: frames 2j + q) and
-    // swap the component the partner needs with one DPP move: 16 instead of 32 cossin
-    // instructions per frame and thread on a VALU-bound kernel.
-    __device__ __forceinline__ void pre_batch(const Params &, Pre (&out)[BATCH])
-    {
-#pragma unroll
-        for (int j = 0; j < BATCH / 2; j++) {
-            const uint32_t ph = acc + inc * uint32_t(2 * j + 1) + (q ? inc : 0u);
-            const Cplx lo = cossin_dev(int32_t(ph), lut);
-            const int32_t mine = q ? lo.im : lo.re, other = q ? lo.re : lo.im;
-            const int32_t recv = pair_swap(other);
-            out[2 * j] = q ? recv : mine;
-            out[2 * j + 1] = q ? mine : recv;
-        }
-        acc += inc * uint32_t(BATCH);
-    }
-    __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo) { return b.step(p, __mulhi(lo, x)); }
-};
 
 template <bool CIRCLE>
 struct DdsSplitProcT {
@@ -479,87 +365,6 @@ __global__ __launch_bounds__(kWave *(NF + 1)) __attribute__((amdgpu_waves_per_eu
     }
 }
 
-// Lock-in with the polar read-out fused on the same thread: `Lockin::process(..)` (src/lockin.rs:30-39)
-// followed by `Complex::<i32>::arg()` (src/complex.rs:254-256, MODE 0, i32) or `norm_sqr()`
-// (src/complex.rs:214-217, MODE 1, i64 with the wrapping sum of a release build).  Saves the 8 byte/sample
-// Complex<i32> round trip through HBM of `lockin` + `atan2`.
-template <int N, int K, int MODE>
-struct LockinPolarProc {
-    using In = int32_t;
-    using Out = std::conditional_t<MODE == 0, int32_t, int64_t>;
-    static constexpr bool HAS_IN = true;
-    static constexpr int kLut = 1 << kCossinDepth;
-    static constexpr int LDS_WORDS = kLut + (MODE == 0 ? 32 : 0);  // cossin table, atan2 reciprocal table
-    static constexpr int IN_DIV = 1;
-    static constexpr bool LM_ONE_FORM = true;  // stream fall-back of the multi-wave kernel: one LaneMajor form is enough
-    // three or four cascaded second-order arms + atan2 next to the staged kernel's 128 staging registers: 12 / 116 B of scratch per
-    // thread (tools/check_scratch.py) — those stay on the tile kernel
-    static constexpr bool LM_STAGED = !(MODE == 0 && N * K >= 6);
-    static constexpr int COST = 110 + 80 * N * K + (MODE == 0 ? 80 : 10);
-    using Params = LpParams;
-    const uint32_t *lut;
-    uint32_t acc, inc;
-    LpBank<N, K> bi, bq;
-    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n)
-    {
-        fill_cossin(sh, tid, n);
-        if constexpr (MODE == 0)
-            for (int i = tid; i < 32; i += n) sh[kLut + i] = d_atan2_table[i];
-    }
-    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
-    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
-    {
-        acc = st[lane];
-        inc = st[lanes + lane];
-        bi.load(st, lanes, lane, 2);
-        bq.load(st, lanes, lane, 2 + 2 * N * K);
-    }
-    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
-    {
-        st[lane] = acc;
-        bi.store(st, lanes, lane, 2);
-        bq.store(st, lanes, lane, 2 + 2 * N * K);
-    }
-    static constexpr int BATCH = 4;
-    using Pre = Cplx;
-    __device__ __forceinline__ Pre pre(const Params &)
-    {
-        acc += inc;
-        return cossin_dev(int32_t(acc), lut);
-    }
-    __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo)
-    {
-        const int32_t re = bi.step(p, __mulhi(lo.re, x));
-        const int32_t im = bq.step(p, __mulhi(lo.im, x));
-        if constexpr (MODE == 0)
-            return atan2_dev(im, re, lut + kLut);
-        else
-            return int64_t(uint64_t(int64_t(re) * re) + uint64_t(int64_t(im) * im));
-    }
-};
-template <int N, int K>
-using LockinArgProc = LockinPolarProc<N, K, 0>;
-template <int N, int K>
-using LockinNormSqrProc = LockinPolarProc<N, K, 1>;
-
-template <template <int, int> class Proc, class OutT>
-int dispatch_nk(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, OutT *y, size_t lanes, size_t frames,
-                int layout, hipStream_t s)
-{
-    const LpParams p = lp_params(cfg);
-#define IDSP_CASE(N, K) \
-    if (cfg->order == N && cfg->cascade == K) return launch_stream<Proc<N, K>>(p, state, x, y, lanes, frames, layout, s)
-    IDSP_CASE(1, 1);
-    IDSP_CASE(1, 2);
-    IDSP_CASE(1, 3);
-    IDSP_CASE(1, 4);
-    IDSP_CASE(2, 1);
-    IDSP_CASE(2, 2);
-    IDSP_CASE(2, 3);
-    IDSP_CASE(2, 4);
-#undef IDSP_CASE
-    return fail(IDSP_EINVAL, "unsupported lowpass configuration");
-}
 
 }  // namespace
 }  // namespace idsp
@@ -633,9 +438,7 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
     if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, false))
         return lockin_waves_iq(cfg, state, x, y, lanes, frames, layout, waves, as_stream(stream));
     // too few lanes to give every SIMD a wave: put the I and Q arms on separate threads (both layouts)
-    if (lanes <= kSplitMaxLanes)
-        return dispatch_nk<LockinSplitProc, int32_t>(cfg, state, x, y, 2 * lanes, frames, layout, as_stream(stream));
-    return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, as_stream(stream));
+    return lockin_stream_iq(cfg, state, x, y, lanes, frames, layout, lanes <= kSplitMaxLanes, as_stream(stream));
 }
 
 int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
@@ -647,7 +450,7 @@ int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *
     if (lanes == 0) return IDSP_OK;
     if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, true))
         return lockin_waves_arg(cfg, state, x, y, lanes, frames, layout, waves, as_stream(stream));
-    return dispatch_nk<LockinArgProc, int32_t>(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
+    return lockin_stream_arg(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 
 int idsp_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y, size_t lanes,
@@ -659,7 +462,7 @@ int idsp_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int3
     if (lanes == 0) return IDSP_OK;
     if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, false))
         return lockin_waves_norm_sqr(cfg, state, x, y, lanes, frames, layout, waves, as_stream(stream));
-    return dispatch_nk<LockinNormSqrProc, int64_t>(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
+    return lockin_stream_norm_sqr(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 
 int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
@@ -703,7 +506,7 @@ int idsp_lowpass_i32(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, 
     if (rc) return rc;
     if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
     if (lanes == 0) return IDSP_OK;
-    return dispatch_nk<LowpassProc, int32_t>(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
+    return lowpass_stream(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 
 }  // extern "C"
