@@ -52,7 +52,7 @@ inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t f
 
 // ------------------------------------------------------------- processors
 // Accu (src/accu.rs:34-41, pre-increment) -> Complex::from_angle (src/complex.rs:237-240)
-// CIRCLE: cossin through the full-circle table (dds_dev.h cossin_circle: 9 VALU + 2 LDS instructions instead of ~28 + 1, 24 KiB of LDS
+// CIRCLE: cossin through the full-circle table (dds_dev.h cossin_circle: 9 VALU + 1 LDS instruction instead of ~28 + 1, 16 KiB of LDS
 // per workgroup, filled at the start of every workgroup) — taken by FrameMajor calls of 256 frames or more (idsp_dds_i32); the 512-byte
 // table otherwise (short calls, LaneMajor — its staged kernel needs the LDS for the 32 KiB tile slot of every wave — and the one-thread-per-lane form).
 template <bool CIRCLE>
