@@ -30,7 +30,7 @@ namespace {
 // The multi-wave kernels take FrameMajor always and LaneMajor for whole 16-frame batches on 16-byte aligned rows
 // (IDSP_LOCKIN_NO_WAVES=1 keeps everything on the one- / two-thread-per-lane stream kernels below).
 // Returns the wave count per 64 lanes, 0 = use the stream kernels.
-inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t frames, int layout, bool heavy_readout)
+inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t frames, int layout, bool heavy_readout, int arm_weight = 0)
 {
     static const bool off = diag_env("IDSP_LOCKIN_NO_WAVES") != nullptr;
     static const int forced = [] {
@@ -47,7 +47,9 @@ inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t f
     // `[Lowpass<N>; 2]` is the stage-wave kernel's at these lane counts).  Two 6-wave workgroups with 16-frame batches do not share a CU, so not above.
     if (layout == IDSP_FRAME_MAJOR && lanes <= 16384) return 6;
     // measured at 4096 frames (arg read-out): 6 waves 0.64 ms at 32768 lanes (4 waves: 0.73), 4 waves 1.07 ms at 65536 (6: 1.12)
-    return heavy_readout && lanes <= kSplitMaxLanes ? 6 : 4;
+    // (`arm_weight` = order x cascade: with six and more second-order-equivalents per arm the arm waves are the longer path again and the four-wave
+    // form with 16-frame batches wins: `[Lowpass<2>; 4]` -> arg at 32768 lanes 0.58 against 0.74 ms, profiles/r03_perf_c4small_32768.jsonl)
+    return heavy_readout && lanes <= kSplitMaxLanes && arm_weight < 6 ? 6 : 4;
 }
 
 // ------------------------------------------------------------- processors
@@ -448,7 +450,7 @@ int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *
     if (rc) return rc;
     if ((rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout))) return rc;
     if (lanes == 0) return IDSP_OK;
-    if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, true))
+    if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, true, cfg->order * cfg->cascade))
         return lockin_waves_arg(cfg, state, x, y, lanes, frames, layout, waves, as_stream(stream));
     return lockin_stream_arg(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
 }

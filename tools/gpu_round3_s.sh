@@ -1,7 +1,6 @@
 #!/bin/bash
-# stage kernel with one lane group per workgroup and an input ring of 5 / 4 / 3 slots (66 / 62 / 58 KiB of LDS): do two workgroups share a CU below 64 KiB?
+# lock-in forms for [Lowpass<N>; K], K != 2, at 32768 lanes: default against 6 waves x 16 frames (66 KiB of LDS with the 16-byte table: do two share a CU now?)
 mkdir -p gpurun_out/s
-for v in ring5 ring4 ring3; do echo "== $v"; timeout 200 build/exp_ls_$v a b c d | python3 -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print(d['mode'], 'G', d['G'], d['lanes'], d['y_mismatches'], d['state_mismatches'], 'waves', d['ms_waves'], 'stages', d['ms_stages'], d['frac_stages'])"; done 2>&1 | tee gpurun_out/s/exp_lockin_ring.txt
+for f in "default" "IDSP_LOCKIN_WAVES=6 IDSP_LOCKIN_B=16" "IDSP_LOCKIN_WAVES=4 IDSP_LOCKIN_B=16"; do
+  if [ "$f" = default ]; then env python tools/perf_configs.py --only c4small 2>&1 | grep "32768" | sed "s/^/[$f] /"; else env IDSP_DIAG=1 $f python tools/perf_configs.py --only c4small 2>&1 | grep "32768" | sed "s/^/[$f] /"; fi
+done | tee gpurun_out/s/perf_c4small_32768.jsonl

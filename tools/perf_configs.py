@@ -393,6 +393,10 @@ def main():
                 lockin(order, cascade, lanes, 4096, FM, it, "C4s")
         lockin(2, 2, 16384, 4096, FM, it, "C4s", "arg")
         lockin(2, 1, 16384, 4096, FM, it, "C4s", "arg")
+        lockin(2, 1, 32768, 4096, FM, it, "C4s", "arg")
+        lockin(1, 1, 32768, 4096, FM, it, "C4s", "arg")
+        lockin(2, 4, 32768, 4096, FM, it, "C4s", "arg")
+        lockin(2, 4, 32768, 4096, FM, it, "C4s")
     if want("nw"):
         biquad("normal_i32_df1", torch.int32, 4, 65536, 4096, FM, 1, it, "nw")
         biquad("normal_f32_df1", torch.float32, 4, 65536, 4096, FM, 1, it, "nw")
