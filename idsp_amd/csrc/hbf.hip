@@ -37,6 +37,9 @@ int hbf_wave_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y
                  bool lane_major, hipStream_t stream);
 int hbf_wave_int(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
                  bool lane_major, hipStream_t stream);
+// hbf_ring_dec.hip: LDS-DMA ring decimators (0 = launched, 1 = shape not covered, 2 = HIP error)
+int hbf_ring_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
+                 bool lane_major, hipStream_t stream);
 
 namespace {
 
@@ -573,6 +576,14 @@ int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state,
     const size_t R = size_t(1) << cfg->stages;
     const void *wide = dec ? static_cast<const void *>(x) : static_cast<const void *>(y);
     if (ts >= 0 && reinterpret_cast<uintptr_t>(wide) % 16 == 0 && (lm ? (frames * R) % 4 == 0 : R >= 4)) {
+        // decimators: the LDS-DMA ring kernels of hbf_ring.h first (LANE_MAJOR any cascade; FRAME_MAJOR /16 on whole
+        // 16-lane groups), then the wave-per-lane kernels of hbf_wave.h
+        static const bool no_ring = diag_env("IDSP_HBF_NO_RING") != nullptr;
+        if (dec && !no_ring) {
+            const int rr = hbf_ring_dec(ts, cfg->stages, static_cast<uint32_t *>(state), x, y, lanes, frames, lm, as_stream(stream));
+            if (rr == 0) return launch_status();
+            if (rr != 1) return IDSP_EHIP;
+        }
         const int rc = dec ? hbf_wave_dec(ts, cfg->stages, static_cast<uint32_t *>(state), x, y, lanes, frames, lm, as_stream(stream))
                            : hbf_wave_int(ts, cfg->stages, static_cast<uint32_t *>(state), x, y, lanes, frames, lm, as_stream(stream));
         if (rc == 0) return launch_status();

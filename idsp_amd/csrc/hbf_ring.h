@@ -1,0 +1,694 @@
+// hbf_ring.h — half-band decimator cascades (HBF_DEC_CASCADE over HBF_TAPS / HBF_TAPS_98, src/hbf.rs:142-192,385-421)
+// on an LDS-DMA input ring with packed-f32 arithmetic.  Round 4 replacement of hbf_wave.h's decimator kernels for the
+// shapes it covers (they stay as the fallback, and the interpolators stay there).
+//
+// Why: the round-3 kernel was co-limited three ways at C3 (/16, 16384 lanes x 65536 samples) — per 1024 input samples a
+// wave issued ~285 essential f32 VALU operations at the ~4.2 cycles this chip takes per non-packed f32 operation and
+// SIMD (0.6 ms of VALU), ~290 LDS cycles on a CU whose 16 waves share one LDS (73 % busy: the P = 1 last stage read its
+// 46-word window with 46 `ds_read_b32`), and its input went through 32 VGPRs of double buffer.  Here:
+//
+//  * input: `global_load_lds_dwordx4` into a ring of four 1 KiB slots per lane (one request per wave and slot, three
+//    to four in flight), no VGPR staging.  LANE_MAJOR: every wave streams its own contiguous row.  FRAME_MAJOR (/16):
+//    16 lanes per workgroup; wave w's request moves frame 16 q + w of ALL 16 lanes = 1 KiB of contiguous global memory
+//    into row 16 q + w of a [64 frames][16 lanes x 64 B + 64 B pad] tile; one LDS barrier per slot hands the rows over.
+//  * stage 0 reads the raw interleaved [even, odd] samples straight from the ring (no split into two streams): thread
+//    t of slot q owns 16-byte piece t (2 outputs) and reads pieces t - M .. t; consecutive threads read consecutive
+//    pieces (conflict-free `ds_read_b128`), the pieces before the slot are the tail of the previous slot (the ring is
+//    the reference's `odd` / `even` history, src/hbf.rs:166-183).
+//  * arithmetic: the symmetric sums `new + old` (src/hbf.rs:60-63) stay scalar `v_add_f32` (their operands sit an odd
+//    distance apart, so no two of them form aligned register pairs), their results are placed as pairs of neighbouring
+//    outputs, and the tap multiplies and the sequential accumulation run as `v_pk_mul_f32` / `v_pk_add_f32` on those
+//    pairs: 2M instead of 3M VALU operations per output, every IEEE operation and its order per output unchanged
+//    (nothing fused, nothing re-associated: -ffp-contract=off).  The lowest-rate stages have one output per thread;
+//    there the pairs run along the taps (k, k + 1) with the reversed `new` pair selected by `op_sel`, and the stage's odd
+//    stream is kept twice, one word apart, so that odd and even threads both read aligned 8-byte pairs.
+//  * one round = 1024 input samples per lane = 4 slots; stages >= 1 run once per round with 4 / 2 / 1 outputs per thread.
+//
+// Rounds past the end of the data, and the pieces of the last round past it, are REQUESTED like any other (from a
+// clamped, valid address) and computed on whatever they hold; only the stores, the history roll and the state
+// write-back know the true count.  That keeps the request / wait bookkeeping static.
+#pragma once
+
+#include <type_traits>
+#include <typeinfo>
+#include <utility>
+
+#include "common.h"
+#include "hbf_taps.h"
+#include "lds_dma.h"
+
+namespace idsp {
+namespace hbfr {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+// One `ds_read_b64` that stays one: the volatile access is not merged with its neighbours into `ds_read2_b64` (half
+// the LDS rate, 8-bit offsets).  Volatile accesses do not take part in address-space inference, hence the explicit
+// LDS pointer (a generic one would make this a `flat_load`).
+__device__ __forceinline__ v2f lds_read_b64(const float *p)
+{
+    return *(const volatile __attribute__((address_space(3))) v2f *)p;
+}
+
+constexpr int kW = 64;               // threads per wave
+constexpr int kSC = 1024;            // raw samples per lane and round
+constexpr int kSlots = 4;            // ring slots = requests per lane and round
+constexpr int kSlotW = kSC / kSlots; // 256 words = 1 KiB = one request
+constexpr int up4(int v) { return (v + 3) & ~3; }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Cascade geometry.  Stage s halves the rate; stage 0 reads the ring, stages s >= 1 read their [even, odd] streams
+// from the wave's LDS region: E_s (M - 1 words of history, then N(s) samples) and O_s (2M - 1 words of history, then
+// N(s) samples), O_s twice when the stage runs one output per thread.
+template <int TS, int S>
+struct Lay {
+    static constexpr int stages = S;
+    static constexpr int rate = 1 << S;
+    static constexpr int M(int s) { return kHbfM[TS][hbf_tuple_index(true, S, s)]; }
+    static constexpr float tap(int s, int k) { return kHbfTaps[TS][hbf_tuple_index(true, S, s)][k]; }
+    static constexpr int He(int s) { return M(s) - 1; }
+    static constexpr int Ho(int s) { return 2 * M(s) - 1; }
+    static constexpr int N(int s) { return kSC >> (s + 1); }  // outputs of stage s per round
+    static constexpr int P(int s) { return N(s) >= 4 * kW ? 4 : (N(s) >= 2 * kW ? 2 : 1); }
+    static constexpr bool dual(int s) { return s >= 1 && s < S && P(s) == 1; }
+    static constexpr int sizeE(int s) { return up4(He(s) + N(s) + 4); }
+    static constexpr int sizeO(int s) { return up4(Ho(s) + N(s) + 6); }
+    static constexpr int offE(int s)
+    {
+        int o = 0;
+        for (int t = 1; t < s; t++) o += sizeS(t);
+        return o;
+    }
+    static constexpr int offO(int s) { return offE(s) + sizeE(s); }
+    // Second copy: element j at offOB + Ho + j + 1.  In a 32-lane `ds_read_b64` group the 16 even threads read 32
+    // consecutive words of the first copy from offO + t and the 16 odd threads 32 consecutive words of the second from
+    // offOB + t + 1: the copies sit == 30 (mod 64) words apart, so that the two runs cover all 64 banks once.
+    static constexpr int gapB(int s)
+    {
+        int d = sizeO(s);
+        while (d % 64 != 30) d += 2;
+        return d;
+    }
+    static constexpr int offOB(int s) { return offO(s) + gapB(s); }
+    static constexpr int sizeS(int s) { return sizeE(s) + (dual(s) ? up4(gapB(s) + sizeO(s)) : sizeO(s)); }
+    static constexpr int words = offE(S);
+    static constexpr int state_off(int s)
+    {
+        int o = 0;
+        for (int t = 0; t < s; t++) o += 3 * M(t) - 2;
+        return o;
+    }
+};
+
+// ------------------------------------------------------------------ history roll of the streams of stages >= 1
+// After a round that consumed n raw samples, stream words [n_s, n_s + H) become the history [0, H) (src/hbf.rs:182-183
+// `copy_within`), n_s = n >> (s + 1).  All histories are one flat list; thread t moves words t, t + 64, ...
+template <class L>
+struct Roll {
+    static constexpr int total()
+    {
+        int t = 0;
+        for (int s = 1; s < L::stages; s++) t += L::He(s) + L::Ho(s) * (L::dual(s) ? 2 : 1);
+        return t;
+    }
+    static constexpr int per_thread = (total() + kW - 1) / kW;
+    int dst[per_thread > 0 ? per_thread : 1], sh[per_thread > 0 ? per_thread : 1], full[per_thread > 0 ? per_thread : 1];
+
+    __device__ __forceinline__ void plan(int lid)
+    {
+#pragma unroll
+        for (int k = 0; k < per_thread; k++) {
+            const int j = lid + k * kW;
+            int base = 0, d = 0, h = 1;
+            static_for<1, L::stages>([&](auto s) {
+                constexpr int s_ = decltype(s)::value;
+                if (j >= base && j < base + L::He(s_)) d = L::offE(s_) + (j - base), h = s_ + 1;
+                base += L::He(s_);
+                if (j >= base && j < base + L::Ho(s_)) d = L::offO(s_) + (j - base), h = s_ + 1;
+                base += L::Ho(s_);
+                if constexpr (L::dual(s_)) {
+                    if (j >= base && j < base + L::Ho(s_)) d = L::offOB(s_) + 1 + (j - base), h = s_ + 1;
+                    base += L::Ho(s_);
+                }
+            });
+            dst[k] = d;
+            sh[k] = h;
+            full[k] = d + (kSC >> h);
+        }
+    }
+    // FULL: a whole round (n == kSC), sources known since plan()
+    template <bool FULL>
+    __device__ __forceinline__ void run(float *str, int lid, int n) const
+    {
+        if constexpr (per_thread > 0) {
+            float t[per_thread];
+#pragma unroll
+            for (int k = 0; k < per_thread; k++)
+                if ((k + 1) * kW <= total() || lid + k * kW < total()) t[k] = str[FULL ? full[k] : dst[k] + (n >> sh[k])];
+            lds_wave_sync();
+#pragma unroll
+            for (int k = 0; k < per_thread; k++)
+                if ((k + 1) * kW <= total() || lid + k * kW < total()) str[dst[k]] = t[k];
+            lds_wave_sync();
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ stage bodies
+// raw sample n (relative to the thread's own piece, n in [-4M, 3]) out of the pieces t - M .. t
+template <int M, int n>
+__device__ __forceinline__ float raw_at(const v4f *pc)
+{
+    constexpr int m = n + 4 * M;
+    static_assert(m >= 0 && m < 4 * (M + 1), "raw sample outside the loaded pieces");
+    return pc[m >> 2][m & 3];
+}
+
+// Stage 0 on one thread's pieces: the two outputs 2t, 2t + 1 of its slot.  e_0[d] = raw[2d], o_0[d] = raw[2d + 1]
+// relative to output 2t; y_i = sum_k (o[i - k] + o[i - (2M-1) + k]) * c_k + e[i - (M-1)]  (src/hbf.rs:46-68,163-185).
+// The sum starts from -0.0 (f32::sum), and -0.0 + p == p for every p, so the first product seeds the accumulator.
+template <class L>
+__device__ __forceinline__ v2f stage0_pair(const v4f *pc)
+{
+    constexpr int M = L::M(0);
+    v2f acc{0.f, 0.f};
+    static_for<0, M>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        const float t0 = raw_at<M, 2 * (0 - k) + 1>(pc) + raw_at<M, 2 * (0 - (2 * M - 1) + k) + 1>(pc);
+        const float t1 = raw_at<M, 2 * (1 - k) + 1>(pc) + raw_at<M, 2 * (1 - (2 * M - 1) + k) + 1>(pc);
+        const v2f p = v2f{t0, t1} * L::tap(0, k);
+        if constexpr (k == 0)
+            acc = p;
+        else
+            acc = acc + p;
+    });
+    acc.x = acc.x + raw_at<M, 2 * (0 - (M - 1))>(pc);
+    acc.y = acc.y + raw_at<M, 2 * (1 - (M - 1))>(pc);
+    return acc;
+}
+
+// Stage s >= 1 with P = 4 or 2 outputs per thread: window words w[j] = O_s element P t - Ho + j, pairs of neighbouring
+// outputs.  sink(q, y) receives outputs P t + 2q and P t + 2q + 1.
+template <class L, int s, class Sink>
+__device__ __forceinline__ void stage_pairs(const float *str, int lid, Sink &&sink)
+{
+    constexpr int M = L::M(s), P = L::P(s);
+    static_assert(P == 4 || P == 2, "pairs of neighbouring outputs");
+    constexpr int NWIN = 2 * M + P - 1, NV = (NWIN + P - 1) / P;
+    float w[NV * P], e[P];
+    const float *O = str + L::offO(s) + P * lid;
+    const float *E = str + L::offE(s) + P * lid;
+    if constexpr (P == 4) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const v4f t = reinterpret_cast<const v4f *>(O)[v];
+            w[4 * v] = t.x, w[4 * v + 1] = t.y, w[4 * v + 2] = t.z, w[4 * v + 3] = t.w;
+        }
+        const v4f t = *reinterpret_cast<const v4f *>(E);
+        e[0] = t.x, e[1] = t.y, e[2] = t.z, e[3] = t.w;
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const v2f t = lds_read_b64(O + 2 * v);
+            w[2 * v] = t.x, w[2 * v + 1] = t.y;
+        }
+        const v2f t = *reinterpret_cast<const v2f *>(E);
+        e[0] = t.x, e[1] = t.y;
+    }
+    static_for<0, P / 2>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        v2f acc{0.f, 0.f};
+        static_for<0, M>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            const float t0 = w[2 * q + 2 * M - 1 - k] + w[2 * q + k];
+            const float t1 = w[2 * q + 1 + 2 * M - 1 - k] + w[2 * q + 1 + k];
+            const v2f p = v2f{t0, t1} * L::tap(s, k);
+            if constexpr (k == 0)
+                acc = p;
+            else
+                acc = acc + p;
+        });
+        acc = acc + v2f{e[2 * q], e[2 * q + 1]};
+        sink(q_, acc);
+    });
+}
+
+// Stage s >= 1 with one output per thread (N(s) <= 64): pairs run along the taps.  Window words w[j] = O_s element
+// t - Ho + j, read as aligned pairs from the copy whose alignment matches the thread's parity.  With wp[m] =
+// (w[2m], w[2m+1]): old pair (k, k+1) = wp[k/2], new pair = wp[M-1-k/2] reversed (op_sel).  Returns y[t].
+template <class L, int s>
+__device__ __forceinline__ float stage_single(const float *str, int lid)
+{
+    constexpr int M = L::M(s);
+    const float *O = str + ((lid & 1) ? L::offOB(s) + 1 + lid : L::offO(s) + lid);
+    v2f wp[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) wp[m] = lds_read_b64(O + 2 * m);
+    const float ev = str[L::offE(s) + lid];
+    float acc = 0.f;
+    static_for<0, M / 2>([&](auto h_) {
+        constexpr int h = decltype(h_)::value, k = 2 * h;
+        const v2f nw = wp[M - 1 - h], od = wp[h];
+        const v2f t = v2f{nw.y, nw.x} + od;
+        const v2f p = t * v2f{L::tap(s, k), L::tap(s, k + 1)};
+        if constexpr (k == 0)
+            acc = p.x;
+        else
+            acc = acc + p.x;
+        acc = acc + p.y;
+    });
+    if constexpr (M % 2 == 1) {
+        const v2f mid = wp[(M - 1) / 2];  // (w[M-1], w[M]) = (old, new) of the centre-most tap
+        const float p = (mid.y + mid.x) * L::tap(s, M - 1);
+        if constexpr (M == 1)
+            acc = p;
+        else
+            acc = acc + p;
+    }
+    return acc + ev;
+}
+
+// ---------------------------------------------------------------------------------------- one wave's cascade
+// Everything a wave does between taking its pieces out of the ring and handing the round's outputs to `Out`.
+template <class L>
+struct WaveCascade {
+    static constexpr int S = L::stages, M0 = L::M(0);
+    float *str;  // this wave's streams
+    int lid;
+    Roll<L> roll;
+
+    __device__ __forceinline__ void init(float *streams, int lane_id)
+    {
+        str = streams;
+        lid = lane_id;
+        roll.plan(lane_id);
+    }
+
+    // history of stages >= 1 <- state words (per stage: even[M-1] then odd[2M-1], oldest first; SoA across lanes)
+    __device__ __forceinline__ void load_state(const uint32_t *st, size_t lanes, size_t lane)
+    {
+        static_for<1, S>([&](auto s) {
+            constexpr int s_ = decltype(s)::value;
+            constexpr int He = L::He(s_), Ho = L::Ho(s_), so = L::state_off(s_);
+            if (lid < He) str[L::offE(s_) + lid] = __uint_as_float(st[size_t(so + lid) * lanes + lane]);
+            if (lid < Ho) {
+                const float v = __uint_as_float(st[size_t(so + He + lid) * lanes + lane]);
+                str[L::offO(s_) + lid] = v;
+                if constexpr (L::dual(s_)) str[L::offOB(s_) + 1 + lid] = v;
+            }
+        });
+    }
+    __device__ __forceinline__ void store_state(uint32_t *st, size_t lanes, size_t lane) const
+    {
+        static_for<1, S>([&](auto s) {
+            constexpr int s_ = decltype(s)::value;
+            constexpr int He = L::He(s_), Ho = L::Ho(s_), so = L::state_off(s_);
+            if (lid < He) st[size_t(so + lid) * lanes + lane] = __float_as_uint(str[L::offE(s_) + lid]);
+            if (lid < Ho) st[size_t(so + He + lid) * lanes + lane] = __float_as_uint(str[L::offO(s_) + lid]);
+        });
+    }
+
+    // stage 0 of slot q: y = outputs 2t, 2t+1 of the slot -> stage 1's streams (`ChunkIn<_, 2>`: consecutive outputs
+    // pair up as the next stage's [even, odd])
+    __device__ __forceinline__ void put_stage0(int q, v2f yv) const
+    {
+        static_assert(S >= 2, "a one-stage cascade stores stage 0 directly");
+        constexpr int j0 = 0;
+        const int j = q * (kSlotW / 4) + lid + j0;
+        str[L::offE(1) + L::He(1) + j] = yv.x;
+        str[L::offO(1) + L::Ho(1) + j] = yv.y;
+        if constexpr (L::dual(1)) str[L::offOB(1) + L::Ho(1) + 1 + j] = yv.y;
+    }
+
+    // stages 1 .. S-1 of a round; out(p, v): the thread's p-th output of the last stage = round output P t + p
+    template <class Out>
+    __device__ __forceinline__ void rest(Out &&out) const
+    {
+        static_for<1, S>([&](auto s) {
+            constexpr int s_ = decltype(s)::value;
+            constexpr int P = L::P(s_);
+            lds_wave_sync();  // the previous stage's stream writes (LDS operations of one wave execute in order)
+            if constexpr (P >= 2) {
+                stage_pairs<L, s_>(str, lid, [&](auto q_, v2f yv) {
+                    constexpr int q = decltype(q_)::value;
+                    if constexpr (s_ + 1 == S) {
+                        out(std::integral_constant<int, 2 * q>{}, yv.x);  // thread-local output index: round output P t + 2q
+                        out(std::integral_constant<int, 2 * q + 1>{}, yv.y);
+                    } else {
+                        const int j = (P / 2) * lid + q;
+                        str[L::offE(s_ + 1) + L::He(s_ + 1) + j] = yv.x;
+                        str[L::offO(s_ + 1) + L::Ho(s_ + 1) + j] = yv.y;
+                        if constexpr (L::dual(s_ + 1)) str[L::offOB(s_ + 1) + L::Ho(s_ + 1) + 1 + j] = yv.y;
+                    }
+                });
+            } else {
+                if (L::N(s_) >= kW || lid < L::N(s_)) {
+                    const float yv = stage_single<L, s_>(str, lid);
+                    if constexpr (s_ + 1 == S) {
+                        out(std::integral_constant<int, 0>{}, yv);
+                    } else {
+                        const int j = lid >> 1;
+                        if (lid & 1) {
+                            str[L::offO(s_ + 1) + L::Ho(s_ + 1) + j] = yv;
+                            if constexpr (L::dual(s_ + 1)) str[L::offOB(s_ + 1) + L::Ho(s_ + 1) + 1 + j] = yv;
+                        } else {
+                            str[L::offE(s_ + 1) + L::He(s_ + 1) + j] = yv;
+                        }
+                    }
+                }
+            }
+        });
+        lds_wave_sync();
+    }
+};
+
+// Request / wait bookkeeping.  Every wave issues exactly ONE request per slot and the output stores of a round at a
+// fixed place, so "my request for slot q has landed" is `s_waitcnt vmcnt(N)` with N = the vector-memory operations the
+// wave has issued since (requests and stores retire in issue order).  Two forms of the round body:
+//   FAST  whole rounds in the middle of the stream: static N, unclamped requests off an SGPR base, unpredicated stores
+//   SAFE  the first round (no store in the queue yet), and the last two (their requests reach past the data, the last
+//         one may store nothing): vmcnt(0), requests clamped to a valid address, predicated stores, runtime roll,
+//         state write-back.
+
+// =============================================================================================== LANE_MAJOR
+// x[(lane*frames + f)*R + k], y[lane*frames + f].  One wave per lane, no barriers.
+// LDS: [ring 4 x 1 KiB][streams].  Per round c and slot q: wait for slot q, read the pieces (slot q and the tail of
+// slot q-1), then request the refill of slot (q-1) & 3 — its last reader has just finished: (c, 3) at q = 0,
+// (c+1, q-1) otherwise.  Queue per round (S >= 2): R(c,3) R(c+1,0) R(c+1,1) R(c+1,2) ST(c); younger than the request
+// of slot q when its wait comes: 3, 3, 3, 2.  S = 1 stores after every slot: R ST R ST ... -> 5.
+template <class L>
+__global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float *x, float *y, const size_t lanes,
+                                                       const size_t frames)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_lm[];
+    constexpr int S = L::stages, R = L::rate, M0 = L::M(0);
+    constexpr int NOUT = kSC / R;  // outputs per round
+    const int lid = threadIdx.x;
+    const size_t lane = blockIdx.x;
+    float *ring = smem_lm, *str = smem_lm + kSC;
+    WaveCascade<L> wc;
+    wc.init(str, lid);
+
+    // stage-0 history -> the ring's tail (raw positions -1, -2, ... wrap to the end of slot 3)
+    {
+        constexpr int He = L::He(0), Ho = L::Ho(0);
+        if (lid < He) ring[kSC + 2 * (lid - He)] = __uint_as_float(st[size_t(lid) * lanes + lane]);
+        if (lid < Ho) ring[kSC + 2 * (lid - Ho) + 1] = __uint_as_float(st[size_t(He + lid) * lanes + lane]);
+    }
+    wc.load_state(st, lanes, lane);
+
+    // piece addresses (words): pa[i] = piece t - M0 + i relative to slot 0; in slot 0 the negative ones wrap
+    int pa[M0 + 1], pa0[M0 + 1];
+#pragma unroll
+    for (int i = 0; i <= M0; i++) {
+        const int g = lid - M0 + i;
+        pa[i] = 4 * g;
+        pa0[i] = 4 * (g < 0 ? g + kSC / 4 : g);
+    }
+
+    const size_t total = frames * size_t(R);  // raw samples of the lane
+    const size_t npieces = total / 4;          // whole 16-byte pieces (the dispatcher guarantees total % 4 == 0)
+    const float *xl = x + lane * total;
+    float *yl = y + lane * frames;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)ring;  // LDS byte address of the ring
+    const uint32_t voff = uint32_t(lid) * 16;
+    // SAFE request of slot q of round c: piece 256 c + 64 q + t, clamped to piece 0 of the row past the end
+    auto request_safe = [&](size_t c, int q) {
+        const size_t g = c * (kSC / 4) + size_t(q) * (kSlotW / 4) + size_t(lid);
+        const float *src = xl + (g < npieces ? g * 4 : 0);
+#ifndef IDSP_EXP_HBF_NOLOAD
+        glds16(src, ring_lds + uint32_t(q) * (kSlotW * 4));
+#endif
+    };
+    const size_t rounds = (total + kSC - 1) / kSC;
+
+    auto round = [&](auto safe_, size_t c) {
+        constexpr bool SAFE = decltype(safe_)::value;
+        const bool last = SAFE && c + 1 == rounds;
+        const int n = last ? int(total - c * kSC) : kSC;  // raw samples of this round
+        const float *xc = uniform_ptr(xl + c * kSC);       // the round's 4 KiB (FAST requests)
+        static_for<0, kSlots>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            if constexpr (SAFE)
+                wait_vmcnt<0>();
+            else
+                wait_vmcnt<(S >= 2 ? (q == 3 ? 2 : 3) : 5)>();
+            v4f pc[M0 + 1];
+#pragma unroll
+            for (int i = 0; i <= M0; i++) pc[i] = *reinterpret_cast<const v4f *>(ring + (q == 0 ? pa0[i] : pa[i] + q * kSlotW));
+            lds_wave_sync();
+            if constexpr (SAFE) {
+                // stage-0 state of the call = the last raw samples before `n`: take them while the previous slot is intact
+                if (last && q == (n - 1) / kSlotW) {
+                    constexpr int He = L::He(0), Ho = L::Ho(0);
+                    if (lid < He) st[size_t(lid) * lanes + lane] = __float_as_uint(ring[(n + 2 * (lid - He) + kSC) % kSC]);
+                    if (lid < Ho) st[size_t(He + lid) * lanes + lane] = __float_as_uint(ring[(n + 2 * (lid - Ho) + 1 + kSC) % kSC]);
+                    lds_wave_sync();
+                }
+                if constexpr (q == 0)
+                    request_safe(c, 3);
+                else
+                    request_safe(c + 1, q - 1);
+            } else {
+#ifndef IDSP_EXP_HBF_NOLOAD
+                // the instruction offset moves the global AND the LDS address: slot s of the round at xc + s KiB -> ring + s KiB
+                if constexpr (q == 0)
+                    glds16_si<3 * kSlotW * 4>(xc, voff, ring_lds);
+                else
+                    glds16_si<(q - 1) * kSlotW * 4>(xc + kSC, voff, ring_lds);
+#endif
+            }
+#ifdef IDSP_EXP_HBF_NOSTAGES
+            if (pc[M0].x == 12345.678f) yl[0] = pc[0].y;
+#else
+            const v2f y0 = stage0_pair<L>(pc);
+            if constexpr (S == 1) {
+                const int i = q * (kSlotW / 2) + 2 * lid;
+                float *dst = yl + c * NOUT + i;
+                if (!SAFE || i + 1 < n / 2)
+                    *reinterpret_cast<v2f *>(dst) = y0;
+                else if (i < n / 2)
+                    dst[0] = y0.x;
+            } else {
+                wc.put_stage0(q, y0);
+            }
+#endif
+        });
+#ifndef IDSP_EXP_HBF_NOSTAGES
+        if constexpr (S >= 2) {
+            constexpr int P = L::P(S - 1), NL = L::N(S - 1);
+            float ov[P];
+            wc.rest([&](auto p_, float v) { ov[decltype(p_)::value] = v; });
+            const int nout = n / R, i0 = P * lid;
+            float *dst = yl + c * NOUT + i0;
+            if constexpr (P == 4) {
+                if (!SAFE || i0 + 3 < nout)
+                    *reinterpret_cast<v4f *>(dst) = v4f{ov[0], ov[1], ov[2], ov[3]};
+                else
+                    for (int p = 0; p < 4; p++)
+                        if (i0 + p < nout) dst[p] = ov[p];
+            } else if constexpr (P == 2) {
+                if (!SAFE || i0 + 1 < nout)
+                    *reinterpret_cast<v2f *>(dst) = v2f{ov[0], ov[1]};
+                else if (i0 < nout)
+                    dst[0] = ov[0];
+            } else {
+                if ((NL >= kW || i0 < NL) && (!SAFE || i0 < nout)) dst[0] = ov[0];
+            }
+            wc.roll.template run<!SAFE>(str, lid, n);
+        }
+#endif
+    };
+    request_safe(0, 0);
+    request_safe(0, 1);
+    request_safe(0, 2);
+    for (size_t c = 0; c < rounds; c++) {
+        if (c == 0 || c + 2 >= rounds)
+            round(std::true_type{}, c);
+        else
+            round(std::false_type{}, c);
+    }
+    wc.store_state(st, lanes, lane);
+}
+
+// ============================================================================================== FRAME_MAJOR
+// x[(f*lanes + lane)*16 + k], y[f*lanes + lane]; /16 cascades (64-byte frames), 16 lanes = 16 waves per workgroup.
+// LDS: [ring 64 rows x kFmPitch][16 x streams][tile 64 x 17].  Ring row 16 q + r = frame r of slot q, all 16 lanes (wave r
+// requests it: 1 KiB of contiguous global memory); a lane's piece g of the round sits in row g >> 2 at
+// lane * 64 + (g & 3) * 16.  Rows are padded by 64 bytes so that the 16 threads of a `ds_read_b128` group — pieces of
+// four different frames — fall into four different bank quarters.
+// Interval I = 4 c + q: wait for the own request of slot q, LDS barrier (everybody's rows of slot q have landed,
+// everybody has finished stage 0 of slot q - 1), request number I + 3 (the refill of slot q - 1) — except the wave that
+// owns row 15, whose last frame the threads 0 .. 3 of the NEXT slot still read: it stays one slot behind (number I + 2).
+// The round's 64 output frames are collected in the tile and stored after the next round's first barrier (one store
+// per wave, right behind that interval's request).  Younger than request I when its wait comes: the two requests
+// I + 1, I + 2 (one for the late wave) plus the store if it fell in between: 2, 3, 3, 3 (late: 1, 2, 2, 1).
+constexpr int kFmLanes = 16;
+constexpr int kFmPitch = kFmLanes * 64 + 64;  // bytes per ring row
+constexpr int kFmRows = kSlots * 16;
+constexpr int kFmTilePitch = kFmLanes + 1;    // words per tile row: conflict-free column writes
+
+template <class L>
+__global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, const float *x, float *y, const size_t lanes,
+                                                                 const size_t frames)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_fm[];
+    constexpr int S = L::stages, R = L::rate, M0 = L::M(0);
+    static_assert(R == 16 && M0 <= 4 && S >= 2, "64-byte frames whose stage-0 history fits the previous frame");
+    constexpr int NOUT = kSC / R;  // 64 output frames per round
+    const int lid = threadIdx.x % kW, w = __builtin_amdgcn_readfirstlane(threadIdx.x / kW);
+    const size_t ngroups = lanes / kFmLanes, per = (ngroups + 7) / 8;
+    const size_t group = (blockIdx.x % 8) * per + blockIdx.x / 8;  // every XCD a contiguous eighth of the lane groups
+    if (group >= ngroups) return;
+    const size_t lane0 = group * kFmLanes, lane = lane0 + w;
+    char *ringb = reinterpret_cast<char *>(smem_fm);
+    float *str = smem_fm + kFmRows * kFmPitch / 4 + w * up4(L::words);
+    float *tile = smem_fm + kFmRows * kFmPitch / 4 + kFmLanes * up4(L::words);
+    WaveCascade<L> wc;
+    wc.init(str, lid);
+
+    // byte address of raw sample n of this lane (n relative to slot 0 of the round, negative ones wrap)
+    auto raw_byte = [&](int n) -> int {
+        const int m = (n + kSC) % kSC, g = m >> 2;
+        return (g >> 2) * kFmPitch + w * 64 + (g & 3) * 16 + (m & 3) * 4;
+    };
+    {
+        constexpr int He = L::He(0), Ho = L::Ho(0);
+        if (lid < He) *reinterpret_cast<float *>(ringb + raw_byte(2 * (lid - He))) = __uint_as_float(st[size_t(lid) * lanes + lane]);
+        if (lid < Ho) *reinterpret_cast<float *>(ringb + raw_byte(2 * (lid - Ho) + 1)) = __uint_as_float(st[size_t(He + lid) * lanes + lane]);
+    }
+    wc.load_state(st, lanes, lane);
+
+    int pa[M0 + 1], pa0[M0 + 1];  // bytes
+#pragma unroll
+    for (int i = 0; i <= M0; i++) {
+        const int g = lid - M0 + i;
+        pa[i] = (g >> 2) * kFmPitch + w * 64 + (g & 3) * 16;  // g >> 2 is -1 for the four pieces before the slot
+        pa0[i] = (((g + kSC / 4) % (kSC / 4)) >> 2) * kFmPitch + w * 64 + (g & 3) * 16;
+    }
+
+    const bool late = w == kFmLanes - 1;  // owns row 15 of every slot
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ringb;
+    const uint32_t voff = uint32_t(lid) * 16;
+    const size_t fpitch = lanes * size_t(R);  // floats per frame row
+    // request number m = (round m / 4, slot m % 4): frame 16 m + w, all 16 lanes; SAFE: past the end -> frame 0
+    auto request = [&](auto safe_, size_t m) {
+        const size_t f = m * 16 + size_t(w);
+        const float *src = uniform_ptr(x + (!decltype(safe_)::value || f < frames ? f : 0) * fpitch + lane0 * R);
+#ifndef IDSP_EXP_HBF_NOLOAD
+        glds16_si<0>(src, voff, ring_lds + uint32_t((int(m % kSlots) * 16 + w) * kFmPitch));
+#endif
+    };
+    // the round's 64 output frames: wave w stores frames 4w .. 4w+3 as 64-byte pieces (16 threads)
+    auto store_tile = [&](size_t c, int nout) {
+        if (lid < 16) {
+            const int r = 4 * w + (lid >> 2), j = lid & 3;
+            if (r < nout) {
+                const float *t = tile + r * kFmTilePitch + 4 * j;
+                *reinterpret_cast<v4f *>(y + (c * NOUT + size_t(r)) * lanes + lane0 + 4 * j) = v4f{t[0], t[1], t[2], t[3]};
+            }
+        }
+    };
+
+    const size_t total = frames * size_t(R);
+    const size_t rounds = (total + kSC - 1) / kSC;
+    int prev_nout = 0;
+    auto round = [&](auto safe_, size_t c) {
+        constexpr bool SAFE = decltype(safe_)::value;
+        const bool last = SAFE && c + 1 == rounds;
+        const int n = last ? int(total - c * kSC) : kSC;
+        static_for<0, kSlots>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            if constexpr (SAFE) {
+                wait_vmcnt<0>();
+            } else {
+                if (late)
+                    wait_vmcnt<(q == 1 || q == 2 ? 2 : 1)>();
+                else
+                    wait_vmcnt<(q == 0 ? 2 : 3)>();
+            }
+            lds_barrier();
+            request(safe_, c * kSlots + q + (late ? 2 : 3));
+            if constexpr (q == 0) {
+                if (c != 0) store_tile(c - 1, prev_nout);
+            }
+            v4f pc[M0 + 1];
+#pragma unroll
+            for (int i = 0; i <= M0; i++) pc[i] = *reinterpret_cast<const v4f *>(ringb + (q == 0 ? pa0[i] : pa[i] + q * 16 * kFmPitch));
+            lds_wave_sync();
+            if constexpr (SAFE) {
+                if (last && q == (n - 1) / kSlotW) {
+                    constexpr int He = L::He(0), Ho = L::Ho(0);
+                    if (lid < He) st[size_t(lid) * lanes + lane] = __float_as_uint(*reinterpret_cast<const float *>(ringb + raw_byte(n + 2 * (lid - He))));
+                    if (lid < Ho) st[size_t(He + lid) * lanes + lane] = __float_as_uint(*reinterpret_cast<const float *>(ringb + raw_byte(n + 2 * (lid - Ho) + 1)));
+                    lds_wave_sync();
+                }
+            }
+#ifdef IDSP_EXP_HBF_NOSTAGES
+            if (pc[M0].x == 12345.678f) y[0] = pc[0].y;
+#else
+            wc.put_stage0(q, stage0_pair<L>(pc));
+#endif
+        });
+#ifndef IDSP_EXP_HBF_NOSTAGES
+        wc.rest([&](auto, float v) { tile[lid * kFmTilePitch + w] = v; });  // one output per thread: frame t of the round
+        wc.roll.template run<!SAFE>(str, lid, n);
+#endif
+        prev_nout = n / R;
+    };
+    request(std::true_type{}, 0);
+    request(std::true_type{}, 1);
+    if (!late) request(std::true_type{}, 2);
+    for (size_t c = 0; c < rounds; c++) {
+        if (c == 0 || c + 2 >= rounds)
+            round(std::true_type{}, c);
+        else
+            round(std::false_type{}, c);
+    }
+    lds_barrier();  // every wave's column of the last tile
+    store_tile(rounds - 1, prev_nout);
+    wc.store_state(st, lanes, lane);
+}
+
+// -------------------------------------------------------------------------------------------------------- host
+template <int TS, int S>
+int launch_ring(uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm, hipStream_t stream)
+{
+    using L = Lay<TS, S>;
+    if (lm) {
+        constexpr size_t bytes = (size_t(kSC) + up4(L::words)) * sizeof(float);
+        if (ensure_dyn_lds<&hbf_dec_ring_lm<L>>(bytes)) return 2;
+        note_kernel("hbf_dec_ring[LaneMajor]", typeid(L).name());
+        hipLaunchKernelGGL((hbf_dec_ring_lm<L>), dim3(unsigned(lanes)), dim3(kW), bytes, stream, st, x, y, lanes, frames);
+        return 0;
+    }
+    if constexpr (L::rate == 16 && L::M(0) <= 4) {
+        if (lanes % kFmLanes != 0) return 1;
+        constexpr size_t bytes = size_t(kFmRows) * kFmPitch + (size_t(kFmLanes) * up4(L::words) + size_t(kSC / L::rate) * kFmTilePitch) * sizeof(float);
+        static_assert(bytes <= 160 * 1024, "one workgroup per CU");
+        if (ensure_dyn_lds<&hbf_dec_ring_fm<L>>(bytes)) return 2;
+        const size_t ngroups = lanes / kFmLanes;
+        note_kernel("hbf_dec_ring[FrameMajor]", typeid(L).name());
+        hipLaunchKernelGGL((hbf_dec_ring_fm<L>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(kFmLanes * kW), bytes, stream, st, x, y, lanes,
+                           frames);
+        return 0;
+    }
+    return 1;
+}
+
+}  // namespace hbfr
+
+// Returns 0 when a ring kernel was launched, 1 when the request is not covered (the caller falls back to
+// hbf_wave.h), 2 on a HIP error (idsp_last_error() holds the text).
+int hbf_ring_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
+                 bool lane_major, hipStream_t stream);
+
+}  // namespace idsp

@@ -46,6 +46,7 @@
 #include <typeinfo>
 
 #include "common.h"
+#include "lds_dma.h"
 
 namespace idsp {
 
@@ -324,46 +325,12 @@ struct LdsRunOf<P, std::void_t<decltype(P::LDS_RUN)>> {
     static constexpr bool value = P::LDS_RUN;
 };
 
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
-{
-    // LDS destination = wave-uniform byte address (M0) + lane * 16; `nt`: streamed once, do not
-    // keep it in L2/MALL (+5 % with nontemporal loads and stores, tools/exp_lds.hip)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))  // uniform by construction; pin it to an SGPR
-                 : "memory");
-}
-// Same with the address split into a wave-uniform base (SGPR pair) and a 32-bit thread offset: no 64-bit VALU add per request
-__device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint32_t lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
-                 : "memory");
-}
-// plain (cacheable) form: rows off the 64-byte grid, where neighbouring workgroups share lines (XCDC)
-__device__ __forceinline__ void glds16_plain(const void *gsrc, uint32_t lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
-                 : "memory");
-}
 #ifndef IDSP_XCDC_LOAD_NT
 #define IDSP_XCDC_LOAD_NT 1
 #endif
 #ifndef IDSP_XCDC_STORE_NT
 #define IDSP_XCDC_STORE_NT 1
 #endif
-template <int N>
-__device__ __forceinline__ void wait_vmcnt()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
-}
-
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f)
 {
