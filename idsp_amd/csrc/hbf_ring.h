@@ -108,60 +108,6 @@ struct Lay {
     }
 };
 
-// ------------------------------------------------------------------ history roll of the streams of stages >= 1
-// After a round that consumed n raw samples, stream words [n_s, n_s + H) become the history [0, H) (src/hbf.rs:182-183
-// `copy_within`), n_s = n >> (s + 1).  All histories are one flat list; thread t moves words t, t + 64, ...
-template <class L>
-struct Roll {
-    static constexpr int total()
-    {
-        int t = 0;
-        for (int s = 1; s < L::stages; s++) t += L::He(s) + L::Ho(s) * (L::dual(s) ? 2 : 1);
-        return t;
-    }
-    static constexpr int per_thread = (total() + kW - 1) / kW;
-    int dst[per_thread > 0 ? per_thread : 1], sh[per_thread > 0 ? per_thread : 1], full[per_thread > 0 ? per_thread : 1];
-
-    __device__ __forceinline__ void plan(int lid)
-    {
-#pragma unroll
-        for (int k = 0; k < per_thread; k++) {
-            const int j = lid + k * kW;
-            int base = 0, d = 0, h = 1;
-            static_for<1, L::stages>([&](auto s) {
-                constexpr int s_ = decltype(s)::value;
-                if (j >= base && j < base + L::He(s_)) d = L::offE(s_) + (j - base), h = s_ + 1;
-                base += L::He(s_);
-                if (j >= base && j < base + L::Ho(s_)) d = L::offO(s_) + (j - base), h = s_ + 1;
-                base += L::Ho(s_);
-                if constexpr (L::dual(s_)) {
-                    if (j >= base && j < base + L::Ho(s_)) d = L::offOB(s_) + 1 + (j - base), h = s_ + 1;
-                    base += L::Ho(s_);
-                }
-            });
-            dst[k] = d;
-            sh[k] = h;
-            full[k] = d + (kSC >> h);
-        }
-    }
-    // FULL: a whole round (n == kSC), sources known since plan()
-    template <bool FULL>
-    __device__ __forceinline__ void run(float *str, int lid, int n) const
-    {
-        if constexpr (per_thread > 0) {
-            float t[per_thread];
-#pragma unroll
-            for (int k = 0; k < per_thread; k++)
-                if ((k + 1) * kW <= total() || lid + k * kW < total()) t[k] = str[FULL ? full[k] : dst[k] + (n >> sh[k])];
-            lds_wave_sync();
-#pragma unroll
-            for (int k = 0; k < per_thread; k++)
-                if ((k + 1) * kW <= total() || lid + k * kW < total()) str[dst[k]] = t[k];
-            lds_wave_sync();
-        }
-    }
-};
-
 // ------------------------------------------------------------------------------------------------ stage bodies
 // raw sample n (relative to the thread's own piece, n in [-4M, 3]) out of the pieces t - M .. t
 template <int M, int n>
@@ -277,19 +223,68 @@ __device__ __forceinline__ float stage_single(const float *str, int lid)
 }
 
 // ---------------------------------------------------------------------------------------- one wave's cascade
-// Everything a wave does between taking its pieces out of the ring and handing the round's outputs to `Out`.
+// Everything a wave does between taking its pieces out of the ring and handing a round's outputs over.
+//
+// Stage schedule ("skew").  Stage 0 runs slot by slot; if stages 1 .. S-1 all followed the fourth slot, the wave would
+// consume its four slots in a burst and then compute for two thirds of the round — the request issued after the first
+// slot would be needed three short steps later (measured: it has not landed, 0.92 ms where the arithmetic alone takes
+// 0.57 and the requests alone 0.70).  So the later stages are spread over the slot steps: stage 1 follows slot 3 of its
+// own round, stage s >= 2 follows slot s - 2 of the NEXT round (working on the previous round's streams, which nothing
+// has touched since).  Every request then has about two thirds of a round to land.  The streams need no extra space;
+// the last stage's outputs of round c leave during round c + 1, and a short epilogue finishes the last round.
 template <class L>
 struct WaveCascade {
     static constexpr int S = L::stages, M0 = L::M(0);
+    static constexpr int roll_words(int s) { return L::He(s) + L::Ho(s) * (L::dual(s) ? 2 : 1); }
+    static constexpr int roll_pt()
+    {
+        int m = 1;
+        for (int s = 1; s < S; s++) m = (roll_words(s) + kW - 1) / kW > m ? (roll_words(s) + kW - 1) / kW : m;
+        return m;
+    }
+    static constexpr int PT = roll_pt();
+    // slot step after which stage s runs (s >= 1), and whether it then works on the previous round
+    static constexpr int step_of(int s) { return s == 1 ? kSlots - 1 : s - 2; }
+    static constexpr bool lagging(int s) { return s >= 2; }
+
     float *str;  // this wave's streams
     int lid;
-    Roll<L> roll;
+    int rdst[S > 1 ? S : 2][PT];  // history roll: destination word of this thread's k-th word of stage s
 
     __device__ __forceinline__ void init(float *streams, int lane_id)
     {
         str = streams;
         lid = lane_id;
-        roll.plan(lane_id);
+        static_for<1, S>([&](auto s) {
+            constexpr int s_ = decltype(s)::value;
+#pragma unroll
+            for (int k = 0; k < PT; k++) {
+                const int j = lid + k * kW;
+                int d = L::offE(s_) + j;
+                if (j >= L::He(s_)) d = L::offO(s_) + (j - L::He(s_));
+                if constexpr (L::dual(s_)) {
+                    if (j >= L::He(s_) + L::Ho(s_)) d = L::offOB(s_) + 1 + (j - L::He(s_) - L::Ho(s_));
+                }
+                rdst[s_][k] = d;
+            }
+        });
+    }
+
+    // After stage s has consumed n_s = n >> (s + 1) input pairs, stream words [n_s, n_s + H) become the history [0, H)
+    // (src/hbf.rs:182-183 `copy_within`).  n = raw samples of the round; FULL: n == kSC.
+    template <int s, bool FULL>
+    __device__ __forceinline__ void roll(int n) const
+    {
+        constexpr int total = roll_words(s), pt = (total + kW - 1) / kW;
+        const int ns = FULL ? L::N(s) : n >> (s + 1);
+        float t[pt];
+#pragma unroll
+        for (int k = 0; k < pt; k++)
+            if ((k + 1) * kW <= total || lid + k * kW < total) t[k] = str[rdst[s][k] + ns];
+        lds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < pt; k++)
+            if ((k + 1) * kW <= total || lid + k * kW < total) str[rdst[s][k]] = t[k];
     }
 
     // history of stages >= 1 <- state words (per stage: even[M-1] then odd[2M-1], oldest first; SoA across lanes)
@@ -321,97 +316,102 @@ struct WaveCascade {
     __device__ __forceinline__ void put_stage0(int q, v2f yv) const
     {
         static_assert(S >= 2, "a one-stage cascade stores stage 0 directly");
-        constexpr int j0 = 0;
-        const int j = q * (kSlotW / 4) + lid + j0;
+        const int j = q * (kSlotW / 4) + lid;
         str[L::offE(1) + L::He(1) + j] = yv.x;
         str[L::offO(1) + L::Ho(1) + j] = yv.y;
         if constexpr (L::dual(1)) str[L::offOB(1) + L::Ho(1) + 1 + j] = yv.y;
     }
 
-    // stages 1 .. S-1 of a round; out(p, v): the thread's p-th output of the last stage = round output P t + p
-    template <class Out>
-    __device__ __forceinline__ void rest(Out &&out) const
+    // stage s (1 .. S-1) of one round; the last stage calls out(p, v) with the thread's p-th output = round output P t + p
+    template <int s, class Out>
+    __device__ __forceinline__ void stage(Out &&out) const
     {
-        static_for<1, S>([&](auto s) {
-            constexpr int s_ = decltype(s)::value;
-            constexpr int P = L::P(s_);
-            lds_wave_sync();  // the previous stage's stream writes (LDS operations of one wave execute in order)
-            if constexpr (P >= 2) {
-                stage_pairs<L, s_>(str, lid, [&](auto q_, v2f yv) {
-                    constexpr int q = decltype(q_)::value;
-                    if constexpr (s_ + 1 == S) {
-                        out(std::integral_constant<int, 2 * q>{}, yv.x);  // thread-local output index: round output P t + 2q
-                        out(std::integral_constant<int, 2 * q + 1>{}, yv.y);
+        constexpr int P = L::P(s);
+        lds_wave_sync();  // the producer's stream writes are issued (LDS operations of one wave execute in order)
+        if constexpr (P >= 2) {
+            stage_pairs<L, s>(str, lid, [&](auto q_, v2f yv) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (s + 1 == S) {
+                    out(std::integral_constant<int, 2 * q>{}, yv.x);
+                    out(std::integral_constant<int, 2 * q + 1>{}, yv.y);
+                } else {
+                    const int j = (P / 2) * lid + q;
+                    str[L::offE(s + 1) + L::He(s + 1) + j] = yv.x;
+                    str[L::offO(s + 1) + L::Ho(s + 1) + j] = yv.y;
+                    if constexpr (L::dual(s + 1)) str[L::offOB(s + 1) + L::Ho(s + 1) + 1 + j] = yv.y;
+                }
+            });
+        } else {
+            if (L::N(s) >= kW || lid < L::N(s)) {
+                const float yv = stage_single<L, s>(str, lid);
+                if constexpr (s + 1 == S) {
+                    out(std::integral_constant<int, 0>{}, yv);
+                } else {
+                    const int j = lid >> 1;
+                    if (lid & 1) {
+                        str[L::offO(s + 1) + L::Ho(s + 1) + j] = yv;
+                        if constexpr (L::dual(s + 1)) str[L::offOB(s + 1) + L::Ho(s + 1) + 1 + j] = yv;
                     } else {
-                        const int j = (P / 2) * lid + q;
-                        str[L::offE(s_ + 1) + L::He(s_ + 1) + j] = yv.x;
-                        str[L::offO(s_ + 1) + L::Ho(s_ + 1) + j] = yv.y;
-                        if constexpr (L::dual(s_ + 1)) str[L::offOB(s_ + 1) + L::Ho(s_ + 1) + 1 + j] = yv.y;
-                    }
-                });
-            } else {
-                if (L::N(s_) >= kW || lid < L::N(s_)) {
-                    const float yv = stage_single<L, s_>(str, lid);
-                    if constexpr (s_ + 1 == S) {
-                        out(std::integral_constant<int, 0>{}, yv);
-                    } else {
-                        const int j = lid >> 1;
-                        if (lid & 1) {
-                            str[L::offO(s_ + 1) + L::Ho(s_ + 1) + j] = yv;
-                            if constexpr (L::dual(s_ + 1)) str[L::offOB(s_ + 1) + L::Ho(s_ + 1) + 1 + j] = yv;
-                        } else {
-                            str[L::offE(s_ + 1) + L::He(s_ + 1) + j] = yv;
-                        }
+                        str[L::offE(s + 1) + L::He(s + 1) + j] = yv;
                     }
                 }
             }
-        });
-        lds_wave_sync();
+        }
     }
 };
 
 // Request / wait bookkeeping.  Every wave issues exactly ONE request per slot and the output stores of a round at a
 // fixed place, so "my request for slot q has landed" is `s_waitcnt vmcnt(N)` with N = the vector-memory operations the
 // wave has issued since (requests and stores retire in issue order).  Two forms of the round body:
-//   FAST  whole rounds in the middle of the stream: static N, unclamped requests off an SGPR base, unpredicated stores
-//   SAFE  the first round (no store in the queue yet), and the last two (their requests reach past the data, the last
-//         one may store nothing): vmcnt(0), requests clamped to a valid address, predicated stores, runtime roll,
-//         state write-back.
+//   FAST  whole rounds in the middle of the stream: static N, unclamped requests off an SGPR base
+//   SAFE  the first two rounds (the store of "the round before" is missing from the queue) and the last two (their
+//         requests reach past the data, the last one is ragged): vmcnt(0), requests clamped to a valid address,
+//         runtime roll, state write-back.
+// Stores: S = 1 after every slot step; S = 2 after step 3 (stage 1 is the last stage); S >= 3 after step S - 3 of the
+// following round (the last stage lags, see WaveCascade).
+template <int S>
+constexpr int store_step() { return S == 2 ? kSlots - 1 : S - 3; }
 
 // =============================================================================================== LANE_MAJOR
 // x[(lane*frames + f)*R + k], y[lane*frames + f].  One wave per lane, no barriers.
-// LDS: [ring 4 x 1 KiB][streams].  Per round c and slot q: wait for slot q, read the pieces (slot q and the tail of
-// slot q-1), then request the refill of slot (q-1) & 3 — its last reader has just finished: (c, 3) at q = 0,
-// (c+1, q-1) otherwise.  Queue per round (S >= 2): R(c,3) R(c+1,0) R(c+1,1) R(c+1,2) ST(c); younger than the request
-// of slot q when its wait comes: 3, 3, 3, 2.  S = 1 stores after every slot: R ST R ST ... -> 5.
-template <class L>
+// LDS: [ring RING x 1 KiB][streams].  The data of slot step g = 4 c + q (round c, step q) lives in ring slot g % RING.
+// Step g: wait for its request, read the pieces (its slot and the tail of the slot before), request the data of step
+// g - 1 + RING into the slot before — its last reader has just finished — then stage 0 and the stages scheduled
+// behind this step.  A request is issued RING - 1 steps before it is needed; younger than it when its wait comes: the
+// RING - 2 requests in between and the stores of those RING - 1 steps.
+// RING = 4: 18 waves per CU with three requests each in flight; RING = 8: 12 waves with seven (the wave count is LDS-bound).
+template <class L, int RING>
 __global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float *x, float *y, const size_t lanes,
                                                        const size_t frames)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_lm[];
+    using WC = WaveCascade<L>;
+    static_assert(RING == 4 || RING == 8, "ring of one or two rounds");
     constexpr int S = L::stages, R = L::rate, M0 = L::M(0);
-    constexpr int NOUT = kSC / R;  // outputs per round
+    constexpr int NOUT = kSC / R;          // outputs per round
+    constexpr int RW = RING * kSlotW;      // ring words
+    constexpr int LEAD = RING / kSlots;    // rounds of settled queue a FAST round needs on either side
     const int lid = threadIdx.x;
     const size_t lane = blockIdx.x;
-    float *ring = smem_lm, *str = smem_lm + kSC;
-    WaveCascade<L> wc;
+    float *ring = smem_lm, *str = smem_lm + RW;
+    WC wc;
     wc.init(str, lid);
 
-    // stage-0 history -> the ring's tail (raw positions -1, -2, ... wrap to the end of slot 3)
+    // stage-0 history -> the ring's tail (raw positions -1, -2, ... wrap to the end of the last slot)
     {
         constexpr int He = L::He(0), Ho = L::Ho(0);
-        if (lid < He) ring[kSC + 2 * (lid - He)] = __uint_as_float(st[size_t(lid) * lanes + lane]);
-        if (lid < Ho) ring[kSC + 2 * (lid - Ho) + 1] = __uint_as_float(st[size_t(He + lid) * lanes + lane]);
+        if (lid < He) ring[RW + 2 * (lid - He)] = __uint_as_float(st[size_t(lid) * lanes + lane]);
+        if (lid < Ho) ring[RW + 2 * (lid - Ho) + 1] = __uint_as_float(st[size_t(He + lid) * lanes + lane]);
     }
     wc.load_state(st, lanes, lane);
 
-    // piece addresses (words): pa[i] = piece t - M0 + i relative to slot 0; in slot 0 the negative ones wrap
+    // piece addresses (words): pa[i] = piece t - M0 + i relative to its slot; in ring slot 0 the negative ones wrap
     int pa[M0 + 1], pa0[M0 + 1];
 #pragma unroll
     for (int i = 0; i <= M0; i++) {
         const int g = lid - M0 + i;
         pa[i] = 4 * g;
-        pa0[i] = 4 * (g < 0 ? g + kSC / 4 : g);
+        pa0[i] = 4 * (g < 0 ? g + RW / 4 : g);
     }
 
     const size_t total = frames * size_t(R);  // raw samples of the lane
@@ -420,50 +420,104 @@ __global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float 
     float *yl = y + lane * frames;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)ring;  // LDS byte address of the ring
     const uint32_t voff = uint32_t(lid) * 16;
-    // SAFE request of slot q of round c: piece 256 c + 64 q + t, clamped to piece 0 of the row past the end
-    auto request_safe = [&](size_t c, int q) {
-        const size_t g = c * (kSC / 4) + size_t(q) * (kSlotW / 4) + size_t(lid);
-        const float *src = xl + (g < npieces ? g * 4 : 0);
+    // SAFE request of slot step g: piece 64 g + t, clamped to piece 0 of the row past the end
+    auto request_safe = [&](size_t g) {
+        const size_t pc = g * (kSlotW / 4) + size_t(lid);
+        const float *src = xl + (pc < npieces ? pc * 4 : 0);
 #ifndef IDSP_EXP_HBF_NOLOAD
-        glds16(src, ring_lds + uint32_t(q) * (kSlotW * 4));
+        glds16(src, ring_lds + uint32_t(g % RING) * (kSlotW * 4));
 #endif
     };
     const size_t rounds = (total + kSC - 1) / kSC;
 
-    auto round = [&](auto safe_, size_t c) {
+    // the last stage s of round `c` (nout outputs; PRED: not a whole round)
+    auto last_stage = [&](auto s_, auto pred_, size_t c, int nout) {
+        constexpr int s = decltype(s_)::value, P = L::P(s), NL = L::N(s);
+        constexpr bool PRED = decltype(pred_)::value;
+        float ov[P];
+        wc.template stage<s>([&](auto p_, float v) { ov[decltype(p_)::value] = v; });
+        const int i0 = P * lid;
+        float *dst = yl + c * NOUT + i0;
+        if constexpr (P == 4) {
+            if (!PRED || i0 + 3 < nout)
+                *reinterpret_cast<v4f *>(dst) = v4f{ov[0], ov[1], ov[2], ov[3]};
+            else
+                for (int p = 0; p < 4; p++)
+                    if (i0 + p < nout) dst[p] = ov[p];
+        } else if constexpr (P == 2) {
+            if (!PRED || i0 + 1 < nout)
+                *reinterpret_cast<v2f *>(dst) = v2f{ov[0], ov[1]};
+            else if (i0 < nout)
+                dst[0] = ov[0];
+        } else {
+            if ((NL >= kW || i0 < NL) && (!PRED || i0 < nout)) dst[0] = ov[0];
+        }
+    };
+    // the stages scheduled behind slot step q of round c (n raw samples; SAFE: n may be short)
+    auto stages_after = [&](auto q_, auto safe_, size_t c, int n) {
+        constexpr int q = decltype(q_)::value;
         constexpr bool SAFE = decltype(safe_)::value;
+        static_for<1, S>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            if constexpr (WC::step_of(s) == q) {
+                if constexpr (!WC::lagging(s)) {
+                    if constexpr (s + 1 == S)
+                        last_stage(s_, safe_, c, n / R);
+                    else
+                        wc.template stage<s>([](auto, float) {});
+                    wc.template roll<s, !SAFE>(n);
+                } else {
+                    if (c != 0) {  // the previous round: always a whole one
+                        if constexpr (s + 1 == S)
+                            last_stage(s_, std::false_type{}, c - 1, NOUT);
+                        else
+                            wc.template stage<s>([](auto, float) {});
+                        wc.template roll<s, true>(kSC);
+                    }
+                }
+            }
+        });
+    };
+
+    // PAR: which round-sized part of the ring this round's slots are ((c * 4) % RING) / 4
+    auto round = [&](auto safe_, auto par_, size_t c) {
+        constexpr bool SAFE = decltype(safe_)::value;
+        constexpr int PAR = decltype(par_)::value;
         const bool last = SAFE && c + 1 == rounds;
         const int n = last ? int(total - c * kSC) : kSC;  // raw samples of this round
         const float *xc = uniform_ptr(xl + c * kSC);       // the round's 4 KiB (FAST requests)
         static_for<0, kSlots>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
-            if constexpr (SAFE)
+            constexpr int SLOT = PAR * kSlots + q;  // ring slot of this step
+            if constexpr (SAFE) {
                 wait_vmcnt<0>();
-            else
-                wait_vmcnt<(S >= 2 ? (q == 3 ? 2 : 3) : 5)>();
+            } else {
+                // stores in the RING - 1 steps before this one: all of them (S = 1); else one per round, and every step of a
+                // round but this one is among those steps RING / 4 times, this one RING / 4 - 1 times
+                constexpr int stores = S == 1 ? RING - 1 : LEAD - (q == store_step<S>() ? 1 : 0);
+                wait_vmcnt<RING - 2 + stores>();
+            }
             v4f pc[M0 + 1];
 #pragma unroll
-            for (int i = 0; i <= M0; i++) pc[i] = *reinterpret_cast<const v4f *>(ring + (q == 0 ? pa0[i] : pa[i] + q * kSlotW));
+            for (int i = 0; i <= M0; i++) pc[i] = *reinterpret_cast<const v4f *>(ring + (SLOT == 0 ? pa0[i] : pa[i] + SLOT * kSlotW));
             lds_wave_sync();
             if constexpr (SAFE) {
-                // stage-0 state of the call = the last raw samples before `n`: take them while the previous slot is intact
+                // stage-0 state of the call = the last raw samples before `n`: take them while the slot before is intact
                 if (last && q == (n - 1) / kSlotW) {
                     constexpr int He = L::He(0), Ho = L::Ho(0);
-                    if (lid < He) st[size_t(lid) * lanes + lane] = __float_as_uint(ring[(n + 2 * (lid - He) + kSC) % kSC]);
-                    if (lid < Ho) st[size_t(He + lid) * lanes + lane] = __float_as_uint(ring[(n + 2 * (lid - Ho) + 1 + kSC) % kSC]);
+                    const int pos = PAR * kSC + n;
+                    if (lid < He) st[size_t(lid) * lanes + lane] = __float_as_uint(ring[(pos + 2 * (lid - He) + RW) % RW]);
+                    if (lid < Ho) st[size_t(He + lid) * lanes + lane] = __float_as_uint(ring[(pos + 2 * (lid - Ho) + 1 + RW) % RW]);
                     lds_wave_sync();
                 }
-                if constexpr (q == 0)
-                    request_safe(c, 3);
-                else
-                    request_safe(c + 1, q - 1);
+                request_safe(c * kSlots + q + RING - 1);
             } else {
 #ifndef IDSP_EXP_HBF_NOLOAD
-                // the instruction offset moves the global AND the LDS address: slot s of the round at xc + s KiB -> ring + s KiB
-                if constexpr (q == 0)
-                    glds16_si<3 * kSlotW * 4>(xc, voff, ring_lds);
-                else
-                    glds16_si<(q - 1) * kSlotW * 4>(xc + kSC, voff, ring_lds);
+                // data of step g = 4 c + q - 1 + RING: slot k = g % 4 of round c + g / 4 ... into ring slot g % RING.  The
+                // instruction offset (k KiB) moves the global AND the LDS address, so M0 carries only the round part.
+                constexpr int G = q - 1 + RING, K = G % kSlots, DR = G / kSlots;          // relative to round c
+                constexpr int TPAR = (PAR + DR) % (RING / kSlots);                      // ring part of the target round
+                glds16_si<K * kSlotW * 4>(xc + DR * kSC, voff, ring_lds + TPAR * kSC * 4);
 #endif
             }
 #ifdef IDSP_EXP_HBF_NOSTAGES
@@ -480,42 +534,43 @@ __global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float 
             } else {
                 wc.put_stage0(q, y0);
             }
+            stages_after(q_, safe_, c, n);
 #endif
         });
-#ifndef IDSP_EXP_HBF_NOSTAGES
-        if constexpr (S >= 2) {
-            constexpr int P = L::P(S - 1), NL = L::N(S - 1);
-            float ov[P];
-            wc.rest([&](auto p_, float v) { ov[decltype(p_)::value] = v; });
-            const int nout = n / R, i0 = P * lid;
-            float *dst = yl + c * NOUT + i0;
-            if constexpr (P == 4) {
-                if (!SAFE || i0 + 3 < nout)
-                    *reinterpret_cast<v4f *>(dst) = v4f{ov[0], ov[1], ov[2], ov[3]};
-                else
-                    for (int p = 0; p < 4; p++)
-                        if (i0 + p < nout) dst[p] = ov[p];
-            } else if constexpr (P == 2) {
-                if (!SAFE || i0 + 1 < nout)
-                    *reinterpret_cast<v2f *>(dst) = v2f{ov[0], ov[1]};
-                else if (i0 < nout)
-                    dst[0] = ov[0];
-            } else {
-                if ((NL >= kW || i0 < NL) && (!SAFE || i0 < nout)) dst[0] = ov[0];
-            }
-            wc.roll.template run<!SAFE>(str, lid, n);
-        }
-#endif
     };
-    request_safe(0, 0);
-    request_safe(0, 1);
-    request_safe(0, 2);
+    for (int g = 0; g < RING - 1; g++) request_safe(size_t(g));
     for (size_t c = 0; c < rounds; c++) {
-        if (c == 0 || c + 2 >= rounds)
-            round(std::true_type{}, c);
-        else
-            round(std::false_type{}, c);
+        // SAFE: the queue behind this round is not the regular one yet (first rounds: the store of "the round before" is
+        // missing), or its requests reach the end of the data
+        const bool safe = c < size_t(LEAD + 1) || c + LEAD + 1 >= rounds;
+        if (RING == 8 && (c & 1)) {
+            if (safe)
+                round(std::true_type{}, std::integral_constant<int, RING == 8 ? 1 : 0>{}, c);
+            else
+                round(std::false_type{}, std::integral_constant<int, RING == 8 ? 1 : 0>{}, c);
+        } else {
+            if (safe)
+                round(std::true_type{}, std::integral_constant<int, 0>{}, c);
+            else
+                round(std::false_type{}, std::integral_constant<int, 0>{}, c);
+        }
     }
+#ifndef IDSP_EXP_HBF_NOSTAGES
+    // epilogue: the lagging stages of the last round
+    {
+        const int n = int(total - (rounds - 1) * kSC);
+        static_for<2, S>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            if constexpr (s + 1 == S)
+                last_stage(s_, std::true_type{}, rounds - 1, n / R);
+            else
+                wc.template stage<s>([](auto, float) {});
+            wc.template roll<s, false>(n);
+        });
+    }
+#endif
+    lds_wave_sync();
+    wait_vmcnt<0>();  // the requests past the end of the data are still landing: they must not outlive the wave's LDS
     wc.store_state(st, lanes, lane);
 }
 
@@ -525,12 +580,12 @@ __global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float 
 // requests it: 1 KiB of contiguous global memory); a lane's piece g of the round sits in row g >> 2 at
 // lane * 64 + (g & 3) * 16.  Rows are padded by 64 bytes so that the 16 threads of a `ds_read_b128` group — pieces of
 // four different frames — fall into four different bank quarters.
-// Interval I = 4 c + q: wait for the own request of slot q, LDS barrier (everybody's rows of slot q have landed,
-// everybody has finished stage 0 of slot q - 1), request number I + 3 (the refill of slot q - 1) — except the wave that
-// owns row 15, whose last frame the threads 0 .. 3 of the NEXT slot still read: it stays one slot behind (number I + 2).
-// The round's 64 output frames are collected in the tile and stored after the next round's first barrier (one store
-// per wave, right behind that interval's request).  Younger than request I when its wait comes: the two requests
-// I + 1, I + 2 (one for the late wave) plus the store if it fell in between: 2, 3, 3, 3 (late: 1, 2, 2, 1).
+// Step I = 4 c + q: wait for the own request of slot q, LDS barrier (everybody's rows of slot q have landed, everybody
+// has finished stage 0 of slot q - 1), request number I + 3 (the refill of slot q - 1) — except the wave that owns row
+// 15, whose last frame the threads 0 .. 3 of the NEXT slot still read: it stays one slot behind (number I + 2).  The
+// last stage (step 1 of the following round) puts the round's 64 output frames into the tile; they are stored behind
+// the barrier of step 2, one 64-byte piece per thread of the first 16 of every wave.  Younger than request I when its
+// wait comes: the requests I + 1, I + 2 (late wave: I + 1) and the store if step 2 fell in between.
 constexpr int kFmLanes = 16;
 constexpr int kFmPitch = kFmLanes * 64 + 64;  // bytes per ring row
 constexpr int kFmRows = kSlots * 16;
@@ -541,9 +596,11 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
                                                                  const size_t frames)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_fm[];
+    using WC = WaveCascade<L>;
     constexpr int S = L::stages, R = L::rate, M0 = L::M(0);
-    static_assert(R == 16 && M0 <= 4 && S >= 2, "64-byte frames whose stage-0 history fits the previous frame");
+    static_assert(R == 16 && M0 <= 4 && S == 4, "64-byte frames whose stage-0 history fits the previous frame");
     constexpr int NOUT = kSC / R;  // 64 output frames per round
+    constexpr int kStoreStep = WC::step_of(S - 1) + 1;  // the step whose barrier follows the last stage
     const int lid = threadIdx.x % kW, w = __builtin_amdgcn_readfirstlane(threadIdx.x / kW);
     const size_t ngroups = lanes / kFmLanes, per = (ngroups + 7) / 8;
     const size_t group = (blockIdx.x % 8) * per + blockIdx.x / 8;  // every XCD a contiguous eighth of the lane groups
@@ -552,7 +609,7 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
     char *ringb = reinterpret_cast<char *>(smem_fm);
     float *str = smem_fm + kFmRows * kFmPitch / 4 + w * up4(L::words);
     float *tile = smem_fm + kFmRows * kFmPitch / 4 + kFmLanes * up4(L::words);
-    WaveCascade<L> wc;
+    WC wc;
     wc.init(str, lid);
 
     // byte address of raw sample n of this lane (n relative to slot 0 of the round, negative ones wrap)
@@ -587,7 +644,7 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
         glds16_si<0>(src, voff, ring_lds + uint32_t((int(m % kSlots) * 16 + w) * kFmPitch));
 #endif
     };
-    // the round's 64 output frames: wave w stores frames 4w .. 4w+3 as 64-byte pieces (16 threads)
+    // a round's 64 output frames: wave w stores frames 4w .. 4w+3 as 64-byte pieces (16 threads)
     auto store_tile = [&](size_t c, int nout) {
         if (lid < 16) {
             const int r = 4 * w + (lid >> 2), j = lid & 3;
@@ -597,10 +654,28 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
             }
         }
     };
+    auto to_tile = [&](auto, float v) { tile[lid * kFmTilePitch + w] = v; };  // one output per thread: frame t of the round
+    auto stages_after = [&](auto q_, auto safe_, size_t c, int n) {
+        constexpr int q = decltype(q_)::value;
+        constexpr bool SAFE = decltype(safe_)::value;
+        static_for<1, S>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            if constexpr (WC::step_of(s) == q) {
+                if constexpr (!WC::lagging(s)) {
+                    wc.template stage<s>(to_tile);
+                    wc.template roll<s, !SAFE>(n);
+                } else {
+                    if (c != 0) {
+                        wc.template stage<s>(to_tile);
+                        wc.template roll<s, true>(kSC);
+                    }
+                }
+            }
+        });
+    };
 
     const size_t total = frames * size_t(R);
     const size_t rounds = (total + kSC - 1) / kSC;
-    int prev_nout = 0;
     auto round = [&](auto safe_, size_t c) {
         constexpr bool SAFE = decltype(safe_)::value;
         const bool last = SAFE && c + 1 == rounds;
@@ -611,14 +686,14 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
                 wait_vmcnt<0>();
             } else {
                 if (late)
-                    wait_vmcnt<(q == 1 || q == 2 ? 2 : 1)>();
+                    wait_vmcnt<(q == (kStoreStep + 1) % kSlots || q == (kStoreStep + 2) % kSlots ? 2 : 1)>();
                 else
-                    wait_vmcnt<(q == 0 ? 2 : 3)>();
+                    wait_vmcnt<(q == kStoreStep ? 2 : 3)>();
             }
             lds_barrier();
             request(safe_, c * kSlots + q + (late ? 2 : 3));
-            if constexpr (q == 0) {
-                if (c != 0) store_tile(c - 1, prev_nout);
+            if constexpr (q == kStoreStep) {
+                if (c != 0) store_tile(c - 1, NOUT);
             }
             v4f pc[M0 + 1];
 #pragma unroll
@@ -636,25 +711,30 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
             if (pc[M0].x == 12345.678f) y[0] = pc[0].y;
 #else
             wc.put_stage0(q, stage0_pair<L>(pc));
+            stages_after(q_, safe_, c, n);
 #endif
         });
-#ifndef IDSP_EXP_HBF_NOSTAGES
-        wc.rest([&](auto, float v) { tile[lid * kFmTilePitch + w] = v; });  // one output per thread: frame t of the round
-        wc.roll.template run<!SAFE>(str, lid, n);
-#endif
-        prev_nout = n / R;
     };
     request(std::true_type{}, 0);
     request(std::true_type{}, 1);
     if (!late) request(std::true_type{}, 2);
     for (size_t c = 0; c < rounds; c++) {
-        if (c == 0 || c + 2 >= rounds)
+        if (c < 2 || c + 2 >= rounds)
             round(std::true_type{}, c);
         else
             round(std::false_type{}, c);
     }
-    lds_barrier();  // every wave's column of the last tile
-    store_tile(rounds - 1, prev_nout);
+    const int n_last = int(total - (rounds - 1) * kSC);
+#ifndef IDSP_EXP_HBF_NOSTAGES
+    static_for<2, S>([&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        wc.template stage<s>(to_tile);
+        wc.template roll<s, false>(n_last);
+    });
+#endif
+    wait_vmcnt<0>();  // the requests past the end of the data are still landing: they must not outlive the workgroup's LDS
+    lds_barrier();    // every wave's column of the last tile
+    store_tile(rounds - 1, n_last / R);
     wc.store_state(st, lanes, lane);
 }
 
@@ -664,10 +744,16 @@ int launch_ring(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
 {
     using L = Lay<TS, S>;
     if (lm) {
-        constexpr size_t bytes = (size_t(kSC) + up4(L::words)) * sizeof(float);
-        if (ensure_dyn_lds<&hbf_dec_ring_lm<L>>(bytes)) return 2;
+        // ring of 4 slots (18 waves per CU, three requests each in flight); 8 slots (12 waves, seven each) measured slower at C3:
+        // 0.955 against 0.892 ms, the arithmetic alone (no requests) 0.643 against 0.567 — the occupancy matters more than the depth
+#ifndef IDSP_HBF_RING
+#define IDSP_HBF_RING 4
+#endif
+        constexpr int RING = IDSP_HBF_RING;
+        constexpr size_t bytes = (size_t(RING) * kSlotW + up4(L::words)) * sizeof(float);
+        if (ensure_dyn_lds<&hbf_dec_ring_lm<L, RING>>(bytes)) return 2;
         note_kernel("hbf_dec_ring[LaneMajor]", typeid(L).name());
-        hipLaunchKernelGGL((hbf_dec_ring_lm<L>), dim3(unsigned(lanes)), dim3(kW), bytes, stream, st, x, y, lanes, frames);
+        hipLaunchKernelGGL((hbf_dec_ring_lm<L, RING>), dim3(unsigned(lanes)), dim3(kW), bytes, stream, st, x, y, lanes, frames);
         return 0;
     }
     if constexpr (L::rate == 16 && L::M(0) <= 4) {

@@ -1,6 +1,9 @@
 // hbf_wave.h — statically specialised half-band cascade kernels for the
 // reference's built-in cascades (HBF_DEC_CASCADE / HBF_INT_CASCADE over HBF_TAPS
-// and HBF_TAPS_98, src/hbf.rs:258-349,385-421,476-512).
+// and HBF_TAPS_98, src/hbf.rs:258-349,385-421,476-512): the interpolators, and the
+// FRAME_MAJOR decimators on shapes hbf_ring.h does not cover (cascades other than
+// /16, lane counts that are not whole 16-lane groups).  LANE_MAJOR decimators and
+// /16 FRAME_MAJOR ones run on the LDS-DMA ring kernels of hbf_ring.h since round 4.
 //
 // Mapping: ONE WAVE per lane, no workgroup barriers.  A wave walks its lane in
 // chunks of kCH = 1024 high-rate samples; every stage of the cascade runs inside
@@ -40,7 +43,7 @@ constexpr int kW = 64;      // threads per workgroup = one wave
 #ifndef IDSP_HBF_CH
 #define IDSP_HBF_CH 1024
 #endif
-constexpr int kCH = IDSP_HBF_CH;   // high-rate samples per chunk (C3 LaneMajor: 512 -> 1.06 ms, 1024 -> 0.906, 2048 -> 0.904 at half the occupancy: tools/exp_hbf.sh)
+constexpr int kCH = IDSP_HBF_CH;   // high-rate samples per chunk
 constexpr int kSlack = 8;   // words readable past the last valid sample of a stream
 
 constexpr int pad4(int h) { return (4 - h % 4) % 4; }
@@ -57,62 +60,21 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// Stream element: one f32 sample of ONE lane (float), or the samples of TWO lanes side by side (v2f, "pair mode").  In pair
-// mode a wave runs two lanes whose streams are interleaved word by word in LDS, so that every register pair a window read
-// delivers is (lane A, lane B) of one sample position and the whole filter arithmetic is v_pk_add_f32 / v_pk_mul_f32 on
-// aligned pairs with the tap as a scalar operand — the same IEEE operations in the same order per lane (nothing is
-// fused or re-associated), at half the VALU instructions per sample.  (The SLP vectoriser's packing of ONE lane's
-// neighbouring outputs needs register shuffles and was measured slower; this packing needs none.)
-template <class E>
-struct ElemTraits {
-    static constexpr int lanes = 1;
-    static __device__ __forceinline__ E splat(float v) { return v; }
-    static __device__ __forceinline__ float a(E e) { return e; }
-    static __device__ __forceinline__ float b(E e) { return e; }
-    static __device__ __forceinline__ E make(float x, float) { return x; }
-};
-template <>
-struct ElemTraits<v2f> {
-    static constexpr int lanes = 2;
-    static __device__ __forceinline__ v2f splat(float v) { return v2f{v, v}; }
-    static __device__ __forceinline__ float a(v2f e) { return e.x; }
-    static __device__ __forceinline__ float b(v2f e) { return e.y; }
-    static __device__ __forceinline__ v2f make(float x, float y) { return v2f{x, y}; }
-};
-// K consecutive elements (K = 1, 2, 4) from / to an LDS address aligned to K elements
-template <class E, int K>
-__device__ __forceinline__ void elem_load(const E *src, E *w)
+// K consecutive words (K = 1, 2, 4) from an LDS address aligned to K words
+template <int K>
+__device__ __forceinline__ void elem_load(const float *src, float *w)
 {
-    if constexpr (std::is_same_v<E, float>) {
-        if constexpr (K == 4) {
-            const v4f t = *reinterpret_cast<const v4f *>(src);
-            w[0] = t.x, w[1] = t.y, w[2] = t.z, w[3] = t.w;
-        } else if constexpr (K == 2) {
-            const v2f t = *reinterpret_cast<const v2f *>(src);
-            w[0] = t.x, w[1] = t.y;
-        } else {
-            w[0] = src[0];
-        }
+    if constexpr (K == 4) {
+        const v4f t = *reinterpret_cast<const v4f *>(src);
+        w[0] = t.x, w[1] = t.y, w[2] = t.z, w[3] = t.w;
+    } else if constexpr (K == 2) {
+        const v2f t = *reinterpret_cast<const v2f *>(src);
+        w[0] = t.x, w[1] = t.y;
     } else {
-        if constexpr (K == 1) {
-            w[0] = src[0];
-        } else {
-#pragma unroll
-            for (int h = 0; h < K / 2; h++) {
-                const v4f t = reinterpret_cast<const v4f *>(src)[h];
-                w[2 * h] = v2f{t.x, t.y}, w[2 * h + 1] = v2f{t.z, t.w};
-            }
-        }
+        w[0] = src[0];
     }
 }
-template <class E>
-__device__ __forceinline__ void elem_store2(E *dst, E e0, E e1)
-{
-    if constexpr (std::is_same_v<E, float>)
-        *reinterpret_cast<v2f *>(dst) = v2f{e0, e1};
-    else
-        *reinterpret_cast<v4f *>(dst) = v4f{e0.x, e0.y, e1.x, e1.y};
-}
+__device__ __forceinline__ void elem_store2(float *dst, float e0, float e1) { *reinterpret_cast<v2f *>(dst) = v2f{e0, e1}; }
 
 template <int TS, int S, bool DEC>
 struct Casc {
@@ -180,10 +142,9 @@ struct Roll {
             src[k] = d + sft;
         }
     }
-    template <class E>
-    __device__ __forceinline__ void run(E *lds, int lid) const
+    __device__ __forceinline__ void run(float *lds, int lid) const
     {
-        E t[per_thread];
+        float t[per_thread];
 #pragma unroll
         for (int k = 0; k < per_thread; k++)
             if ((k + 1) * kW <= total() || lid + k * kW < total()) t[k] = lds[src[k]];
@@ -196,11 +157,11 @@ struct Roll {
 };
 
 // Σ_k (w[lo + 2M-1-k] + w[lo + k]) * tap_k, sequential from -0.0 (src/hbf.rs:60-66)
-template <class C, int s, class E>
-__device__ __forceinline__ E window_sum(const E *w, int lo)
+template <class C, int s>
+__device__ __forceinline__ float window_sum(const float *w, int lo)
 {
     constexpr int M = C::M(s);
-    E acc = ElemTraits<E>::splat(-0.0f);
+    float acc = -0.0f;
     static_for<0, M>([&](auto k) {
         constexpr int K = decltype(k)::value;
         acc = acc + (w[lo + 2 * M - 1 - K] + w[lo + K]) * C::tap(s, K);
@@ -209,11 +170,11 @@ __device__ __forceinline__ E window_sum(const E *w, int lo)
 }
 
 // load NV vectors of P elements from an aligned LDS address into w[]
-template <int P, int NV, class E>
-__device__ __forceinline__ void lds_window(const E *src, E *w)
+template <int P, int NV>
+__device__ __forceinline__ void lds_window(const float *src, float *w)
 {
 #pragma unroll
-    for (int v = 0; v < NV; v++) elem_load<E, P>(src + P * v, w + P * v);
+    for (int v = 0; v < NV; v++) elem_load<P>(src + P * v, w + P * v);
 }
 
 // where the last stage's outputs go: element i of the chunk
@@ -222,35 +183,24 @@ struct StridedOut {
     size_t stride;
     __device__ __forceinline__ void operator()(int i, float v) const { p[size_t(i) * stride] = v; }
 };
-struct PairOut {  // lane A and lane B of a pair-mode wave (B masked when the lane count is odd)
-    float *pa, *pb;
-    size_t stride;
-    bool has_b;
-    __device__ __forceinline__ void operator()(int i, v2f v) const
-    {
-        pa[size_t(i) * stride] = v.x;
-        if (has_b) pb[size_t(i) * stride] = v.y;
-    }
-};
-
 // ------------------------------------------------------------- decimator
 // stage s of `HbfDec` (src/hbf.rs:163-185): y[i] = get(odd)[i] + even[i]
-template <class C, int s, bool FULL, class E, class YS>
-__device__ __forceinline__ void dec_stage(E *lds, int n_rt, const YS &yout, int lid)
+template <class C, int s, bool FULL, class YS>
+__device__ __forceinline__ void dec_stage(float *lds, int n_rt, const YS &yout, int lid)
 {
     constexpr int M = C::M(s), N = C::n(s), P = blocking(N);
     constexpr int de = pad4(M - 1), dq = pad4(2 * M - 1);
     constexpr int oq = dq % P, NV = (oq + 2 * M + P - 1 + P - 1) / P;
     constexpr int oe = de % P, NVE = (oe + P + P - 1) / P;
     constexpr int ITER = (N / P + kW - 1) / kW;
-    const E *Ev = lds + C::offA(s) + (de - oe);
-    const E *O = lds + C::offB(s) + (dq - oq);
+    const float *Ev = lds + C::offA(s) + (de - oe);
+    const float *O = lds + C::offB(s) + (dq - oq);
     const int n = FULL ? N : n_rt;
 #pragma unroll
     for (int it = 0; it < ITER; it++) {
         const int g = lid + it * kW, i0 = g * P;
         if (i0 >= n) continue;
-        E w[NV * P], e[NVE * P], out[P];
+        float w[NV * P], e[NVE * P], out[P];
         lds_window<P, NV>(O + i0, w);
         lds_window<P, NVE>(Ev + i0, e);
 #pragma unroll
@@ -262,10 +212,10 @@ __device__ __forceinline__ void dec_stage(E *lds, int n_rt, const YS &yout, int 
         } else {
             // `ChunkIn<_, 2>`: consecutive outputs pair up as the next stage's [even, odd]
             constexpr int Mn = C::M(s + 1);
-            E *En = lds + C::offA(s + 1) + up4(Mn - 1), *On = lds + C::offB(s + 1) + up4(2 * Mn - 1);
+            float *En = lds + C::offA(s + 1) + up4(Mn - 1), *On = lds + C::offB(s + 1) + up4(2 * Mn - 1);
             if constexpr (P == 4) {
-                elem_store2<E>(En + (i0 >> 1), out[0], out[2]);
-                elem_store2<E>(On + (i0 >> 1), out[1], out[3]);
+                elem_store2(En + (i0 >> 1), out[0], out[2]);
+                elem_store2(On + (i0 >> 1), out[1], out[3]);
             } else if constexpr (P == 2) {
                 En[g] = out[0];
                 On[g] = out[1];
@@ -276,18 +226,11 @@ __device__ __forceinline__ void dec_stage(E *lds, int n_rt, const YS &yout, int 
     }
 }
 
-template <class C, bool FULL, class E, class YS>
-__device__ __forceinline__ void dec_chunk(E *lds, int nin, const YS &yout, int lid, const Roll<C> &roll)
+template <class C, bool FULL, class YS>
+__device__ __forceinline__ void dec_chunk(float *lds, int nin, const YS &yout, int lid, const Roll<C> &roll)
 {
-#ifdef IDSP_EXP_HBF_NOSTAGES  // timing experiment only (tools/exp_hbf.sh): memory traffic without the arithmetic
-    if (lid == 0 && FULL) yout(0, lds[C::offA(0) + 8]);
-    return;
-#endif
     static_for<0, C::stages>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
-#ifdef IDSP_EXP_HBF_SKIP
-        if constexpr (((IDSP_EXP_HBF_SKIP) >> s_) & 1) return;
-#endif
         dec_stage<C, s_, FULL>(lds, nin >> (s_ + 1), yout, lid);
         lds_wave_sync();
     });
@@ -296,13 +239,13 @@ __device__ __forceinline__ void dec_chunk(E *lds, int nin, const YS &yout, int l
         return;
     }
     // ragged last chunk: roll the histories stage by stage, word j <- word n_s + j (src/hbf.rs:182-183)
-    E ke[C::stages], ko[C::stages];
+    float ke[C::stages], ko[C::stages];
     static_for<0, C::stages>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
         constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1;
         const int ns = nin >> (s_ + 1);
-        ke[s_] = lid < He ? lds[C::offA(s_) + pad4(He) + ns + lid] : ElemTraits<E>::splat(0.f);
-        ko[s_] = lid < Ho ? lds[C::offB(s_) + pad4(Ho) + ns + lid] : ElemTraits<E>::splat(0.f);
+        ke[s_] = lid < He ? lds[C::offA(s_) + pad4(He) + ns + lid] : 0.f;
+        ko[s_] = lid < Ho ? lds[C::offB(s_) + pad4(Ho) + ns + lid] : 0.f;
     });
     lds_wave_sync();
     static_for<0, C::stages>([&](auto s) {
@@ -326,157 +269,70 @@ __device__ __forceinline__ size_t xcd_lane(size_t lanes)
     return (blockIdx.x % 8) * per + blockIdx.x / 8;
 }
 
-#ifdef IDSP_HBF_WPE  // experiment (tools/exp_hbf.sh): register budget for this many waves per SIMD
-#define IDSP_HBF_WPE_ATTR __attribute__((amdgpu_waves_per_eu(IDSP_HBF_WPE, IDSP_HBF_WPE)))
-#else
-#define IDSP_HBF_WPE_ATTR
-#endif
-template <class C, bool LM, int PK = 1>
-__global__ __launch_bounds__(kW) IDSP_HBF_WPE_ATTR void hbf_dec_wave(uint32_t *st, const float *x, float *y, const size_t lanes,
-                                                   const size_t frames)
+// FRAME_MAJOR decimator, one wave per lane: the fallback for lane counts that are not whole workgroups of the kernels below
+// (and of hbf_ring.h).  x[(f*lanes + lane)*R + k], y[f*lanes + lane]; its loads are R*4-byte fragments that rely on L2
+// to merge neighbouring lanes, hence one chunk in flight only (two ran 1.72 instead of 1.4 ms at C3).
+template <class C>
+__global__ __launch_bounds__(kW) void hbf_dec_wave(uint32_t *st, const float *x, float *y, const size_t lanes, const size_t frames)
 {
-    using E = std::conditional_t<PK == 2, v2f, float>;
-    using T = ElemTraits<E>;
-    __shared__ __attribute__((aligned(16))) E lds[C::lds_words];
+    __shared__ __attribute__((aligned(16))) float lds[C::lds_words];
     constexpr int S = C::stages, R = C::rate;
-    static_assert(LM || R >= 4, "FRAME_MAJOR wave kernel needs 16-byte frame pieces");
-    static_assert(PK == 1 || PK == 2, "one lane or a pair of lanes per wave");
+    static_assert(R >= 4, "FRAME_MAJOR wave kernel needs 16-byte frame pieces");
     const int lid = threadIdx.x;
-    // pair mode: wave w runs lanes 2 w and 2 w + 1 (an odd lane count leaves the last wave's lane B a masked shadow of lane A)
-    const size_t nunits = (lanes + PK - 1) / PK;
-    const size_t unit = LM ? size_t(blockIdx.x) : xcd_lane(nunits);
-    if (unit >= nunits) return;
-    const size_t lane = unit * PK;
-#ifdef IDSP_EXP_HBF_STAGGER  // timing experiment only (tools/exp_hbf.sh): first-generation waves start (blockIdx % 16) x this many ~0.4 us apart,
-                             // so that the lanes in flight do not all sit at the same offset inside their (power-of-two apart) rows
-    for (int i = 0; i < int(blockIdx.x % 16) * (IDSP_EXP_HBF_STAGGER); i++) __builtin_amdgcn_s_sleep(16);
-#endif
-    const bool has_b = PK == 2 && lane + 1 < lanes;
-    const size_t lane_b = has_b ? lane + 1 : lane;
+    const size_t lane = xcd_lane(lanes);
+    if (lane >= lanes) return;
 
     // history <- state words (per stage: even[M-1] then odd[2M-1], oldest first)
     static_for<0, S>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
         constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1, so = C::state_off(s_);
-        if (lid < He)
-            lds[C::offA(s_) + pad4(He) + lid] = T::make(__uint_as_float(st[size_t(so + lid) * lanes + lane]), __uint_as_float(st[size_t(so + lid) * lanes + lane_b]));
-        if (lid < Ho)
-            lds[C::offB(s_) + pad4(Ho) + lid] =
-                T::make(__uint_as_float(st[size_t(so + He + lid) * lanes + lane]), __uint_as_float(st[size_t(so + He + lid) * lanes + lane_b]));
+        if (lid < He) lds[C::offA(s_) + pad4(He) + lid] = __uint_as_float(st[size_t(so + lid) * lanes + lane]);
+        if (lid < Ho) lds[C::offB(s_) + pad4(Ho) + lid] = __uint_as_float(st[size_t(so + He + lid) * lanes + lane]);
     });
 
     Roll<C> roll;
     roll.plan(lid);
-    constexpr int CHF = kCH / R;     // output frames per chunk
-    constexpr int kPre = kCH / 4 / kW;  // 16-byte pieces per thread, lane and chunk
-    constexpr int M0 = C::M(0);
-    E *E0n = lds + C::offA(0) + up4(M0 - 1), *O0n = lds + C::offB(0) + up4(2 * M0 - 1);
-    // Two chunks in flight (register double buffer, statically indexed: the chunk loop is unrolled by two): with 16-18
-    // waves per CU one 4 KiB chunk per wave left only 64-72 KiB per CU in flight and the loads alone (arithmetic removed,
-    // tools/exp_hbf.sh) ran at 0.72 of the HBM peak.  Whole chunks take an unpredicated path: the per-piece `q < n`
-    // tests with their exec-mask bookkeeping were ~50 of the ~500 instructions per chunk of an issue-bound kernel.
-    // FRAME_MAJOR (this kernel is the fallback there; the 4-lane workgroups of hbf_dec_block_fm are the default) keeps one
-    // chunk in flight: its loads are 64-byte fragments that rely on L2 to merge neighbouring lanes, and twice as many of
-    // them in flight ran 1.72 instead of 1.4 ms at C3.
-    constexpr int kAhead = LM ? 2 : 1;
-    v4f pre[kAhead][PK][kPre];
-    auto piece = [&](size_t ln, size_t f0, int q) -> const v4f * {
-        if constexpr (LM) {
-            return reinterpret_cast<const v4f *>(x + (ln * frames + f0) * size_t(R)) + q;
-        } else {
-            constexpr int PPF = R / 4;  // pieces per frame
-            return reinterpret_cast<const v4f *>(x + ((f0 + size_t(q / PPF)) * lanes + ln) * size_t(R)) + (q % PPF);
-        }
+    constexpr int CHF = kCH / R;        // output frames per chunk
+    constexpr int kPre = kCH / 4 / kW;  // 16-byte pieces per thread and chunk
+    constexpr int M0 = C::M(0), PPF = R / 4;
+    float *E0n = lds + C::offA(0) + up4(M0 - 1), *O0n = lds + C::offB(0) + up4(2 * M0 - 1);
+    v4f pre[kPre];
+    auto piece = [&](size_t f0, int q) -> const v4f * {
+        return reinterpret_cast<const v4f *>(x + ((f0 + size_t(q / PPF)) * lanes + lane) * size_t(R)) + (q % PPF);
     };
-    // contiguous 1 KiB per wave instruction in LANE_MAJOR: streamed once -> nontemporal;
-    // FRAME_MAJOR pieces are 64-byte fragments that rely on L2 to merge neighbours
-    auto load = [&](size_t ln, size_t f0, int q) -> v4f {
-#ifdef IDSP_EXP_HBF_NOLOAD  // timing experiment only: the arithmetic without the input stream
-        return v4f{float(q), 1.f, 2.f, 3.f};
-#else
-        return LM ? __builtin_nontemporal_load(piece(ln, f0, q)) : *piece(ln, f0, q);
-#endif
-    };
-    auto fetch = [&](auto slot, size_t f0) {
-        constexpr int SL = decltype(slot)::value;
+    auto fetch = [&](size_t f0) {
         if (f0 >= frames) return;
-        if (frames - f0 >= size_t(CHF)) {
+        const int nq = frames - f0 >= size_t(CHF) ? kCH / 4 : int(frames - f0) * R / 4;
 #pragma unroll
-            for (int i = 0; i < kPre; i++) {
-                pre[SL][0][i] = load(lane, f0, lid + i * kW);
-                if constexpr (PK == 2) pre[SL][1][i] = load(lane_b, f0, lid + i * kW);
-            }
-        } else {
-            const int nf = int(frames - f0);
+        for (int i = 0; i < kPre; i++)
+            if (lid + i * kW < nq) pre[i] = *piece(f0, lid + i * kW);
+    };
+    fetch(0);
+    for (size_t f0 = 0; f0 < frames; f0 += size_t(CHF)) {
+        const int nin = frames - f0 >= size_t(CHF) ? kCH : int(frames - f0) * R;
+        // stage-0 input: pairs [even, odd] split into the two streams
 #pragma unroll
-            for (int i = 0; i < kPre; i++) {
-                const int q = lid + i * kW;
-                if (q < nf * R / 4) {
-                    pre[SL][0][i] = load(lane, f0, q);
-                    if constexpr (PK == 2) pre[SL][1][i] = load(lane_b, f0, q);
-                }
+        for (int i = 0; i < kPre; i++) {
+            const int q = lid + i * kW;
+            if (q < nin / 4) {
+                elem_store2(E0n + 2 * q, pre[i].x, pre[i].z);
+                elem_store2(O0n + 2 * q, pre[i].y, pre[i].w);
             }
         }
-    };
-    // stage-0 input: pairs [even, odd] split into the two streams (pair mode: lane A and lane B side by side)
-    auto split = [&](auto slot, int i, int q) {
-        constexpr int SL = decltype(slot)::value;
-        const v4f a = pre[SL][0][i], b = pre[SL][PK - 1][i];
-        elem_store2<E>(E0n + 2 * q, T::make(a.x, b.x), T::make(a.z, b.z));
-        elem_store2<E>(O0n + 2 * q, T::make(a.y, b.y), T::make(a.w, b.w));
-    };
-    auto chunk = [&](auto slot, size_t f0) {
-        float *yg = LM ? y + lane * frames + f0 : y + f0 * lanes + lane;
-        const size_t ystride = LM ? 1 : lanes;
-        auto yout = [&]() {
-            if constexpr (PK == 2)
-                return PairOut{yg, LM ? yg + frames : yg + 1, ystride, has_b};
-            else
-                return StridedOut{yg, ystride};
-        }();
-        if (frames - f0 >= size_t(CHF)) {
-#pragma unroll
-            for (int i = 0; i < kPre; i++) split(slot, i, lid + i * kW);
-            fetch(slot, f0 + kAhead * size_t(CHF));  // kAhead chunks ahead, into the slot just emptied
-            lds_wave_sync();
-            dec_chunk<C, true>(lds, kCH, yout, lid, roll);
-        } else {
-            const int nin = int(frames - f0) * R;
-#pragma unroll
-            for (int i = 0; i < kPre; i++) {
-                const int q = lid + i * kW;
-                if (q < nin / 4) split(slot, i, q);
-            }
-            lds_wave_sync();
+        fetch(f0 + size_t(CHF));
+        lds_wave_sync();
+        const StridedOut yout{y + f0 * lanes + lane, lanes};
+        if (nin == kCH)
+            dec_chunk<C, true>(lds, nin, yout, lid, roll);
+        else
             dec_chunk<C, false>(lds, nin, yout, lid, roll);
-        }
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    fetch(S0{}, 0);
-    if constexpr (kAhead == 2) {
-        fetch(S1{}, size_t(CHF));
-        for (size_t f0 = 0; f0 < frames; f0 += 2 * size_t(CHF)) {
-            chunk(S0{}, f0);
-            if (f0 + CHF < frames) chunk(S1{}, f0 + CHF);
-        }
-    } else {
-        for (size_t f0 = 0; f0 < frames; f0 += size_t(CHF)) chunk(S0{}, f0);
     }
 
     static_for<0, S>([&](auto s) {
         constexpr int s_ = decltype(s)::value;
         constexpr int M = C::M(s_), He = M - 1, Ho = 2 * M - 1, so = C::state_off(s_);
-        if (lid < He) {
-            const E e = lds[C::offA(s_) + pad4(He) + lid];
-            st[size_t(so + lid) * lanes + lane] = __float_as_uint(T::a(e));
-            if (has_b) st[size_t(so + lid) * lanes + lane_b] = __float_as_uint(T::b(e));
-        }
-        if (lid < Ho) {
-            const E e = lds[C::offB(s_) + pad4(Ho) + lid];
-            st[size_t(so + He + lid) * lanes + lane] = __float_as_uint(T::a(e));
-            if (has_b) st[size_t(so + He + lid) * lanes + lane_b] = __float_as_uint(T::b(e));
-        }
+        if (lid < He) st[size_t(so + lid) * lanes + lane] = __float_as_uint(lds[C::offA(s_) + pad4(He) + lid]);
+        if (lid < Ho) st[size_t(so + He + lid) * lanes + lane] = __float_as_uint(lds[C::offB(s_) + pad4(Ho) + lid]);
     });
 }
 
@@ -813,33 +669,18 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
 {
     using C = Casc<TS, S, DEC>;
     const dim3 grid{unsigned(lm ? lanes : 8 * ((lanes + 7) / 8))}, block{unsigned(kW)};
-    // Decimator pair mode (two lanes per wave, packed f32 arithmetic; IDSP_DIAG=1 IDSP_HBF_PAIR=1): bit-exact (the GPU suite runs
-    // it, tests/test_gpu_hbf_pair_mode.py) and NOT the default — it halves the VALU instructions per sample and is no
-    // faster: C3 0.928 ms against 0.911 with one lane per wave; its arithmetic alone (input loads removed) takes 0.687 ms
-    // against 0.61, its loads alone 0.80 against 0.79 (profiles/r03_exp_hbf_pair.jsonl).  v_pk_add_f32 / v_pk_mul_f32 do not
-    // issue at the rate of two scalar operations here, and 189 VGPRs leave 8 waves per CU to hide the LDS round trips.
-    static const bool no_pair = diag_env("IDSP_HBF_PAIR") == nullptr;
-    const size_t npairs = (lanes + 1) / 2;
     if (lm) {
-        note_kernel(DEC ? (no_pair ? "hbf_dec_wave[LaneMajor]" : "hbf_dec_wave[LaneMajor, 2 lanes per wave]") : "hbf_int_wave[LaneMajor]", typeid(C).name());
         if constexpr (DEC) {
-            if (no_pair)
-                hipLaunchKernelGGL((hbf_dec_wave<C, true, 1>), grid, block, 0, stream, st, x, y, lanes, frames);
-            else
-                hipLaunchKernelGGL((hbf_dec_wave<C, true, 2>), dim3(unsigned(npairs)), block, 0, stream, st, x, y, lanes, frames);
-        } else
+            return 1;  // LANE_MAJOR decimators: hbf_ring.h
+        } else {
+            note_kernel("hbf_int_wave[LaneMajor]", typeid(C).name());
             hipLaunchKernelGGL((hbf_int_wave<C, true>), grid, block, 0, stream, st, x, y, lanes, frames);
+        }
     } else {
         if constexpr (S >= 2) {
             if constexpr (DEC) {
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + 2 * (kCH / C::rate) * kBlkLanes) * sizeof(float);
                 static const bool use_block = !diag_env("IDSP_HBF_NO_BLOCK_FM");
-                static const bool fm_pair = diag_env("IDSP_HBF_FM_PAIR") != nullptr;  // experiment: the pair-mode wave kernel on FRAME_MAJOR
-                if (fm_pair) {
-                    note_kernel("hbf_dec_wave[FrameMajor, 2 lanes per wave]", typeid(C).name());
-                    hipLaunchKernelGGL((hbf_dec_wave<C, false, 2>), dim3(unsigned(8 * ((npairs + 7) / 8))), block, 0, stream, st, x, y, lanes, frames);
-                    return 0;
-                }
                 if (use_block && bytes <= 160 * 1024 && lanes % kBlkLanes == 0) {
                     if (ensure_dyn_lds<&hbf_dec_block_fm<C>>(bytes)) return 1;  // once per device (common.h)
                     const size_t ngroups = lanes / kBlkLanes;
@@ -849,7 +690,7 @@ int launch_wave(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
                     return 0;
                 }
                 note_kernel("hbf_dec_wave[FrameMajor]", typeid(C).name());
-                hipLaunchKernelGGL((hbf_dec_wave<C, false, 1>), grid, block, 0, stream, st, x, y, lanes, frames);
+                hipLaunchKernelGGL((hbf_dec_wave<C>), grid, block, 0, stream, st, x, y, lanes, frames);
             }
             else {
                 constexpr size_t bytes = (size_t(kBlkLanes) * up4(C::lds_words) + size_t(kBlkLanes) * kCH) * sizeof(float);

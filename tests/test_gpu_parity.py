@@ -295,7 +295,10 @@ HBF_CASES = [(_cascade, 0, s) for s in (1, 2, 3, 4, 5)] + [(_cascade, 1, s) for 
 def hbf_shapes(stages):
     ch = 4096 >> stages
     return [(1, 1), (3, 5), (2, ch - 1), (2, ch), (3, ch + 1), (1, 2 * ch + 7), (17, 40),
-            (4, 1), (4, ch + 3), (8, 130), (12, 2 * ch + 5), (64, 3 * (1024 >> stages) + 1)]  # whole 4-lane workgroups: FM block kernel
+            (4, 1), (4, ch + 3), (8, 130), (12, 2 * ch + 5), (20, 70),  # whole 4-lane workgroups: FM block kernel
+            # whole 16-lane groups: the FM ring kernel (/16); rounds of 1024 input samples: one, ragged, the first / last two (SAFE) and FAST ones
+            (64, 3 * (1024 >> stages) + 1), (16, 1), (16, (1024 >> stages) - 1), (48, 2 * (1024 >> stages) + 5), (16, 7 * (1024 >> stages) + 3),
+            (3, 9 * (1024 >> stages)), (2, 6 * (1024 >> stages) + 4)]  # LM ring kernel through FAST rounds
 
 
 @pytest.mark.parametrize("tap_set,stages", [(c[1], c[2]) for c in HBF_CASES])

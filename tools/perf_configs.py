@@ -119,18 +119,40 @@ def biquad(op, dtype, words, lanes, frames, layout, n_sections, iters, tag):
            8 * lanes * frames * passes, med, mn)
 
 
+_hbf_lib = None
+
+
+def hbf_call(name, *args):
+    """idsp_hbf_{dec,int}_f32 from IDSP_HBF_LIB if set (a small library holding only the half-band objects: timing
+    variants of tools/exp_hbf_ring.sh), else from the engine."""
+    global _hbf_lib
+    path = os.environ.get("IDSP_HBF_LIB")
+    if not path:
+        return call(name, *args)
+    if _hbf_lib is None:
+        _hbf_lib = C.CDLL(path)
+    fn = getattr(_hbf_lib, "idsp_" + name)
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+    rc = fn(*args)
+    assert rc == 0, rc
+    return rc
+
+
 def hbf(kind, stages, lanes, frames_low, layout, iters, tag):
     cfg = _abi.HbfCascadeF32()
     call(f"hbf_{kind}_cascade", 0, stages, C.byref(cfg))
     R = 1 << stages
     words = call(f"hbf_{kind}_state_words", C.byref(cfg))
     hi = torch.randn(lanes * frames_low * R, dtype=torch.float32, device=dev)
+    if os.environ.get("IDSP_PERF_ZERO"):  # diagnostic only: all-zero input draws less power (the clock it buys is not a valid result)
+        hi.zero_()
     lo = torch.randn(lanes * frames_low, dtype=torch.float32, device=dev)
     st = torch.zeros((words, lanes), dtype=torch.int32, device=dev)
     x, y = (hi, lo) if kind == "dec" else (lo, hi)
 
     def run():
-        call(f"hbf_{kind}_f32", C.byref(cfg), p(st), p(x), p(y), lanes, frames_low, layout, sptr())
+        hbf_call(f"hbf_{kind}_f32", C.byref(cfg), p(st), p(x), p(y), lanes, frames_low, layout, sptr())
 
     med, mn = timeit(run, iters)
     n_hi = lanes * frames_low * R
@@ -378,6 +400,9 @@ def main():
         for lg in (17, 20):
             biquad("biquad_i32_df1", torch.int32, 4, 1 << lg, 4096, FM, 1, max(3, it >> max(0, lg - 17)), "C5s")
             biquad("biquad_i32_df1_clamp", torch.int32, 4, 1 << lg, 4096, FM, 1, max(3, it >> max(0, lg - 17)), "C5s")
+    if want("c3dec"):  # the decimator alone (profiling passes)
+        hbf("dec", 4, 16384, 4096, LM, it, "C3")
+        hbf("dec", 4, 16384, 4096, FM, it, "C3")
     if want("c3"):
         hbf("dec", 4, 16384, 4096, LM, it, "C3")
         hbf("dec", 4, 16384, 4096, FM, max(3, it // 3), "C3")
