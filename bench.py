@@ -6,6 +6,16 @@
     `idsp_biquad_i32_df1` on a FRAME_MAJOR `[[i32; 65536]; 4096]` tensor (1 GiB in, 1 GiB out).
     With --gpus N every rank runs this per-GPU workload on its own lanes (WEAK scaling).
     The line also carries a `c5` sub-object (below) so that one command yields both scaling curves.
+    Beside `c5` the default line carries `c3` and `c4` sub-objects: the other two single-GPU configurations of BASELINE.json,
+    each with its own timed region (<= 20 steps), `roofline` and `integrity`, so that one driver run measures all four.
+--config c3 (BASELINE.json configs[2], "C3"):
+    hbf::HbfDec /16 (HBF_TAPS stages 3,2,1,0; src/hbf.rs:385-421), f32, 16384 lanes x 65536 input samples per lane
+    (4 GiB in, 256 MiB out), `idsp_hbf_dec_f32`; 4.25 algorithmic bytes per input sample.
+--config c4 (BASELINE.json configs[3], "C4"):
+    DDC lock-in Accu -> cossin -> mix -> [Lowpass<2>; 2] (src/lockin.rs:30-39), i32, 32768 lanes x 4096 samples, per-lane
+    Accu step, `idsp_lockin_i32_process`; 12 algorithmic bytes per sample (4 in, Complex<i32> out).
+    C3 / C4 inputs are counter hashes like C5's (below); with --gpus N every rank runs the same lanes (replicas of the
+    per-GPU workload: WEAK scaling, one checksum on file serves every rank).
 --config c5 (BASELINE.json configs[4], "C5"):
     f32 DF2T biquad over 2^20 lanes x 4096 samples (16 GiB in, 16 GiB out in total), the lanes split
     contiguously over the ranks by idsp_amd.sharding.lane_shard (STRONG scaling: total work fixed).
@@ -76,6 +86,18 @@ CONFIGS = {
         scaling="weak", state_words=4, bytes_per_sample=8, seed=2, oracle_kind=0,
         workload="configs[1]: 65536-lane i32 Biquad DF1 (Q30 lowpass f0=0.01), shared coeffs, 4096 samples/lane, per GPU",
     ),
+    "c3": dict(
+        metric="f32_hbf_dec16_16k_lanes_throughput", family="hbf_dec", entry="hbf_dec_f32", dtype="f32", lanes=16384, frames=4096,
+        rate=16, scaling="weak", replicas=True, state_words=118, bytes_per_frame=68, samples_per_frame=16, seed=3,
+        workload="configs[2]: hbf::HbfDec /16 (HBF_TAPS stages 3,2,1,0), f32, 16384 lanes x 65536 input samples per lane "
+                 "(4096 output frames), per GPU",
+    ),
+    "c4": dict(
+        metric="i32_lockin_32k_lanes_throughput", family="lockin", entry="lockin_i32_process", dtype="i32", lanes=32768, frames=4096,
+        scaling="weak", replicas=True, state_words=18, bytes_per_frame=12, seed=4,
+        workload="configs[3]: DDC lock-in Accu -> cossin -> mix -> [Lowpass<2>; 2] (f0 = 1e-3 fn), i32, 32768 lanes x 4096 "
+                 "samples, per-lane Accu step, Complex<i32> out, per GPU",
+    ),
     "c5": dict(
         metric="f32_df2t_biquad_1M_lanes_throughput", entry="biquad_f32_df2t", dtype="f32", lanes=1 << 20, frames=4096,
         scaling="strong", state_words=2, bytes_per_sample=8, seed=5, oracle_kind=1,
@@ -101,6 +123,8 @@ def job_shard(cfg: dict, rank: int, world: int, lanes_override: int | None = Non
     from idsp_amd.sharding import lane_shard
 
     lanes = lanes_override or cfg["lanes"]
+    if cfg.get("replicas"):
+        return 0, lanes  # every rank the same lanes (C3 / C4)
     if cfg["scaling"] == "weak":
         return rank * lanes, lanes
     lo, hi = lane_shard(lanes, rank, world)
@@ -108,8 +132,9 @@ def job_shard(cfg: dict, rank: int, world: int, lanes_override: int | None = Non
 
 
 def algorithmic_bytes(cfg: dict, lanes: int, frames: int) -> int:
-    """4 B read + 4 B written per sample, plus each state plane once in and once out."""
-    return lanes * frames * cfg["bytes_per_sample"] + 2 * cfg["state_words"] * 4 * lanes
+    """biquads 4 B read + 4 B written per sample; HbfDec /16 4.25 B per input sample (16 x 4 B in + 4 B out
+    per output frame); lock-in 4 B in + 8 B out per sample — plus each state plane once in and once out."""
+    return lanes * frames * cfg.get("bytes_per_frame", cfg.get("bytes_per_sample", 8)) + 2 * cfg["state_words"] * 4 * lanes
 
 
 def wrap64(v: int) -> int:
@@ -158,6 +183,63 @@ def c5_input(xp, lane_lo: int, lanes: int, f_lo: int, f_hi: int, layout: str = "
     return ((_c5_hash(idx, xp) >> 8).astype(xp.float32) * xp.float32(2.0 ** -23) - xp.float32(1.0)).astype(xp.float32)
 
 
+def c3_input(xp, lane_lo: int, lanes: int, f_lo: int, f_hi: int, layout: str = "frame", device=None, rate: int = 16):
+    """C3 input samples of lanes [lane_lo, lane_lo + lanes), output frames [f_lo, f_hi) (`rate` samples each): uniform in
+    [-1, 1), x = (h >> 8) * 2^-23 - 1 with h = hash(2^32 + lane * 2^16 + sample).  FRAME_MAJOR [frame][lane][rate],
+    LANE_MAJOR [lane][frame * rate]."""
+    tor = xp.__name__ == "torch"
+    kw = dict(device=device) if tor else {}
+    f = xp.arange(f_lo, f_hi, dtype=xp.int64, **kw)
+    l = xp.arange(lane_lo, lane_lo + lanes, dtype=xp.int64, **kw)
+    k = xp.arange(rate, dtype=xp.int64, **kw)
+    if layout == "frame":
+        idx = (l[None, :, None] << 16) + f[:, None, None] * rate + k[None, None, :]
+    else:
+        idx = (l[:, None, None] << 16) + f[None, :, None] * rate + k[None, None, :]
+    h = _c5_hash(idx + (1 << 32), xp) >> 8
+    if tor:
+        return h.to(xp.float32) * (2.0 ** -23) - 1.0
+    return (h.astype(xp.float32) * xp.float32(2.0 ** -23) - xp.float32(1.0)).astype(xp.float32)
+
+
+def c4_input(xp, lane_lo: int, lanes: int, f_lo: int, f_hi: int, layout: str = "frame", device=None):
+    """C4 samples: i32 uniform in [-2^28, 2^28), x = (h >> 3) - 2^28 with h = hash(2^33 + frame * 2^20 + lane)."""
+    tor = xp.__name__ == "torch"
+    kw = dict(device=device) if tor else {}
+    f = xp.arange(f_lo, f_hi, dtype=xp.int64, **kw)
+    l = xp.arange(lane_lo, lane_lo + lanes, dtype=xp.int64, **kw)
+    idx = (f[:, None] << 20) + l[None, :] if layout == "frame" else (f[None, :] << 20) + l[:, None]
+    v = (_c5_hash(idx + (1 << 33), xp) >> 3) - (1 << 28)
+    return v.to(xp.int32) if tor else v.astype(xp.int32)
+
+
+def c4_steps(xp, lane_lo: int, lanes: int, device=None):
+    """Per-lane `Accu` step (src/accu.rs:16-41): all 32 bits of hash(2^34 + lane), as i32."""
+    tor = xp.__name__ == "torch"
+    l = xp.arange(lane_lo, lane_lo + lanes, dtype=xp.int64, **(dict(device=device) if tor else {}))
+    h = _c5_hash(l + (1 << 34), xp)
+    h = h - ((h >> 31) << 32)  # two's complement view of the 32-bit pattern
+    return h.to(xp.int32) if tor else h.astype(xp.int32)
+
+
+def lockin_k():
+    """[Lowpass<2>; 2] configuration of C4: k = pi 2^31 f0 / fn with f0 = 1e-3 fn; [k^2 / 2^32, -k sqrt 2] (src/lowpass.rs:29-46)."""
+    k = math.pi * (1 << 31) * 1e-3
+    return [int(k * k / (1 << 32)), -int(k * math.sqrt(2.0))]
+
+
+def blockwise(gen, xp, out, lanes, frames, layout, per_frame=1):
+    """Fill `out` ([frames][lanes](xR) or [lanes][frames](xR)) from gen(f0, f1) in pieces of ~16 M elements."""
+    step = max(1, (1 << 24) // max(lanes * per_frame, 1))
+    for f0 in range(0, frames, step):
+        f1 = min(frames, f0 + step)
+        if layout == "frame":
+            out[f0:f1] = gen(f0, f1)
+        else:
+            out[:, f0:f1] = gen(f0, f1)
+    return out
+
+
 def c5_input_host(lane_lo: int, lanes: int, frames: int, layout: str = "frame"):
     """The C5 samples of a lane block on the host (numpy), built in pieces of ~4 M samples."""
     import numpy as np
@@ -193,6 +275,9 @@ def expected_for(cfg_name: str, layout: str, rank: int, lane_lo: int, lanes: int
     if cfg_name == "c2":
         e = tab.get("ranks", {}).get(str(rank))
         return [int(e["y"]), int(e["state"])] if e else None
+    if cfg_name in ("c3", "c4"):  # every rank runs the same lanes
+        e = tab.get("ranks", {}).get("0")
+        return [int(e["y"]), int(e["state"])] if e else None
     blocks = tab.get("blocks", [])
     if tab.get("block_lanes") != C5_BLOCK or lane_lo % C5_BLOCK or lanes % C5_BLOCK:
         return None
@@ -206,6 +291,8 @@ def expected_for(cfg_name: str, layout: str, rank: int, lane_lo: int, lanes: int
 
 class HipEngine:
     """The product path: device buffers from torch, launches through the C ABI on one HIP stream."""
+
+    FAMILIES = ("biquad", "hbf_dec", "lockin")  # configuration families this engine runs (rank_main skips the others' sub-objects)
 
     @staticmethod
     def device_setup(local_rank: int):
@@ -231,8 +318,31 @@ class HipEngine:
         self.lanes, self.frames, self.frame_major = lanes, frames, layout == "frame"
         self.layout = _abi.FRAME_MAJOR if self.frame_major else _abi.LANE_MAJOR
         self.x_host = None
-        sos = (C.c_double * 6)(*lowpass_sos(F0))
-        if cfg["dtype"] == "i32":
+        self.family = cfg.get("family", "biquad")
+        self.state_init = None  # rows of the state that are not zero at the start of a stream: {row: tensor}
+        n_sections = 1
+        if self.family == "hbf_dec":
+            R = cfg["rate"]
+            self.cfgs = _abi.HbfCascadeF32()
+            call("hbf_dec_cascade", 0, R.bit_length() - 1, C.byref(self.cfgs))
+            assert self.fn["hbf_dec_state_words"](C.byref(self.cfgs)) == cfg["state_words"]
+            self.x = torch.empty(lanes * frames * R, dtype=torch.float32, device=self.dev)
+            xv = self.x.view(frames, lanes, R) if self.frame_major else self.x.view(lanes, frames, R)
+            blockwise(lambda f0, f1: c3_input(torch, lane_lo, lanes, f0, f1, layout, self.dev, R), torch, xv, lanes, frames, layout, R)
+            self.y = torch.empty(lanes * frames, dtype=torch.float32, device=self.dev)
+        elif self.family == "lockin":
+            self.cfgs = _abi.LockinI32()
+            self.cfgs.order, self.cfgs.cascade = 2, 2
+            for c in range(2):
+                self.cfgs.k[c][0], self.cfgs.k[c][1] = lockin_k()
+            assert self.fn["lockin_state_words"](C.byref(self.cfgs)) == cfg["state_words"]
+            self.x = torch.empty(lanes * frames, dtype=torch.int32, device=self.dev)
+            xv = self.x.view(frames, lanes) if self.frame_major else self.x.view(lanes, frames)
+            blockwise(lambda f0, f1: c4_input(torch, lane_lo, lanes, f0, f1, layout, self.dev), torch, xv, lanes, frames, layout)
+            self.y = torch.empty(lanes * frames * 2, dtype=torch.int32, device=self.dev)
+            self.state_init = {1: c4_steps(torch, lane_lo, lanes, self.dev)}  # Accu {state, step}: row 1 = step
+        elif cfg["dtype"] == "i32":
+            sos = (C.c_double * 6)(*lowpass_sos(F0))
             rec = _abi.BiquadI32()
             call("biquad_i32_from_sos", sos, FRAC, C.byref(rec))
             self.cfgs = (_abi.BiquadI32 * 1)(rec)
@@ -241,26 +351,32 @@ class HipEngine:
             if rank != 0:
                 self.x_host = None
         else:
+            sos = (C.c_double * 6)(*lowpass_sos(F0))
             rec = _abi.BiquadF32()
             call("biquad_f32_from_sos_f64", sos, C.byref(rec))
             self.cfgs = (_abi.BiquadF32 * 1)(rec)
             self.x = torch.empty(lanes * frames, dtype=torch.float32, device=self.dev)
             xv = self.x.view(frames, lanes) if self.frame_major else self.x.view(lanes, frames)
-            step = max(1, (1 << 24) // max(lanes, 1))  # ~16 M samples (x 8 B x a few temporaries) at a time
-            for f0 in range(0, frames, step):
-                f1 = min(frames, f0 + step)
-                blk = c5_input(torch, lane_lo, lanes, f0, f1, layout, self.dev)
-                if self.frame_major:
-                    xv[f0:f1] = blk
-                else:
-                    xv[:, f0:f1] = blk
-        self.y = torch.empty_like(self.x)  # a plain second allocation: no placement tuning
+            blockwise(lambda f0, f1: c5_input(torch, lane_lo, lanes, f0, f1, layout, self.dev), torch, xv, lanes, frames, layout)
+        if self.family == "biquad":
+            self.y = torch.empty_like(self.x)  # a plain second allocation: no placement tuning
         self.state = torch.zeros((cfg["state_words"], lanes), dtype=torch.int32, device=self.dev)
+        self.reset_state()
         self.stream = torch.cuda.Stream(device=self.dev)
         self.entry = cfg["entry"]
-        self._args = (C.cast(self.cfgs, C.c_void_p), 1, C.c_void_p(self.state.data_ptr()), C.c_void_p(self.x.data_ptr()),
-                      C.c_void_p(self.y.data_ptr()), lanes, frames, self.layout, C.c_void_p(self.stream.cuda_stream))
+        tail = (C.c_void_p(self.state.data_ptr()), C.c_void_p(self.x.data_ptr()), C.c_void_p(self.y.data_ptr()), lanes, frames,
+                self.layout, C.c_void_p(self.stream.cuda_stream))
+        if self.family == "biquad":
+            self._args = (C.cast(self.cfgs, C.c_void_p), n_sections) + tail
+        else:
+            self._args = (C.byref(self.cfgs),) + tail
         self.sync()
+
+    def reset_state(self):
+        """The state at the start of a stream: zero, except the rows a configuration initialises (C4: the Accu steps)."""
+        self.state.zero_()
+        for row, val in (self.state_init or {}).items():
+            self.state[row] = val
 
     def step(self):
         self.call(self.entry, *self._args)
@@ -299,7 +415,7 @@ class HipEngine:
         from idsp_amd.sharding import checksum_i64
 
         self.sync()
-        self.state.zero_()
+        self.reset_state()
         self.sync()
         self.step()
         self.sync()
@@ -335,16 +451,19 @@ def run_timed(engine, steps: int, warmup: int, settle_ms: float, dist=None):
             engine.step()
         done += 8
         engine.sync()
+    # barrier, synchronize, THEN the clock; after the K steps synchronize, read the clock, THEN the closing barrier: the
+    # interval holds this rank's K steps only (the MAX over the ranks is taken by the caller), not the rendezvous
     if dist:
         dist.barrier()
     engine.sync()
     t0 = time.perf_counter()
     durations = engine.timed_steps(steps)
     engine.sync()
+    elapsed = time.perf_counter() - t0
     if dist:
         dist.barrier()
     engine.sync()
-    return time.perf_counter() - t0, durations(), done
+    return elapsed, durations(), done
 
 
 def host_cpu_budget(affinity_cpus: int):
@@ -485,7 +604,7 @@ def committed_traffic(config: str, kernel: str):
 
 
 def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, untimed, kernel, total_lanes):
-    samples_all = total_lanes * frames  # samples per step over all ranks
+    samples_all = total_lanes * frames * cfg.get("samples_per_frame", 1)  # (input) samples per step over all ranks
     alg_bytes = algorithmic_bytes(cfg, lanes_rank, frames)
     med = statistics.median(kern_ms) if kern_ms else 0.0
     achieved = alg_bytes / (med * 1e-3) / 1e9 if med > 0 else 0.0
@@ -575,7 +694,7 @@ def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend
     cfg = CONFIGS[cfg_name]
     frames = frames_override or cfg["frames"]
     lane_lo, lanes_rank = job_shard(cfg, rank, world, lanes_override or None)
-    total_lanes = (lanes_override or cfg["lanes"]) * (world if cfg["scaling"] == "weak" else 1)
+    total_lanes = (lanes_override or cfg["lanes"]) * (world if cfg["scaling"] == "weak" else 1)  # replicas count as lanes of their own
     engine = engine_factory(cfg_name, cfg, lane_lo, lanes_rank, frames, args.layout, rank, local)
     rdev = engine.reduce_device(backend)
     elapsed, kern_ms, untimed = run_timed(engine, steps, warmup, settle_ms, dist)
@@ -659,6 +778,16 @@ def rank_main(args, engine_factory=HipEngine):
         sub, e5 = run_config("c5", args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
                              min(args.warmup, 3), min(args.settle_ms, 100.0), args.c5_lanes, args.c5_frames)
         e5.free()
+    subs = {}
+    if args.config == "c2" and not (args.lanes or args.frames):
+        # the other single-GPU configurations of BASELINE.json beside the headline: own timed region, roofline and integrity
+        families = getattr(engine_factory, "FAMILIES", ("biquad",))
+        for name, skip in (("c3", args.no_c3), ("c4", args.no_c4)):
+            if skip or CONFIGS[name]["family"] not in families:
+                continue
+            subs[name], e = run_config(name, args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
+                                       min(args.warmup, 3), min(args.settle_ms, 100.0), 0, 0)
+            e.free()
     if rank == 0:
         line["rccl_ranks"] = rccl_ranks
         line["backend"] = "nccl (RCCL)" if backend == "nccl" else backend
@@ -670,7 +799,11 @@ def rank_main(args, engine_factory=HipEngine):
             keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config",
                     "roofline", "ranks", "integrity")
             line["c5"] = {k: sub[k] for k in keep}
-        if world == 1 and not args.no_cpu:
+        for name, sl in subs.items():
+            keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config",
+                    "roofline", "ranks", "integrity")
+            line[name] = {k: sl[k] for k in keep}
+        if world == 1 and not args.no_cpu and CONFIGS[args.config].get("family", "biquad") == "biquad":
             cb = cpu_baseline(args.config, CONFIGS[args.config], x_host, args.layout)
             integ = line["integrity"]
             if cb["oracle_checksum_lanes"] == line["config"]["lanes_per_gpu"]:
@@ -701,6 +834,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=0, help="override the samples per lane (diagnostics)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 strong-scaling sub-object of the default run")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 (HbfDec /16) sub-object of the default run")
+    ap.add_argument("--no-c4", action="store_true", help="skip the C4 (lock-in) sub-object of the default run")
     ap.add_argument("--c5-lanes", type=int, default=0, help="total lanes of the C5 sub-object (diagnostics; default 2^20)")
     ap.add_argument("--c5-frames", type=int, default=0, help="samples per lane of the C5 sub-object (diagnostics; default 4096)")
     return ap.parse_args(argv)

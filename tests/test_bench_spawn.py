@@ -124,3 +124,24 @@ def test_expected_checksums_on_file_cover_every_rank_and_split():
         assert tot == bench.expected_for("c5", "frame", 0, 0, 1 << 20, False)
     assert bench.expected_for("c2", "frame", 3, 0, 65536, False) is not None
     assert bench.expected_for("c2", "lane", 0, 0, 65536, False) is None and bench.expected_for("c2", "frame", 0, 0, 65536, True) is None
+
+
+def test_c3_c4_inputs_are_the_same_on_host_and_device_code_paths_and_their_checksums_are_on_file():
+    """bench.py's C3 / C4 sub-objects: counter-hash inputs (numpy == torch, FRAME_MAJOR == transposed LANE_MAJOR), and the
+    oracle checksums tests/golden/make_bench_checksums.py recorded for them."""
+    import torch
+
+    a = bench.c3_input(np, 3, 5, 2, 6, "frame")
+    assert a.shape == (4, 5, 16) and a.dtype == np.float32 and np.array_equal(a, bench.c3_input(torch, 3, 5, 2, 6, "frame").numpy())
+    assert np.array_equal(a.transpose(1, 0, 2), bench.c3_input(np, 3, 5, 2, 6, "lane")) and -1.0 <= a.min() and a.max() < 1.0
+    b = bench.c4_input(np, 3, 5, 2, 6, "frame")
+    assert b.dtype == np.int32 and np.array_equal(b, bench.c4_input(torch, 3, 5, 2, 6, "frame").numpy())
+    assert np.array_equal(b.T, bench.c4_input(np, 3, 5, 2, 6, "lane")) and -(1 << 28) <= b.min() and b.max() < (1 << 28)
+    assert np.array_equal(bench.c4_steps(np, 7, 9), bench.c4_steps(torch, 7, 9).numpy())
+    tab = bench.expected_checksums()
+    for name in ("c3", "c4"):
+        assert tab[name]["lanes"] == bench.CONFIGS[name]["lanes"] and tab[name]["frames"] == bench.CONFIGS[name]["frames"]
+        assert bench.expected_for(name, "frame", 5, 0, bench.CONFIGS[name]["lanes"], False) == bench.expected_for(name, "frame", 0, 0, 1, False)
+    assert bench.job_shard(bench.CONFIGS["c3"], 3, 8) == (0, 16384) and bench.job_shard(bench.CONFIGS["c4"], 1, 2) == (0, 32768)
+    assert bench.algorithmic_bytes(bench.CONFIGS["c3"], 16384, 4096) == 16384 * 4096 * 68 + 2 * 118 * 4 * 16384
+    assert bench.algorithmic_bytes(bench.CONFIGS["c4"], 32768, 4096) == 32768 * 4096 * 12 + 2 * 18 * 4 * 32768
