@@ -131,6 +131,8 @@ def test_c3_c4_inputs_are_the_same_on_host_and_device_code_paths_and_their_check
     oracle checksums tests/golden/make_bench_checksums.py recorded for them."""
     import torch
 
+    import bench
+
     a = bench.c3_input(np, 3, 5, 2, 6, "frame")
     assert a.shape == (4, 5, 16) and a.dtype == np.float32 and np.array_equal(a, bench.c3_input(torch, 3, 5, 2, 6, "frame").numpy())
     assert np.array_equal(a.transpose(1, 0, 2), bench.c3_input(np, 3, 5, 2, 6, "lane")) and -1.0 <= a.min() and a.max() < 1.0
