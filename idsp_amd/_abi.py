@@ -125,6 +125,8 @@ _I = C.c_int
 # last void*) is dropped when binding the checker library.
 _STREAM_SIG = [_P, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]  # cfg, n, state, x, y, lanes, frames, layout, stream
 _CFG_SIG = [_P, _P, _P, _P, _SZ, _SZ, _I, _P]          # cfg, state, x, y, lanes, frames, layout, stream
+_STREAM_LO_SIG = [_P, _SZ, _P, _P, _P, _P, _SZ, _SZ, _I, _P]  # sections, n, state, x, lo, y, lanes, frames, layout, stream
+_CFG_LO_SIG = [_P, _P, _P, _P, _P, _SZ, _SZ, _I, _P]          # cfg, state, x, lo, y, lanes, frames, layout, stream
 
 _BYLANE_I32_SIG = [_P, _I, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]  # coef, frac, n, state, x, y, lanes, frames, layout, stream
 _BYLANE_F_SIG = [_P, _SZ, _P, _P, _P, _SZ, _SZ, _I, _P]        # coef, n, state, x, y, lanes, frames, layout, stream
@@ -178,6 +180,10 @@ PROCESSING = {
     "lockin_i32_process": _CFG_SIG,
     "lockin_i32_arg": _CFG_SIG,
     "lockin_i32_norm_sqr": _CFG_SIG,
+    "lockin_i32_biquad_process": _STREAM_SIG,
+    "lockin_i32_lo_process": _CFG_LO_SIG,
+    "lockin_i32_biquad_lo_process": _STREAM_LO_SIG,
+    "lockin_f32_biquad_lo_process": _STREAM_LO_SIG,
     "lowpass_i32": _CFG_SIG,
     "fm_disc_i32": _CFG_SIG,
 }
@@ -205,6 +211,7 @@ HELPERS = {
     "hbf_dec_state_words": (_SZ, [_P]),
     "hbf_int_state_words": (_SZ, [_P]),
     "lockin_state_words": (_SZ, [_P]),
+    "lockin_biquad_state_words": (_SZ, [_SZ, _I]),
     "fir_sym_state_words": (_SZ, [_P]),
     "normal_from_sos": (_I, [_P, _P]),
     "wdf_quantize": (_I, [_I, C.c_uint32, _P, _P]),

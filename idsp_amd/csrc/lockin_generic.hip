@@ -1,0 +1,331 @@
+// lockin_generic.hip — `Lockin<C>` as the reference defines it (src/lockin.rs:11-39): arm filters other than `[Lowpass<N>; K]`
+// and the external-LO form `(x, Complex<U>) -> Complex<X>` (:17-27), on the one-thread-per-lane stream kernels of
+// lane_stream.h.  (The phase form with lowpass arms — the C4 configuration — has its own multi-wave kernels, lockin_waves.h.)
+//
+//   idsp_lockin_i32_biquad_process      phase form, arms `[Biquad<Q32<F>>; n]` x `[DirectForm1<i32>; n]`
+//   idsp_lockin_i32_lo_process          external LO, arms `[Lowpass<N>; K]`
+//   idsp_lockin_i32_biquad_lo_process   external LO, biquad arms (i32)
+//   idsp_lockin_f32_biquad_lo_process   external LO, `[Biquad<f32>; n]` arms: the mix -> lowpass graph of examples/ddc_lockin.rs
+//
+// External LO: the stream kernel carries the LO samples (8 bytes, like the 8-byte output); the 4-byte x sample of the
+// same (frame, lane) is read by the processor itself in its pre-stage (four frames ahead of the recurrence), through a
+// pointer that walks the lane's x samples.  The kernels split lanes only for 4-byte-in / 4-byte-out processors, so the
+// lane index a processor sees here is the caller's.
+#include "biquad_sections.h"
+#include "dds_dev.h"
+
+namespace idsp {
+namespace {
+
+typedef int32_t cplx_i32 __attribute__((ext_vector_type(2)));
+typedef float cplx_f32 __attribute__((ext_vector_type(2)));
+
+// n serial sections on one arm, state words at `word0` (section-major, {x0,x1,y0,y1} each)
+template <class Sec, int NS>
+struct Arm {
+    uint32_t s[NS][Sec::W];
+    __device__ __forceinline__ void load(const uint32_t *st, size_t lanes, size_t lane, int word0)
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+#pragma unroll
+            for (int w = 0; w < Sec::W; w++) s[k][w] = st[size_t(word0 + k * Sec::W + w) * lanes + lane];
+    }
+    __device__ __forceinline__ void store(uint32_t *st, size_t lanes, size_t lane, int word0) const
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+#pragma unroll
+            for (int w = 0; w < Sec::W; w++) st[size_t(word0 + k * Sec::W + w) * lanes + lane] = s[k][w];
+    }
+    template <class P>
+    __device__ __forceinline__ typename Sec::T step(const P &p, typename Sec::T x)
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++) x = Sec::step(p.sec[k], s[k], x);
+        return x;
+    }
+};
+
+// phase form, biquad arms (src/lockin.rs:30-39 -> :17-27)
+template <int NS>
+struct LockinBiquadProc {
+    using In = int32_t;
+    using Out = Cplx;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 1 << kCossinDepth;
+    static constexpr int IN_DIV = 1;
+    static constexpr int COST = 110 + 100 * NS;
+    using Params = bq::ChainParams<bq::SecI32, NS>;
+    const uint32_t *lut;
+    uint32_t acc, inc;
+    Arm<bq::Df1I32<false>, NS> bi, bqarm;
+    static __device__ __forceinline__ void fill_shared(uint32_t *sh, int tid, int n) { fill_cossin(sh, tid, n); }
+    __device__ __forceinline__ void set_shared(const uint32_t *sh) { lut = sh; }
+    __device__ __forceinline__ void load(const Params &, const uint32_t *st, size_t lanes, size_t lane)
+    {
+        acc = st[lane];
+        inc = st[lanes + lane];
+        bi.load(st, lanes, lane, 2);
+        bqarm.load(st, lanes, lane, 2 + 4 * NS);
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+        st[lane] = acc;
+        bi.store(st, lanes, lane, 2);
+        bqarm.store(st, lanes, lane, 2 + 4 * NS);
+    }
+    static constexpr int BATCH = 4;
+    using Pre = Cplx;
+    __device__ __forceinline__ Pre pre(const Params &)
+    {
+        acc += inc;
+        return cossin_dev(int32_t(acc), lut);
+    }
+    __device__ __forceinline__ Out step(const Params &p, In x, const Pre &lo)
+    {
+        return Cplx{bi.step(p, __mulhi(lo.re, x)), bqarm.step(p, __mulhi(lo.im, x))};
+    }
+};
+
+// where the x samples of the external-LO forms are, beside the kernel's own (LO) input stream
+struct XWalk {
+    const void *x;
+    uint32_t frame_major;
+    size_t frames;
+};
+
+// external LO, lowpass arms
+struct LpLoParams {
+    LpParams lp;
+    XWalk xw;
+};
+template <int N, int K>
+struct LockinLoProc {
+    using In = cplx_i32;
+    using Out = Cplx;
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 0;
+    static constexpr int IN_DIV = 1;
+    static constexpr int COST = 20 + 80 * N * K;
+    using Params = LpLoParams;
+    const int32_t *xp;
+    size_t xstride;
+    LpBank<N, K> bi, bq_;
+    __device__ __forceinline__ void load(const Params &p, const uint32_t *st, size_t lanes, size_t lane)
+    {
+        xp = static_cast<const int32_t *>(p.xw.x) + (p.xw.frame_major ? lane : lane * p.xw.frames);
+        xstride = p.xw.frame_major ? lanes : 1;
+        bi.load(st, lanes, lane, 0);
+        bq_.load(st, lanes, lane, 2 * N * K);
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+        bi.store(st, lanes, lane, 0);
+        bq_.store(st, lanes, lane, 2 * N * K);
+    }
+    static constexpr int BATCH = 4;
+    using Pre = int32_t;  // the x sample of the frame
+    __device__ __forceinline__ Pre pre(const Params &)
+    {
+        const int32_t v = *xp;
+        xp += xstride;
+        return v;
+    }
+    __device__ __forceinline__ Out step(const Params &p, In lo, const Pre &x)
+    {
+        return Cplx{bi.step(p.lp, __mulhi(lo.x, x)), bq_.step(p.lp, __mulhi(lo.y, x))};
+    }
+};
+
+// external LO, biquad arms; T = int32_t (Q32<32> LO) or float
+template <class Sec, int NS>
+struct BqLoParams {
+    typename Sec::Sec sec[NS];
+    XWalk xw;
+};
+template <class Sec, int NS>
+struct LockinBiquadLoProc {
+    using T = typename Sec::T;
+    typedef T In __attribute__((ext_vector_type(2)));
+    typedef T Out __attribute__((ext_vector_type(2)));
+    static constexpr bool HAS_IN = true;
+    static constexpr int LDS_WORDS = 0;
+    static constexpr int IN_DIV = 1;
+    static constexpr int COST = 20 + 2 * NS * Sec::COST;
+    using Params = BqLoParams<Sec, NS>;
+    const T *xp;
+    size_t xstride;
+    Arm<Sec, NS> bi, bq_;
+    __device__ __forceinline__ void load(const Params &p, const uint32_t *st, size_t lanes, size_t lane)
+    {
+        xp = static_cast<const T *>(p.xw.x) + (p.xw.frame_major ? lane : lane * p.xw.frames);
+        xstride = p.xw.frame_major ? lanes : 1;
+        bi.load(st, lanes, lane, 0);
+        bq_.load(st, lanes, lane, 4 * NS);
+    }
+    __device__ __forceinline__ void store(const Params &, uint32_t *st, size_t lanes, size_t lane)
+    {
+        bi.store(st, lanes, lane, 0);
+        bq_.store(st, lanes, lane, 4 * NS);
+    }
+    static constexpr int BATCH = 4;
+    using Pre = T;
+    __device__ __forceinline__ Pre pre(const Params &)
+    {
+        const T v = *xp;
+        xp += xstride;
+        return v;
+    }
+    static __device__ __forceinline__ int32_t mix(int32_t x, int32_t lo) { return __mulhi(lo, x); }
+    static __device__ __forceinline__ float mix(float x, float lo) { return x * lo; }
+    __device__ __forceinline__ Out step(const Params &p, In lo, const Pre &x)
+    {
+        return Out{bi.step(p, mix(x, lo.x)), bq_.step(p, mix(x, lo.y))};
+    }
+};
+
+bool sections_ok(const void *sections, size_t n) { return sections && n >= 1 && n <= IDSP_LOCKIN_MAX_SECTIONS; }
+
+template <int NS>
+void fill_i32(const idsp_biquad_i32 *sec, bq::SecI32 (&out)[NS])
+{
+    for (int k = 0; k < NS; k++) {
+        for (int i = 0; i < 5; i++) out[k].ba[i] = sec[k].ba[i];
+        out[k].frac = sec[k].frac;
+        out[k].u = 0, out[k].mn = INT32_MIN, out[k].mx = INT32_MAX;
+    }
+}
+template <int NS>
+void fill_f32(const idsp_biquad_f32 *sec, bq::SecF32 (&out)[NS])
+{
+    for (int k = 0; k < NS; k++) {
+        for (int i = 0; i < 5; i++) out[k].ba[i] = sec[k].ba[i];
+        out[k].u = 0.f, out[k].mn = -__builtin_inff(), out[k].mx = __builtin_inff();
+    }
+}
+
+int check_lo_args(const void *cfg, const void *state, const void *x, const void *lo, const void *y, size_t lanes, size_t frames, int layout)
+{
+    int rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (lanes && frames && !lo) return fail(IDSP_EINVAL, "lo is NULL");
+    return IDSP_OK;
+}
+
+template <int NS>
+int run_biquad_phase(const idsp_biquad_i32 *sec, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    typename LockinBiquadProc<NS>::Params p;
+    fill_i32<NS>(sec, p.sec);
+    return launch_stream<LockinBiquadProc<NS>>(p, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, s);
+}
+template <int NS>
+int run_biquad_lo_i32(const idsp_biquad_i32 *sec, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames,
+                      int layout, hipStream_t s)
+{
+    using P = LockinBiquadLoProc<bq::Df1I32<false>, NS>;
+    typename P::Params p;
+    fill_i32<NS>(sec, p.sec);
+    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, frames};
+    return launch_stream<P>(p, state, reinterpret_cast<const typename P::In *>(lo), reinterpret_cast<typename P::Out *>(y), lanes, frames, layout, s);
+}
+template <int NS>
+int run_biquad_lo_f32(const idsp_biquad_f32 *sec, void *state, const float *x, const float *lo, float *y, size_t lanes, size_t frames, int layout,
+                      hipStream_t s)
+{
+    using P = LockinBiquadLoProc<bq::Df1F32<false>, NS>;
+    typename P::Params p;
+    fill_f32<NS>(sec, p.sec);
+    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, frames};
+    return launch_stream<P>(p, state, reinterpret_cast<const typename P::In *>(lo), reinterpret_cast<typename P::Out *>(y), lanes, frames, layout, s);
+}
+
+}  // namespace
+}  // namespace idsp
+
+using namespace idsp;
+
+extern "C" {
+
+size_t idsp_lockin_biquad_state_words(size_t n, int with_accu)
+{
+    return n >= 1 && n <= IDSP_LOCKIN_MAX_SECTIONS ? size_t(with_accu ? 2 : 0) + 8 * n : 0;
+}
+
+#define IDSP_BY_SECTIONS(call)                                     \
+    switch (n) {                                                   \
+        case 1: return call(1);                                    \
+        case 2: return call(2);                                    \
+        case 3: return call(3);                                    \
+        default: return call(4);                                   \
+    }
+
+int idsp_lockin_i32_biquad_process(const idsp_biquad_i32 *sections, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes,
+                                   size_t frames, int layout, void *stream)
+{
+    if (!sections_ok(sections, n)) return fail(IDSP_EINVAL, "sections is NULL or n = %zu not in 1..%d", n, IDSP_LOCKIN_MAX_SECTIONS);
+    int rc = check_stream_args(sections, 1, state, x, y, lanes, frames, layout);
+    if (rc) return rc;
+    for (size_t k = 0; k < n; k++)
+        if (sections[k].frac < 0 || sections[k].frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, sections[k].frac);
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+#define IDSP_CALL(NS) run_biquad_phase<NS>(sections, state, x, y, lanes, frames, layout, as_stream(stream))
+    IDSP_BY_SECTIONS(IDSP_CALL)
+#undef IDSP_CALL
+}
+
+int idsp_lockin_i32_lo_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes,
+                               size_t frames, int layout, void *stream)
+{
+    if (!cfg || (cfg->order != 1 && cfg->order != 2) || cfg->cascade < 1 || cfg->cascade > IDSP_LOCKIN_MAX_CASCADE)
+        return fail(IDSP_EINVAL, "lock-in configuration: order 1..2, cascade 1..%d", IDSP_LOCKIN_MAX_CASCADE);
+    int rc = check_lo_args(cfg, state, x, lo, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+    LpLoParams p;
+    p.lp = lp_params(cfg);
+    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, frames};
+    const cplx_i32 *l2 = reinterpret_cast<const cplx_i32 *>(lo);
+    Cplx *y2 = reinterpret_cast<Cplx *>(y);
+#define IDSP_CASE(N, K) \
+    if (cfg->order == N && cfg->cascade == K) return launch_stream<LockinLoProc<N, K>>(p, state, l2, y2, lanes, frames, layout, as_stream(stream))
+    IDSP_CASE(1, 1);
+    IDSP_CASE(1, 2);
+    IDSP_CASE(1, 3);
+    IDSP_CASE(1, 4);
+    IDSP_CASE(2, 1);
+    IDSP_CASE(2, 2);
+    IDSP_CASE(2, 3);
+    IDSP_CASE(2, 4);
+#undef IDSP_CASE
+    return fail(IDSP_EINVAL, "unsupported lowpass configuration");
+}
+
+int idsp_lockin_i32_biquad_lo_process(const idsp_biquad_i32 *sections, size_t n, void *state, const int32_t *x, const int32_t *lo, int32_t *y,
+                                      size_t lanes, size_t frames, int layout, void *stream)
+{
+    if (!sections_ok(sections, n)) return fail(IDSP_EINVAL, "sections is NULL or n = %zu not in 1..%d", n, IDSP_LOCKIN_MAX_SECTIONS);
+    int rc = check_lo_args(sections, state, x, lo, y, lanes, frames, layout);
+    if (rc) return rc;
+    for (size_t k = 0; k < n; k++)
+        if (sections[k].frac < 0 || sections[k].frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, sections[k].frac);
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+#define IDSP_CALL(NS) run_biquad_lo_i32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream))
+    IDSP_BY_SECTIONS(IDSP_CALL)
+#undef IDSP_CALL
+}
+
+int idsp_lockin_f32_biquad_lo_process(const idsp_biquad_f32 *sections, size_t n, void *state, const float *x, const float *lo, float *y,
+                                      size_t lanes, size_t frames, int layout, void *stream)
+{
+    if (!sections_ok(sections, n)) return fail(IDSP_EINVAL, "sections is NULL or n = %zu not in 1..%d", n, IDSP_LOCKIN_MAX_SECTIONS);
+    int rc = check_lo_args(sections, state, x, lo, y, lanes, frames, layout);
+    if (rc) return rc;
+    if (lanes == 0 || frames == 0) return IDSP_OK;
+#define IDSP_CALL(NS) run_biquad_lo_f32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream))
+    IDSP_BY_SECTIONS(IDSP_CALL)
+#undef IDSP_CALL
+}
+
+}  // extern "C"

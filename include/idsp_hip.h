@@ -707,6 +707,29 @@ int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *
 int idsp_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x,
                              int64_t *y, size_t lanes, size_t frames, int layout, void *stream);
 
+/* ---- `Lockin<C>` as the reference defines it (src/lockin.rs:11-39): any arm filter `C: SplitProcess<X, X, S>`, the LO
+ * either from a phase (:30-39, the entries above and idsp_lockin_i32_biquad_process) or given per sample (:17-27, the `_lo`
+ * entries).  Arm filters here: `[Lowpass<N>; K]` (idsp_lockin_i32 above) and `[Biquad<C>; n]` x `[DirectForm1<T>; n]`
+ * (src/iir/biquad.rs:366-383 under the array composition of dsp-process/src/compose.rs:80-113; n = 1 is a plain
+ * `Biquad<C>`), 1 <= n <= IDSP_LOCKIN_MAX_SECTIONS; the same sections run on I (`state[0]`) and on Q (`state[1]`).
+ * External LO: lo[index(f,l)*2 + {0: re, 1: im}] holds `Complex<Q32<32>>` bits (i32) or `Complex<f32>`; the mixer is
+ * `x * lo.re`, `x * lo.im` — for i32 `((q as i64 * x as i64) >> 32) as i32` (dsp-fixedpoint/src/lib.rs:449-456), for f32 one
+ * rounded multiply — and the output `Complex<X>` = [re, im] adjacent as above.  x, lo and y are three separate buffers.
+ * The f32 entry with lo = (cos, -sin) is the `mix * lowpass.lanes()` graph of examples/ddc_lockin.rs:35-42.
+ * State words per lane: phase form { accu.state, accu.step, I: n x {x0,x1,y0,y1}, Q: n x {x0,x1,y0,y1} };
+ * `_lo` forms: the two arms only — biquad arms { I: n x {x0,x1,y0,y1}, Q: ... }, lowpass arms the words of
+ * idsp_lockin_state_words() without its first two (idsp_lockin_state_words(cfg) - 2). */
+#define IDSP_LOCKIN_MAX_SECTIONS 4
+size_t idsp_lockin_biquad_state_words(size_t n, int with_accu);
+int idsp_lockin_i32_biquad_process(const idsp_biquad_i32 *sections, size_t n, void *state, const int32_t *x, int32_t *y,
+                                   size_t lanes, size_t frames, int layout, void *stream);
+int idsp_lockin_i32_lo_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y,
+                               size_t lanes, size_t frames, int layout, void *stream);
+int idsp_lockin_i32_biquad_lo_process(const idsp_biquad_i32 *sections, size_t n, void *state, const int32_t *x,
+                                      const int32_t *lo, int32_t *y, size_t lanes, size_t frames, int layout, void *stream);
+int idsp_lockin_f32_biquad_lo_process(const idsp_biquad_f32 *sections, size_t n, void *state, const float *x,
+                                      const float *lo, float *y, size_t lanes, size_t frames, int layout, void *stream);
+
 /* `Lowpass<N>` cascade alone on a real stream (src/lowpass.rs:47-78; array
  * composition dsp-process/src/compose.rs:80-113).  State: `[LowpassState<N>; K]`
  * words ((c*N + j)*2 + {lo,hi}). */

@@ -1508,6 +1508,142 @@ int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const i
     return lockin_run(cfg, state, x, y, lanes, frames, layout, LOCKIN_IQ);
 }
 
+/* ---- `Lockin<C>` as the reference defines it (src/lockin.rs:16-39): any arm filter C, the LO from a phase or given ----
+ * Arms below: C = `[Biquad<Q32<F>>; n]` x `[DirectForm1<i32>; n]` (src/iir/biquad.rs:366-383, array composition
+ * dsp-process/src/compose.rs:80-113, sample-major), n = 1 being a plain `Biquad<Q32<F>>`; and `[Biquad<f32>; n]` for the
+ * f32 graph of examples/ddc_lockin.rs:35-42.  The same n sections run on I (state[0]) and on Q (state[1]).
+ * External LO (src/lockin.rs:17-27): `Complex::new(C(state[0], x * lo.re), C(state[1], x * lo.im))`; `i32 * Q32<32>` =
+ * ((q as i64 * x as i64) >> 32) as i32 (dsp-fixedpoint/src/lib.rs:449-456), `f32 * f32` one rounded multiply. */
+static int biquad_arms_ok(const void *sections, size_t n, const void *state, const void *x, const void *y, size_t lanes,
+                          size_t frames, int layout)
+{
+    if (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR) return 0;
+    if (!sections || n < 1 || n > IDSP_LOCKIN_MAX_SECTIONS) return 0;
+    if (lanes && (!state || (frames && (!x || !y)))) return 0;
+    return 1;
+}
+
+size_t idsp_ref_lockin_biquad_state_words(size_t n, int with_accu)
+{
+    return n >= 1 && n <= IDSP_LOCKIN_MAX_SECTIONS ? (size_t)(with_accu ? 2 : 0) + 8 * n : 0;
+}
+
+/* phase form (src/lockin.rs:30-39) with biquad arms; state words { accu.state, accu.step, I: n x {x0,x1,y0,y1}, Q: n x {..} } */
+int idsp_ref_lockin_i32_biquad_process(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, int32_t *y,
+                                       size_t lanes, size_t frames, int layout)
+{
+    if (!biquad_arms_ok(sec, n, state, x, y, lanes, frames, layout)) return IDSP_EINVAL;
+    for (size_t k = 0; k < n; k++)
+        if (sec[k].frac < 0 || sec[k].frac > 31) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        uint32_t acc = st[l], step = st[lanes + l];
+        uint32_t s[2][IDSP_LOCKIN_MAX_SECTIONS][4];
+        for (int q = 0; q < 2; q++)
+            for (size_t k = 0; k < n; k++)
+                for (int w = 0; w < 4; w++) s[q][k][w] = st[(2 + (q * n + k) * 4 + w) * lanes + l];
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            acc += step;
+            int32_t c, sn;
+            idsp_ref_cossin((int32_t)acc, &c, &sn);
+            int32_t v[2] = {trunc32(mul_wide(c, x[i]) >> 32), trunc32(mul_wide(sn, x[i]) >> 32)};
+            for (int q = 0; q < 2; q++) {
+                for (size_t k = 0; k < n; k++) v[q] = df1_i32(sec[k].ba, sec[k].frac, s[q][k], v[q]);
+                y[2 * i + q] = v[q];
+            }
+        }
+        st[l] = acc;
+        for (int q = 0; q < 2; q++)
+            for (size_t k = 0; k < n; k++)
+                for (int w = 0; w < 4; w++) st[(2 + (q * n + k) * 4 + w) * lanes + l] = s[q][k][w];
+    }
+    return IDSP_OK;
+}
+
+/* external LO, `[Lowpass<N>; K]` arms; state words = those of idsp_lockin_state_words WITHOUT the two accumulator words */
+int idsp_ref_lockin_i32_lo_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y,
+                                   size_t lanes, size_t frames, int layout)
+{
+    if (!lockin_cfg_ok(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !lo || !y)))) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    int ns = cfg->cascade * cfg->order;
+    for (size_t l = 0; l < lanes; l++) {
+        int64_t s[2][IDSP_LOCKIN_MAX_CASCADE * 2];
+        for (int q = 0; q < 2; q++)
+            for (int j = 0; j < ns; j++) {
+                size_t w = (size_t)((q * ns + j) * 2);
+                s[q][j] = (int64_t)(((uint64_t)st[(w + 1) * lanes + l] << 32) | st[w * lanes + l]);
+            }
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            for (int q = 0; q < 2; q++) y[2 * i + q] = lowpass_cascade(cfg, s[q], trunc32(mul_wide(lo[2 * i + q], x[i]) >> 32));
+        }
+        for (int q = 0; q < 2; q++)
+            for (int j = 0; j < ns; j++) {
+                size_t w = (size_t)((q * ns + j) * 2);
+                st[w * lanes + l] = (uint32_t)(uint64_t)s[q][j];
+                st[(w + 1) * lanes + l] = (uint32_t)((uint64_t)s[q][j] >> 32);
+            }
+    }
+    return IDSP_OK;
+}
+
+/* external LO, biquad arms (i32); state words { I: n x {x0,x1,y0,y1}, Q: n x {..} } */
+int idsp_ref_lockin_i32_biquad_lo_process(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, const int32_t *lo,
+                                          int32_t *y, size_t lanes, size_t frames, int layout)
+{
+    if (!biquad_arms_ok(sec, n, state, x, y, lanes, frames, layout) || (lanes && frames && !lo)) return IDSP_EINVAL;
+    for (size_t k = 0; k < n; k++)
+        if (sec[k].frac < 0 || sec[k].frac > 31) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        uint32_t s[2][IDSP_LOCKIN_MAX_SECTIONS][4];
+        for (int q = 0; q < 2; q++)
+            for (size_t k = 0; k < n; k++)
+                for (int w = 0; w < 4; w++) s[q][k][w] = st[((q * n + k) * 4 + w) * lanes + l];
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            for (int q = 0; q < 2; q++) {
+                int32_t v = trunc32(mul_wide(lo[2 * i + q], x[i]) >> 32);
+                for (size_t k = 0; k < n; k++) v = df1_i32(sec[k].ba, sec[k].frac, s[q][k], v);
+                y[2 * i + q] = v;
+            }
+        }
+        for (int q = 0; q < 2; q++)
+            for (size_t k = 0; k < n; k++)
+                for (int w = 0; w < 4; w++) st[((q * n + k) * 4 + w) * lanes + l] = s[q][k][w];
+    }
+    return IDSP_OK;
+}
+
+/* external LO, `Biquad<f32>` arms: the `mix * lowpass.lanes()` graph of examples/ddc_lockin.rs:35-42 with lo = (cos, -sin) */
+int idsp_ref_lockin_f32_biquad_lo_process(const idsp_biquad_f32 *sec, size_t n, void *state, const float *x, const float *lo,
+                                          float *y, size_t lanes, size_t frames, int layout)
+{
+    if (!biquad_arms_ok(sec, n, state, x, y, lanes, frames, layout) || (lanes && frames && !lo)) return IDSP_EINVAL;
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        uint32_t s[2][IDSP_LOCKIN_MAX_SECTIONS][4];
+        for (int q = 0; q < 2; q++)
+            for (size_t k = 0; k < n; k++)
+                for (int w = 0; w < 4; w++) s[q][k][w] = st[((q * n + k) * 4 + w) * lanes + l];
+        for (size_t f = 0; f < frames; f++) {
+            size_t i = idx_of(f, l, lanes, frames, layout);
+            for (int q = 0; q < 2; q++) {
+                float v = x[i] * lo[2 * i + q];
+                for (size_t k = 0; k < n; k++) v = df1_f32(sec[k].ba, s[q][k], v);
+                y[2 * i + q] = v;
+            }
+        }
+        for (int q = 0; q < 2; q++)
+            for (size_t k = 0; k < n; k++)
+                for (int w = 0; w < 4; w++) st[((q * n + k) * 4 + w) * lanes + l] = s[q][k][w];
+    }
+    return IDSP_OK;
+}
+
 /* `Lockin::process(..).arg()` (src/lockin.rs:30-39, src/complex.rs:254-256) */
 int idsp_ref_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
                             size_t lanes, size_t frames, int layout)

@@ -146,6 +146,15 @@ int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int
 size_t idsp_ref_lockin_state_words(const idsp_lockin_i32 *cfg);
 int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x,
                                 int32_t *y, size_t lanes, size_t frames, int layout);
+size_t idsp_ref_lockin_biquad_state_words(size_t n, int with_accu);
+int idsp_ref_lockin_i32_biquad_process(const idsp_biquad_i32 *sections, size_t n, void *state, const int32_t *x, int32_t *y,
+                                       size_t lanes, size_t frames, int layout);
+int idsp_ref_lockin_i32_lo_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y,
+                                   size_t lanes, size_t frames, int layout);
+int idsp_ref_lockin_i32_biquad_lo_process(const idsp_biquad_i32 *sections, size_t n, void *state, const int32_t *x,
+                                          const int32_t *lo, int32_t *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_lockin_f32_biquad_lo_process(const idsp_biquad_f32 *sections, size_t n, void *state, const float *x,
+                                          const float *lo, float *y, size_t lanes, size_t frames, int layout);
 int idsp_ref_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y,
                             size_t lanes, size_t frames, int layout);
 int idsp_ref_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y,

@@ -803,3 +803,34 @@ def lockin(ks, states_iq: List[List[list]], x: int, phase: int) -> Tuple[int, in
     xi = i32((c * x) >> 32)
     xq = i32((s * x) >> 32)
     return lowpass_cascade(ks, states_iq[0], xi), lowpass_cascade(ks, states_iq[1], xq)
+
+
+def lockin_lo(arm, states_iq, x, lo):
+    """`Lockin<C>` on (sample, LO) (src/lockin.rs:17-27): `Complex::new(C(state[0], x * lo.re), C(state[1], x * lo.im))`.
+    `arm(state, v)` is the arm filter C; for i32 samples `x * Q32<32>` = ((q as i64 * x as i64) >> 32) as i32
+    (dsp-fixedpoint/src/lib.rs:449-456), for f32 one rounded multiply."""
+    if isinstance(x, (int, np.integer)):
+        mix = [i32((int(lo[0]) * int(x)) >> 32), i32((int(lo[1]) * int(x)) >> 32)]
+    else:
+        mix = [f32(x) * f32(lo[0]), f32(x) * f32(lo[1])]
+    return arm(states_iq[0], mix[0]), arm(states_iq[1], mix[1])
+
+
+def lockin_phase(arm, states_iq, x: int, phase: int):
+    """`Lockin<C>` on (sample, phase) for any arm filter (src/lockin.rs:30-39): LO = `Complex::<i32>::from_angle(phase)` read
+    as `Complex<Q32<32>>` bits."""
+    return lockin_lo(arm, states_iq, x, cossin(phase))
+
+
+def biquad_chain_i32(sections, states: List[DirectForm1], x0: int) -> int:
+    """`[Biquad<Q32<F>>; n]` x `[DirectForm1<i32>; n]`, sample-major (dsp-process/src/compose.rs:84-93); sections = [(ba, frac)]."""
+    for (ba, frac), st in zip(sections, states):
+        x0 = biquad_i32_df1(ba, frac, st, x0)
+    return x0
+
+
+def biquad_chain_f32(sections, states: List[DirectForm1], x0):
+    """`[Biquad<f32>; n]` x `[DirectForm1<f32>; n]`; sections = [ba]."""
+    for ba, st in zip(sections, states):
+        x0 = biquad_f32_df1(ba, st, x0)
+    return x0

@@ -481,6 +481,89 @@ impl<const N: usize, const K: usize> GpuKernel<LockinState<N, K>> for Lockin<[Lo
     }
 }
 
+/// Lock-in state with biquad arms: `{ accu.state, accu.step }` followed by `[[DirectForm1<i32>; NS]; 2]` (index 0 = I,
+/// 1 = Q), four words each — include/idsp_hip.h, `idsp_lockin_biquad_state_words(NS, 1)`.
+#[derive(Clone, Debug)]
+pub struct LockinBiquadState<const NS: usize> {
+    pub phase: i32,
+    pub step: i32,
+    pub iq: [[DirectForm1<i32>; NS]; 2],
+}
+impl<const NS: usize> StateRecord for LockinBiquadState<NS> {
+    const WORDS: usize = 2 + 8 * NS;
+    fn to_words(&self, w: &mut [u32]) {
+        w[0] = self.phase as u32;
+        w[1] = self.step as u32;
+        for (q, arm) in self.iq.iter().enumerate() {
+            for (k, st) in arm.iter().enumerate() {
+                st.to_words(&mut w[2 + (q * NS + k) * 4..][..4]);
+            }
+        }
+    }
+    fn from_words(w: &[u32]) -> Self {
+        let iq = core::array::from_fn(|q| core::array::from_fn(|k| DirectForm1::<i32>::from_words(&w[2 + (q * NS + k) * 4..][..4])));
+        Self { phase: w[0] as i32, step: w[1] as i32, iq }
+    }
+}
+
+/// `Lockin<[Biquad<Q32<F>>; NS]>` (any arm filter `C: SplitProcess<i32, i32, S>`, src/lockin.rs:16-39) fed by a per-lane
+/// phase accumulator: the same `NS` DF1 sections on I and on Q.  `Lockin<Biquad<Q32<F>>>` is `NS = 1`.
+impl<const F: i8, const NS: usize> GpuKernel<LockinBiquadState<NS>> for Lockin<[Biquad<Q32<F>>; NS]> {
+    type In = i32;
+    type Out = Complex<i32>;
+    unsafe fn launch(&self, state: *mut c_void, x: *const i32, y: *mut Complex<i32>, lanes: usize, frames: usize, layout: c_int, stream: Stream) -> c_int {
+        let sec: [sys::IdspBiquadI32; NS] = core::array::from_fn(|k| cfg_i32(&self.0[k]));
+        // SAFETY: Complex<i32> is repr(transparent) over [i32; 2]; `sec` outlives the call (the library copies it into the launch).
+        unsafe { sys::idsp_lockin_i32_biquad_process(sec.as_ptr(), NS, state, x, y.cast(), lanes, frames, layout, stream.0) }
+    }
+}
+
+/// External-LO form `(x, Complex<U>) -> Complex<X>` (src/lockin.rs:17-27): two input buffers, so it is a method rather
+/// than a `GpuKernel`.  `Lockin<[Biquad<f32>; NS]>` with lo = (cos, -sin) is the graph of examples/ddc_lockin.rs:35-42.
+pub trait GpuLockinLo<S> {
+    type X: Copy;
+    type U: Copy;
+    /// # Safety
+    /// `state` holds `lanes` records of `[S; 2]` in the library's plane layout; x, lo and y are device buffers of
+    /// lanes * frames (x) and lanes * frames pairs (lo, y) in `layout`.
+    unsafe fn launch_lo(&self, state: *mut c_void, x: *const Self::X, lo: *const Complex<Self::U>, y: *mut Complex<Self::X>, lanes: usize,
+                        frames: usize, layout: c_int, stream: Stream) -> c_int;
+}
+impl<const N: usize, const K: usize> GpuLockinLo<[LowpassState<N>; K]> for Lockin<[Lowpass<N>; K]> {
+    type X = i32;
+    type U = Q32<32>;
+    unsafe fn launch_lo(&self, state: *mut c_void, x: *const i32, lo: *const Complex<Q32<32>>, y: *mut Complex<i32>, lanes: usize, frames: usize,
+                        layout: c_int, stream: Stream) -> c_int {
+        let mut k = [[0i32; 2]; sys::IDSP_LOCKIN_MAX_CASCADE];
+        for (c, lp) in self.0.iter().enumerate() {
+            k[c][..N].copy_from_slice(&lp.0);
+        }
+        let cfg = sys::IdspLockinI32 { order: N as i32, cascade: K as i32, k };
+        // SAFETY: Q32 and Complex are repr(transparent): Complex<Q32<32>> is [i32; 2].
+        unsafe { sys::idsp_lockin_i32_lo_process(&cfg, state, x, lo.cast(), y.cast(), lanes, frames, layout, stream.0) }
+    }
+}
+impl<const F: i8, const NS: usize> GpuLockinLo<[DirectForm1<i32>; NS]> for Lockin<[Biquad<Q32<F>>; NS]> {
+    type X = i32;
+    type U = Q32<32>;
+    unsafe fn launch_lo(&self, state: *mut c_void, x: *const i32, lo: *const Complex<Q32<32>>, y: *mut Complex<i32>, lanes: usize, frames: usize,
+                        layout: c_int, stream: Stream) -> c_int {
+        let sec: [sys::IdspBiquadI32; NS] = core::array::from_fn(|k| cfg_i32(&self.0[k]));
+        // SAFETY: as above.
+        unsafe { sys::idsp_lockin_i32_biquad_lo_process(sec.as_ptr(), NS, state, x, lo.cast(), y.cast(), lanes, frames, layout, stream.0) }
+    }
+}
+impl<const NS: usize> GpuLockinLo<[DirectForm1<f32>; NS]> for Lockin<[Biquad<f32>; NS]> {
+    type X = f32;
+    type U = f32;
+    unsafe fn launch_lo(&self, state: *mut c_void, x: *const f32, lo: *const Complex<f32>, y: *mut Complex<f32>, lanes: usize, frames: usize,
+                        layout: c_int, stream: Stream) -> c_int {
+        let sec: [sys::IdspBiquadF32; NS] = core::array::from_fn(|k| sys::IdspBiquadF32 { ba: self.0[k].ba });
+        // SAFETY: as above.
+        unsafe { sys::idsp_lockin_f32_biquad_lo_process(sec.as_ptr(), NS, state, x, lo.cast(), y.cast(), lanes, frames, layout, stream.0) }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- lanes
 /// GPU-side `Lanes<C>` (dsp-process/src/compose.rs:449-513): one configuration shared by all lanes.
 #[derive(Clone, Copy, Debug, Default)]

@@ -17,6 +17,7 @@ import glob
 import os
 import re
 import shutil
+import struct
 import subprocess
 import sys
 import tempfile
@@ -38,8 +39,26 @@ def kernels_of(lib: str):
     try:
         local = os.path.join(tmp, "lib.so")
         shutil.copy(lib, local)
-        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, stdout=subprocess.DEVNULL,
-                       stderr=subprocess.DEVNULL, cwd=tmp)
+        # The library is linked with --offload-compress: .hip_fatbin holds one compressed bundle ("CCOB", version 3: magic,
+        # u16 version, u16 method, u64 file size, u64 uncompressed size, u64 hash; bundles are padded to 4 KiB) per translation
+        # unit.  Cut them apart and let clang-offload-bundler unpack the gfx950 code object of each.
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", local, fat], check=True)
+        data = open(fat, "rb").read()
+        pos, n = data.find(b"CCOB"), 0
+        if pos < 0:  # not compressed: the plain route
+            subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, cwd=tmp)
+        while pos >= 0:
+            size = struct.unpack("<Q", data[pos + 8:pos + 16])[0]
+            piece = os.path.join(tmp, f"bundle{n}.bin")
+            with open(piece, "wb") as fh:
+                fh.write(data[pos:pos + size])
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={piece}",
+                            f"--output={os.path.join(tmp, f'lib.so.{n}.gfx950')}"], check=True, capture_output=True)
+            n += 1
+            pos = data.find(b"CCOB", pos + size)
         out = []
         for co in sorted(glob.glob(os.path.join(tmp, "lib.so.*gfx950"))):
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
