@@ -153,6 +153,9 @@ struct LockinBiquadLoProc {
     static constexpr int LDS_WORDS = 0;
     static constexpr int IN_DIV = 1;
     static constexpr int COST = 20 + 2 * NS * Sec::COST;
+    // 2 x NS sections of state beside a deep register window or the staged kernel's staging registers spill (tools/check_scratch.py)
+    static constexpr int MAX_U = NS >= 3 ? 8 : 24;
+    static constexpr bool LM_STAGED = NS <= 2;
     using Params = BqLoParams<Sec, NS>;
     const T *xp;
     size_t xstride;
