@@ -24,6 +24,7 @@ MAX_SECTIONS = 64
 HBF_MAX_STAGES = 5
 HBF_MAX_TAPS = 32
 LOCKIN_MAX_CASCADE = 4
+LOCKIN_MAX_SECTIONS = 4
 
 
 class BiquadI32(C.Structure):
@@ -60,6 +61,18 @@ class HbfCascadeF32(C.Structure):
 
 class FirSymF32(C.Structure):
     _fields_ = [("kind", C.c_int32), ("m", C.c_int32), ("taps", C.c_float * HBF_MAX_TAPS)]
+
+
+class HbfCascadeF64(C.Structure):
+    _fields_ = [
+        ("stages", C.c_int32),
+        ("m", C.c_int32 * HBF_MAX_STAGES),
+        ("taps", (C.c_double * HBF_MAX_TAPS) * HBF_MAX_STAGES),
+    ]
+
+
+class FirSymF64(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("m", C.c_int32), ("taps", C.c_double * HBF_MAX_TAPS)]
 
 
 class LockinI32(C.Structure):
@@ -166,6 +179,9 @@ PROCESSING = {
     "hbf_dec_f32": _CFG_SIG,
     "hbf_int_f32": _CFG_SIG,
     "fir_sym_f32_process": _CFG_SIG,
+    "hbf_dec_f64": _CFG_SIG,
+    "hbf_int_f64": _CFG_SIG,
+    "fir_sym_f64_process": _CFG_SIG,
     "normal_i32_df1": _STREAM_SIG,
     "normal_f32_df1": _STREAM_SIG,
     "normal_f64_df1": _STREAM_SIG,
@@ -213,6 +229,11 @@ HELPERS = {
     "lockin_state_words": (_SZ, [_P]),
     "lockin_biquad_state_words": (_SZ, [_SZ, _I]),
     "fir_sym_state_words": (_SZ, [_P]),
+    "hbf_dec_cascade_f64": (_I, [_I, _I, _P]),
+    "hbf_int_cascade_f64": (_I, [_I, _I, _P]),
+    "hbf_dec_state_words_f64": (_SZ, [_P]),
+    "hbf_int_state_words_f64": (_SZ, [_P]),
+    "fir_sym_state_words_f64": (_SZ, [_P]),
     "normal_from_sos": (_I, [_P, _P]),
     "wdf_quantize": (_I, [_I, C.c_uint32, _P, _P]),
     "wdf_state_words": (_SZ, [_P, _SZ]),

@@ -19,6 +19,7 @@ own:
                                                          .process_view(View(...), ViewMut(...))
     HBF_DEC_CASCADE / HbfDec16 ...       (hbf.rs:363-421) HbfDecCascade(stages).lanes(N)
     Lockin<[Lowpass<N>; K]>, Accu        (lockin.rs, accu.rs) Lockin([...]).lanes(N, step=...)
+    Lockin<C> biquad arms / external LO  (lockin.rs:16-27)    Lockin([Biquad...]), LockinLo(arms, N).process(x, lo, y)
     Split::stateful(Cic::new(rate)).decimate() (cic.rs:338) Cic(N, rate).decimate().lanes(n)
     cossin(phase)                        (cossin.rs:14)  cossin(phases)
     atan2(y, x) / Complex::arg           (atan2.rs:66)   atan2(xy)
@@ -43,7 +44,7 @@ __all__ = [
     "FrameMajor", "LaneMajor", "View", "ViewMut", "Biquad", "BiquadClamp", "Cascade",
     "DirectForm1", "DirectForm2Transposed", "DirectForm1Wide", "DirectForm1Dither", "DirectForm",
     "Split", "Lanes", "ByLane", "HbfDecCascade", "HbfIntCascade", "FirSym", "Cic", "Normal", "Wdf", "HBF_TAPS", "HBF_TAPS_98",
-    "Lowpass", "Lockin", "Accu", "Dds", "FmDisc", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
+    "Lowpass", "Lockin", "LockinLo", "Accu", "Dds", "FmDisc", "cossin", "atan2", "sos", "sos_clamp_wide", "IdspError",
 ]
 
 FrameMajor = _abi.FRAME_MAJOR  # dsp-process/src/view.rs:10
@@ -758,22 +759,77 @@ class Lockin(_LaneOp):
     _OUTPUTS = {"iq": ("lockin_i32_process", 2, torch.int32), "arg": ("lockin_i32_arg", 1, torch.int32),
                 "norm_sqr": ("lockin_i32_norm_sqr", 1, torch.int64)}
 
-    def __init__(self, lowpasses: Sequence[Lowpass], output: str = "iq"):
+    def __init__(self, arms: Sequence, output: str = "iq"):
+        """`arms`: `[Lowpass<N>; K]`, or — `Lockin<C>` takes any arm filter (src/lockin.rs:16-27) — 1..4 fixed-point
+        `Biquad`s (`[Biquad<Q32<F>>; n]` x `[DirectForm1<i32>; n]`, the same sections on I and Q; `output="iq"` only)."""
         if output not in self._OUTPUTS:
             raise ValueError(f"output must be one of {sorted(self._OUTPUTS)}")
-        self.cfg = _lockin_cfg(lowpasses)
+        self.biquads = None
+        if arms and isinstance(arms[0], Biquad):
+            if output != "iq" or not all(b.is_fixed for b in arms) or not 1 <= len(arms) <= _abi.LOCKIN_MAX_SECTIONS:
+                raise ValueError("biquad arms: 1..4 Biquad<Q32<F>> sections, output 'iq'")
+            self.biquads = (_abi.BiquadI32 * len(arms))()
+            for rec, b in zip(self.biquads, arms):
+                rec.ba[:] = b.ba
+                rec.frac = b.frac
+            self._entry, self.out_width, self.dtype_out = "lockin_i32_biquad_process", 2, torch.int32
+            return
+        self.cfg = _lockin_cfg(arms)
         self._entry, self.out_width, self.dtype_out = self._OUTPUTS[output]
 
     def lanes(self, n: int, step, state=0, device="cuda") -> "Lockin":
-        words = call("lockin_state_words", C.byref(self.cfg))
+        words = (call("lockin_biquad_state_words", len(self.biquads), 1) if self.biquads is not None
+                 else call("lockin_state_words", C.byref(self.cfg)))
         _LaneOp.__init__(self, n, words, device)
         self.state[0] = _to_i32_tensor(state, n, self.device)
         self.state[1] = _to_i32_tensor(step, n, self.device)
         return self
 
     def _run(self, x, y, frames, layout):
+        if self.biquads is not None:
+            call(self._entry, C.cast(self.biquads, C.c_void_p), len(self.biquads), C.c_void_p(self.state.data_ptr()),
+                 C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
+            return
         call(self._entry, C.byref(self.cfg), C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()),
              C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
+
+
+class LockinLo:
+    """`Lockin<C>` on `(x, Complex<U>)` (src/lockin.rs:17-27): the LO is an input, not a phase.  Arms: `[Lowpass<N>; K]`,
+    1..4 `Biquad<Q32<F>>` (x: i32, lo: `Complex<Q32<32>>` bits) or 1..4 `Biquad<f32>` (x, lo: f32 — with lo = (cos, -sin) the
+    `mix * lowpass.lanes()` graph of examples/ddc_lockin.rs:35-42).  State: `[S; 2]` per lane, zero = `Default`."""
+
+    def __init__(self, arms: Sequence, n_lanes: int, device="cuda"):
+        load()
+        self.n_lanes, self.device = int(n_lanes), torch.device(device)
+        if arms and isinstance(arms[0], Biquad):
+            if not 1 <= len(arms) <= _abi.LOCKIN_MAX_SECTIONS or any(b.f64 or b.is_fixed != arms[0].is_fixed for b in arms):
+                raise ValueError("1..4 Biquad sections, all Q32<F> or all f32")
+            fixed = arms[0].is_fixed
+            self.cfg = ((_abi.BiquadI32 if fixed else _abi.BiquadF32) * len(arms))()
+            for rec, b in zip(self.cfg, arms):
+                rec.ba[:] = b.ba
+                if fixed:
+                    rec.frac = b.frac
+            self.n, self.dtype = len(arms), torch.int32 if fixed else torch.float32
+            self._entry = "lockin_i32_biquad_lo_process" if fixed else "lockin_f32_biquad_lo_process"
+            words = call("lockin_biquad_state_words", self.n, 0)
+        else:
+            self.cfg, self.n, self.dtype, self._entry = _lockin_cfg(arms), None, torch.int32, "lockin_i32_lo_process"
+            words = call("lockin_state_words", C.byref(self.cfg)) - 2
+        self.state = torch.zeros((words, self.n_lanes), dtype=torch.int32, device=self.device)
+
+    def process(self, x: torch.Tensor, lo: torch.Tensor, y: torch.Tensor, layout: int = FrameMajor):
+        """x[frames, lanes] (FrameMajor) or [lanes, frames]; lo and y carry a trailing [re, im] pair per sample."""
+        for t, what in ((x, "x"), (lo, "lo"), (y, "y")):
+            _check(t, self.dtype, what)
+        if x.numel() % max(self.n_lanes, 1) or lo.numel() != 2 * x.numel() or y.numel() != 2 * x.numel():
+            raise ValueError("x.len() != lo.len() != y.len()")
+        frames = x.numel() // self.n_lanes if self.n_lanes else 0
+        head = (C.byref(self.cfg),) if self.n is None else (C.cast(self.cfg, C.c_void_p), self.n)
+        call(self._entry, *head, C.c_void_p(self.state.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(lo.data_ptr()),
+             C.c_void_p(y.data_ptr()), self.n_lanes, frames, layout, _stream_ptr(x))
+        return y
 
 
 class Dds:

@@ -651,6 +651,33 @@ size_t idsp_fir_sym_state_words(const idsp_fir_sym_f32 *cfg);
 int idsp_fir_sym_f32_process(const idsp_fir_sym_f32 *cfg, void *state, const float *x, float *y,
                              size_t lanes, size_t frames, int layout, void *stream);
 
+/* The same three processors on f64 samples with f64 taps: `EvenSymmetric<[C; M]>` and the `type_fir!` types are generic in
+ * the sample type (src/hbf.rs:70-138, `T: Mul<C, Output = T>`), so `HbfDec<[f64; N]>` / `HbfInt<[f64; N]>` cascades run
+ * with `[f64; M]` taps.  Same definitions as the f32 entries above; every f64 state value takes two state words
+ * (value v -> words 2v: low half, 2v + 1: high half), so the `_f64` word counts are twice the f32 ones.  The cascade
+ * builders widen the built-in f32 tap sets exactly (an f32 is an f64). */
+typedef struct idsp_hbf_cascade_f64 {
+    int32_t stages;
+    int32_t m[IDSP_HBF_MAX_STAGES];
+    double taps[IDSP_HBF_MAX_STAGES][IDSP_HBF_MAX_TAPS];
+} idsp_hbf_cascade_f64;
+typedef struct idsp_fir_sym_f64 {
+    int32_t kind; /* idsp_fir_kind */
+    int32_t m;
+    double taps[IDSP_HBF_MAX_TAPS];
+} idsp_fir_sym_f64;
+int idsp_hbf_dec_cascade_f64(int tap_set, int stages, idsp_hbf_cascade_f64 *out);
+int idsp_hbf_int_cascade_f64(int tap_set, int stages, idsp_hbf_cascade_f64 *out);
+size_t idsp_hbf_dec_state_words_f64(const idsp_hbf_cascade_f64 *cfg);
+size_t idsp_hbf_int_state_words_f64(const idsp_hbf_cascade_f64 *cfg);
+size_t idsp_fir_sym_state_words_f64(const idsp_fir_sym_f64 *cfg);
+int idsp_hbf_dec_f64(const idsp_hbf_cascade_f64 *cfg, void *state, const double *x, double *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+int idsp_hbf_int_f64(const idsp_hbf_cascade_f64 *cfg, void *state, const double *x, double *y,
+                     size_t lanes, size_t frames, int layout, void *stream);
+int idsp_fir_sym_f64_process(const idsp_fir_sym_f64 *cfg, void *state, const double *x, double *y,
+                             size_t lanes, size_t frames, int layout, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* cossin / Accu DDS / Lockin                                               */
 /* ------------------------------------------------------------------------ */

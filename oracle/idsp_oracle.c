@@ -957,6 +957,205 @@ int idsp_ref_fir_sym_f32_process(const idsp_fir_sym_f32 *c, void *state, const f
     return IDSP_OK;
 }
 
+/* ---- the same half-band / FIR processors on f64 (`EvenSymmetric<[f64; M]>`, `T = f64`: the reference types are generic in
+ * the sample type, src/hbf.rs:70-138,142-236).  Restated, not macro-generated from the f32 code above: `f64::sum` folds
+ * from -0.0 like `f32::sum`.  State value v occupies words 2v (low) and 2v + 1 (high). */
+static int hbf_cfg_ok_f64(const idsp_hbf_cascade_f64 *c)
+{
+    if (!c || c->stages < 1 || c->stages > IDSP_HBF_MAX_STAGES) return 0;
+    for (int s = 0; s < c->stages; s++) if (c->m[s] < 1 || c->m[s] > IDSP_HBF_MAX_TAPS) return 0;
+    return 1;
+}
+
+static int hbf_fill_f64(int tap_set, int stages, int dec, idsp_hbf_cascade_f64 *out)
+{
+    idsp_hbf_cascade_f32 f;
+    int rc = hbf_fill(tap_set, stages, dec, &f);
+    if (rc || !out) return IDSP_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->stages = f.stages;
+    for (int s = 0; s < f.stages; s++) {
+        out->m[s] = f.m[s];
+        for (int k = 0; k < f.m[s]; k++) out->taps[s][k] = (double)f.taps[s][k];
+    }
+    return IDSP_OK;
+}
+int idsp_ref_hbf_dec_cascade_f64(int tap_set, int stages, idsp_hbf_cascade_f64 *out) { return hbf_fill_f64(tap_set, stages, 1, out); }
+int idsp_ref_hbf_int_cascade_f64(int tap_set, int stages, idsp_hbf_cascade_f64 *out) { return hbf_fill_f64(tap_set, stages, 0, out); }
+
+size_t idsp_ref_hbf_dec_state_words_f64(const idsp_hbf_cascade_f64 *c)
+{
+    if (!hbf_cfg_ok_f64(c)) return 0;
+    size_t w = 0;
+    for (int s = 0; s < c->stages; s++) w += (size_t)(3 * c->m[s] - 2);
+    return 2 * w;
+}
+size_t idsp_ref_hbf_int_state_words_f64(const idsp_hbf_cascade_f64 *c)
+{
+    if (!hbf_cfg_ok_f64(c)) return 0;
+    size_t w = 0;
+    for (int s = 0; s < c->stages; s++) w += (size_t)(2 * c->m[s] - 1);
+    return 2 * w;
+}
+size_t idsp_ref_fir_sym_state_words_f64(const idsp_fir_sym_f64 *c)
+{
+    if (!c || c->kind < 0 || c->kind > 3 || c->m < 1 || c->m > IDSP_HBF_MAX_TAPS) return 0;
+    int odd = (c->kind == IDSP_FIR_ODD_SYMMETRIC || c->kind == IDSP_FIR_ODD_ANTISYMMETRIC);
+    return (size_t)(2 * (2 * c->m - 1 + odd));
+}
+
+static inline double plane_f64(const uint32_t *st, size_t v, size_t lanes, size_t l)
+{
+    uint64_t u = ((uint64_t)st[(2 * v + 1) * lanes + l] << 32) | st[(2 * v) * lanes + l];
+    double d; memcpy(&d, &u, 8); return d;
+}
+static inline void plane_f64_put(uint32_t *st, size_t v, size_t lanes, size_t l, double d)
+{
+    uint64_t u; memcpy(&u, &d, 8);
+    st[(2 * v) * lanes + l] = (uint32_t)u;
+    st[(2 * v + 1) * lanes + l] = (uint32_t)(u >> 32);
+}
+
+/* src/hbf.rs:46-68 on f64 */
+static inline double hbf_get_f64(const double *taps, int m, const double *w)
+{
+    double acc = -0.0;
+    for (int k = 0; k < m; k++) acc = acc + (w[2 * m - 1 - k] + w[k]) * taps[k];
+    return acc;
+}
+
+/* src/hbf.rs:163-185 */
+static void hbf_dec_stage_f64(const double *taps, int m, double *st, const double *in, double *out, size_t n)
+{
+    int len = 2 * m - 1;
+    double even[IDSP_HBF_MAX_TAPS - 1 + HBF_BLOCK], odd[2 * IDSP_HBF_MAX_TAPS - 1 + HBF_BLOCK];
+    memcpy(even, st, sizeof(double) * (size_t)(m - 1));
+    memcpy(odd, st + (m - 1), sizeof(double) * (size_t)len);
+    for (size_t p = 0; p < n; p += HBF_BLOCK) {
+        size_t c = n - p < HBF_BLOCK ? n - p : HBF_BLOCK;
+        for (size_t i = 0; i < c; i++) {
+            even[(size_t)(m - 1) + i] = in[2 * (p + i)];
+            odd[(size_t)len + i] = in[2 * (p + i) + 1];
+        }
+        for (size_t i = 0; i < c; i++) out[p + i] = hbf_get_f64(taps, m, odd + i) + even[i];
+        memmove(even, even + c, sizeof(double) * (size_t)(m - 1));
+        memmove(odd, odd + c, sizeof(double) * (size_t)len);
+    }
+    memcpy(st, even, sizeof(double) * (size_t)(m - 1));
+    memcpy(st + (m - 1), odd, sizeof(double) * (size_t)len);
+}
+
+/* src/hbf.rs:207-227 */
+static void hbf_int_stage_f64(const double *taps, int m, double *st, const double *in, double *out, size_t n)
+{
+    int len = 2 * m - 1;
+    double xb[2 * IDSP_HBF_MAX_TAPS - 1 + HBF_BLOCK];
+    memcpy(xb, st, sizeof(double) * (size_t)len);
+    for (size_t p = 0; p < n; p += HBF_BLOCK) {
+        size_t c = n - p < HBF_BLOCK ? n - p : HBF_BLOCK;
+        memcpy(xb + len, in + p, sizeof(double) * c);
+        for (size_t i = 0; i < c; i++) {
+            out[2 * (p + i)] = hbf_get_f64(taps, m, xb + i);
+            out[2 * (p + i) + 1] = xb[(size_t)m + i];
+        }
+        memmove(xb, xb + c, sizeof(double) * (size_t)len);
+    }
+    memcpy(st, xb, sizeof(double) * (size_t)len);
+}
+
+int idsp_ref_hbf_dec_f64(const idsp_hbf_cascade_f64 *cfg, void *state, const double *x, double *y,
+                         size_t lanes, size_t frames, int layout)
+{
+    if (!hbf_cfg_ok_f64(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    size_t R = (size_t)1 << cfg->stages, W = idsp_ref_hbf_dec_state_words_f64(cfg) / 2;
+    uint32_t *st = (uint32_t *)state;
+    double *a = (double *)malloc(sizeof(double) * (frames * R + 1));
+    double *b = (double *)malloc(sizeof(double) * (frames * R / 2 + 1));
+    double *ls = (double *)malloc(sizeof(double) * W);
+    if (!a || !b || !ls) { free(a); free(b); free(ls); return IDSP_EINVAL; }
+    for (size_t l = 0; l < lanes; l++) {
+        for (size_t w = 0; w < W; w++) ls[w] = plane_f64(st, w, lanes, l);
+        for (size_t f = 0; f < frames; f++)
+            memcpy(a + f * R, x + idx_of(f, l, lanes, frames, layout) * R, sizeof(double) * R);
+        size_t n = frames * R, off = 0;
+        double *src = a, *dst = b;
+        for (int s = 0; s < cfg->stages; s++) {
+            n /= 2;
+            hbf_dec_stage_f64(cfg->taps[s], cfg->m[s], ls + off, src, dst, n);
+            off += (size_t)(3 * cfg->m[s] - 2);
+            double *t = src; src = dst; dst = t;
+        }
+        for (size_t f = 0; f < frames; f++) y[idx_of(f, l, lanes, frames, layout)] = src[f];
+        for (size_t w = 0; w < W; w++) plane_f64_put(st, w, lanes, l, ls[w]);
+    }
+    free(a); free(b); free(ls);
+    return IDSP_OK;
+}
+
+int idsp_ref_hbf_int_f64(const idsp_hbf_cascade_f64 *cfg, void *state, const double *x, double *y,
+                         size_t lanes, size_t frames, int layout)
+{
+    if (!hbf_cfg_ok_f64(cfg) || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    size_t R = (size_t)1 << cfg->stages, W = idsp_ref_hbf_int_state_words_f64(cfg) / 2;
+    uint32_t *st = (uint32_t *)state;
+    double *a = (double *)malloc(sizeof(double) * (frames * R + 1));
+    double *b = (double *)malloc(sizeof(double) * (frames * R + 1));
+    double *ls = (double *)malloc(sizeof(double) * W);
+    if (!a || !b || !ls) { free(a); free(b); free(ls); return IDSP_EINVAL; }
+    for (size_t l = 0; l < lanes; l++) {
+        for (size_t w = 0; w < W; w++) ls[w] = plane_f64(st, w, lanes, l);
+        for (size_t f = 0; f < frames; f++) a[f] = x[idx_of(f, l, lanes, frames, layout)];
+        size_t n = frames, off = 0;
+        double *src = a, *dst = b;
+        for (int s = 0; s < cfg->stages; s++) {
+            hbf_int_stage_f64(cfg->taps[s], cfg->m[s], ls + off, src, dst, n);
+            n *= 2;
+            off += (size_t)(2 * cfg->m[s] - 1);
+            double *t = src; src = dst; dst = t;
+        }
+        for (size_t f = 0; f < frames; f++)
+            memcpy(y + idx_of(f, l, lanes, frames, layout) * R, src + f * R, sizeof(double) * R);
+        for (size_t w = 0; w < W; w++) plane_f64_put(st, w, lanes, l, ls[w]);
+    }
+    free(a); free(b); free(ls);
+    return IDSP_OK;
+}
+
+/* src/hbf.rs:70-138 on f64 */
+int idsp_ref_fir_sym_f64_process(const idsp_fir_sym_f64 *c, void *state, const double *x, double *y,
+                                 size_t lanes, size_t frames, int layout)
+{
+    size_t len = idsp_ref_fir_sym_state_words_f64(c) / 2;
+    if (!len || (layout != IDSP_FRAME_MAJOR && layout != IDSP_LANE_MAJOR)) return IDSP_EINVAL;
+    if (lanes && (!state || (frames && (!x || !y)))) return IDSP_EINVAL;
+    int m = c->m;
+    int odd = (c->kind == IDSP_FIR_ODD_SYMMETRIC || c->kind == IDSP_FIR_ODD_ANTISYMMETRIC);
+    int sym = (c->kind == IDSP_FIR_ODD_SYMMETRIC || c->kind == IDSP_FIR_EVEN_SYMMETRIC);
+    uint32_t *st = (uint32_t *)state;
+    for (size_t l = 0; l < lanes; l++) {
+        double buf[2 * IDSP_HBF_MAX_TAPS + HBF_BLOCK];
+        for (size_t w = 0; w < len; w++) buf[w] = plane_f64(st, w, lanes, l);
+        for (size_t p = 0; p < frames; p += HBF_BLOCK) {
+            size_t n = frames - p < HBF_BLOCK ? frames - p : HBF_BLOCK;
+            for (size_t i = 0; i < n; i++) buf[len + i] = x[idx_of(p + i, l, lanes, frames, layout)];
+            for (size_t i = 0; i < n; i++) {
+                const double *w = buf + i;
+                double acc = -0.0;
+                for (int k = 0; k < m; k++) {
+                    double nw = w[2 * m - 1 + odd - k], od = w[k];
+                    acc = acc + (sym ? nw + od : nw - od) * c->taps[k];
+                }
+                y[idx_of(p + i, l, lanes, frames, layout)] = (odd && sym) ? acc + w[m] : acc;
+            }
+            memmove(buf, buf + n, sizeof(double) * len);
+        }
+        for (size_t w = 0; w < len; w++) plane_f64_put(st, w, lanes, l, buf[w]);
+    }
+    return IDSP_OK;
+}
+
 /* ----------------------------------------------------------------- cossin */
 
 #define COSSIN_DEPTH 7

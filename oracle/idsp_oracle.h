@@ -143,6 +143,14 @@ int32_t idsp_ref_atan2(int32_t y, int32_t x);
 int idsp_ref_atan2_i32(const int32_t *xy, int32_t *out, size_t n);
 int idsp_ref_cossin_i32(const int32_t *phase, int32_t *out, size_t n);
 int idsp_ref_dds_i32(void *state, int32_t *out, size_t lanes, size_t frames, int layout);
+int idsp_ref_hbf_dec_cascade_f64(int tap_set, int stages, idsp_hbf_cascade_f64 *out);
+int idsp_ref_hbf_int_cascade_f64(int tap_set, int stages, idsp_hbf_cascade_f64 *out);
+size_t idsp_ref_hbf_dec_state_words_f64(const idsp_hbf_cascade_f64 *cfg);
+size_t idsp_ref_hbf_int_state_words_f64(const idsp_hbf_cascade_f64 *cfg);
+size_t idsp_ref_fir_sym_state_words_f64(const idsp_fir_sym_f64 *cfg);
+int idsp_ref_hbf_dec_f64(const idsp_hbf_cascade_f64 *cfg, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_hbf_int_f64(const idsp_hbf_cascade_f64 *cfg, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
+int idsp_ref_fir_sym_f64_process(const idsp_fir_sym_f64 *cfg, void *state, const double *x, double *y, size_t lanes, size_t frames, int layout);
 size_t idsp_ref_lockin_state_words(const idsp_lockin_i32 *cfg);
 int idsp_ref_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32_t *x,
                                 int32_t *y, size_t lanes, size_t frames, int layout);

@@ -280,3 +280,35 @@ def test_fm_disc_receiver_core():
     y = torch.empty(n, dtype=torch.int32, device="cuda")
     rx.process_view(ia.View(x, ia.LaneMajor, 1, width=2), ia.ViewMut(y, ia.LaneMajor, 1))
     assert y[0].item() == 0 and abs(y[-1].item() / offset - 1.0) < 2e-3
+
+
+def test_lockin_with_biquad_arms_and_external_lo_recover_dc_iq():
+    """`Lockin<C>` beyond lowpass arms (src/lockin.rs:16-27) through the host mirror: the integer lock-in with a Q30 biquad
+    arm on a phase accumulator, and the f32 `mix -> Biquad<f32>.lanes()` graph of examples/ddc_lockin.rs:35-42 with its
+    own acceptance bounds (:100-111)."""
+    n, lanes, f, phi = 16384, 4, 0.173, 0.37
+    step = int(round(f * (1 << 32)))
+    t = np.arange(1, n + 1)
+    amp = 1 << 28
+    x = np.round(amp * np.cos(2 * np.pi * ((t * step) % (1 << 32)) / (1 << 32) - phi)).astype(np.int32)
+    w0 = math.tau * 0.002
+    alpha = 0.5 * math.sin(w0) * math.sqrt(2.0)
+    b = 0.5 * (1.0 - math.cos(w0))
+    sos = [b, 2 * b, b, 1 + alpha, -2 * math.cos(w0), 1 - alpha]
+    p = ia.Lockin([ia.Biquad.from_sos(sos, frac=30)]).lanes(lanes, step=step)
+    xd = torch.from_numpy(np.repeat(x[:, None], lanes, axis=1).copy()).cuda()
+    y = torch.empty((n, lanes, 2), dtype=torch.int32, device="cuda")
+    p.block(xd, y)
+    iq = y[12288:].double().mean(dim=0).cpu().numpy() / amp
+    assert np.allclose(iq[:, 0], 0.25 * math.cos(phi), atol=3e-3) and np.allclose(iq[:, 1], 0.25 * math.sin(phi), atol=3e-3)
+    # f32 graph with the LO as an input
+    ph = (np.float32(math.tau * f) * np.arange(n, dtype=np.float32))
+    xf = np.cos(ph + np.float32(phi)).astype(np.float32)
+    lo = np.stack([np.cos(ph), -np.sin(ph)], axis=1).astype(np.float32)
+    q = ia.LockinLo([ia.Biquad.from_sos(sos)], lanes)
+    xfd = torch.from_numpy(np.repeat(xf[:, None], lanes, axis=1).copy()).cuda()
+    lod = torch.from_numpy(np.repeat(lo[:, None, :], lanes, axis=1).copy()).cuda()
+    yf = torch.empty((n, lanes, 2), dtype=torch.float32, device="cuda")
+    q.process(xfd, lod, yf)
+    m = yf[12288:].double().mean(dim=0).cpu().numpy()
+    assert np.allclose(m[:, 0], 0.5 * math.cos(phi), atol=3e-3) and np.allclose(m[:, 1], 0.5 * math.sin(phi), atol=3e-3)

@@ -110,7 +110,7 @@ def test_repr_c_struct_sizes_match_ctypes():
     src = open(SYS).read()
     pairs = {"IdspBiquadI32": _abi.BiquadI32, "IdspBiquadClampI32": _abi.BiquadClampI32, "IdspBiquadF32": _abi.BiquadF32,
              "IdspBiquadClampF32": _abi.BiquadClampF32, "IdspBiquadF64": _abi.BiquadF64, "IdspBiquadClampF64": _abi.BiquadClampF64,
-             "IdspHbfCascadeF32": _abi.HbfCascadeF32, "IdspFirSymF32": _abi.FirSymF32, "IdspLockinI32": _abi.LockinI32,
+             "IdspHbfCascadeF32": _abi.HbfCascadeF32, "IdspFirSymF32": _abi.FirSymF32, "IdspHbfCascadeF64": _abi.HbfCascadeF64, "IdspFirSymF64": _abi.FirSymF64, "IdspLockinI32": _abi.LockinI32,
              "IdspWdf": _abi.Wdf, "IdspFmDisc": _abi.FmDisc, "IdspCic": _abi.Cic, "IdspFilter": _abi.Filter,
              "IdspPidBuilder": _abi.PidBuilder, "IdspUnits": _abi.Units, "IdspPid": _abi.Pid, "IdspBaConfig": _abi.BaConfig,
              "IdspFilterConfig": _abi.FilterConfig}
