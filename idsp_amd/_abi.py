@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2  # IDSP_ABI_VERSION of include/idsp_hip.h
+ABI_VERSION = 3  # IDSP_ABI_VERSION of include/idsp_hip.h
 
 IDSP_OK = 0
 IDSP_EINVAL = -1

@@ -37,7 +37,7 @@ def load():
             )
         _lib = ctypes.CDLL(LIB_PATH)
         _fn = _abi.bind(_lib, "idsp_", with_stream=True, utils=True)
-        if _fn["version"]() != _abi.ABI_VERSION:
+        if _fn["version"]() < _abi.ABI_VERSION:  # versions only add symbols (include/idsp_hip.h): a newer library is fine
             raise ImportError(f"libidsp_hip.so reports ABI version {_fn['version']()}, this package binds version {_abi.ABI_VERSION}: rebuild (`make lib`)")
     return _fn, _lib
 

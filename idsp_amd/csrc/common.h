@@ -4,6 +4,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <cstdarg>
@@ -26,7 +28,7 @@ int fail(int code, const char *fmt, ...);
             return ::idsp::fail(IDSP_EHIP, "%s: %s", #expr, hipGetErrorString(e_));     \
     } while (0)
 
-// Kernel-selection switches exist for A/B measurements and for tests that force a
+// Kernel-selection switches (profiles/NOTES.md, "Kernel-selection switches") exist for A/B measurements and for tests that force a
 // path a default run would not reach.  A production process must not change dispatch because of a stray
 // variable, so they are honoured only when IDSP_DIAG=1 is set as well; every caller caches the answer in a
 // function-local static (read once per process).
@@ -44,18 +46,39 @@ inline bool diag_on() { return diag_env("IDSP_DIAG") != nullptr; }
 
 // A second stream per (thread, device) with the two events that fork it off the caller's stream and join it back: a launch
 // can put an independent piece of a call beside the main kernel (lane_stream.h: the lanes beyond the last whole round of
-// workgroups).  Created on first use, kept for the life of the thread; NULL if the runtime refuses.
+// workgroups).  The device is that of the CALLER'S STREAM (hipStreamGetDevice), not the current one; a caller whose stream
+// lives on another device than the current one gets NULL, and the launch takes its unsplit single-stream form.  Created on
+// first use, released when the thread exits (thread_local holder); NULL if the runtime refuses anything.
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-inline SideStream *side_stream()
+struct SideStreamTable {
+    static constexpr int kMaxDev = 64;
+    SideStream e[kMaxDev];
+    ~SideStreamTable()
+    {
+        // The main thread's holder dies at process exit, possibly after the HIP runtime has shut down: leave its streams
+        // to the process teardown.  Worker threads release theirs while the runtime is alive.
+        if (getpid() == pid_t(syscall(SYS_gettid))) return;
+        for (SideStream &s : e) {
+            if (s.fork) (void)hipEventDestroy(s.fork);
+            if (s.join) (void)hipEventDestroy(s.join);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+        }
+    }
+};
+inline SideStream *side_stream(hipStream_t caller)
 {
-    constexpr int kMaxDev = 64;
-    static thread_local SideStream table[kMaxDev];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    SideStream &e = table[dev];
+    static thread_local SideStreamTable table;
+    int cur = 0, dev = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    if (caller == nullptr)
+        dev = cur;  // the NULL stream is the current device's
+    else if (hipStreamGetDevice(caller, &dev) != hipSuccess)
+        return nullptr;
+    if (dev != cur || dev < 0 || dev >= SideStreamTable::kMaxDev) return nullptr;
+    SideStream &e = table.e[dev];
     if (!e.stream) {
         hipStream_t s = nullptr;
         hipEvent_t f = nullptr, j = nullptr;

@@ -109,7 +109,7 @@ struct Casc {
 // History roll of a FULL chunk as one flat copy.  After a chunk, every stream's last H samples become the history in
 // front of the next chunk (src/hbf.rs:182-183,224 `copy_within`).  Done stage by stage with `lid < H` predicates that
 // was ~120 wave instructions per 1024-sample chunk (8 predicated reads, 8 predicated writes, their exec-mask
-// bookkeeping) out of ~570 — on a kernel that is instruction-issue bound.  The histories of all
+// bookkeeping) out of ~570 — on a kernel that is instruction-issue bound (profiles/NOTES.md section 3).  The histories of all
 // streams are one list of `roll_total` words (118 for /16); thread t moves words t, t + 64, ... and knows their
 // source / destination LDS offsets from before the chunk loop: 2 reads, 2 writes, one predicate.
 template <class C>

@@ -1418,7 +1418,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             }
             const size_t odd = lanes % 4, body = lanes - odd;
             if (odd && !align16_only && body >= 8192 && frames >= 16 && (FmStagedOf<P>::value || LdsEligibleOf<P>::value)) {
-                if (SideStream *ss = side_stream()) {
+                if (SideStream *ss = side_stream(s)) {
                     IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
                     IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
                     hipLaunchKernelGGL((stream_frame_major_few<P>), dim3(1), dim3(kWave), 0, ss->stream, shift_lanes(prm, body, sizeof(typename P::In)), st + body,
@@ -1436,7 +1436,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             const size_t head = lanes / (size_t(256) * kFmBlock) * (size_t(256) * kFmBlock), tail = lanes - head;
             if (head && tail && tail <= kSplitTailMax && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() && rows_ok &&
                 xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
-                if (SideStream *ss = side_stream()) {
+                if (SideStream *ss = side_stream(s)) {
                     IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
                     IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
                     int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, sp);

@@ -121,6 +121,7 @@ int idsp_multi_shard(const idsp_multi *m, size_t lanes, int index, size_t *lane_
 
 int idsp_multi_for_each(idsp_multi *m, size_t lanes, idsp_shard_fn fn, void *user)
 {
+    last_block() = -1;
     if (!m || !fn) return fail(IDSP_EINVAL, "m or fn is NULL");
     DeviceGuard guard;
     const size_t G = m->devices.size();
@@ -228,10 +229,10 @@ template <class Cfg, class T, class Fn>
 int multi_biquad(idsp_multi *m, Fn entry, const Cfg *cfg, size_t n, void *const *state, const T *const *x, T *const *y, size_t lanes,
                  size_t frames, int layout)
 {
+    last_block() = -1;  // reset before ANY return: a stale value must not be read as this call's block
     if (!m || !state || !x || !y) return fail(IDSP_EINVAL, "m, state, x or y is NULL");
     DeviceGuard guard;
     const size_t G = m->devices.size();
-    last_block() = -1;
     // Validate EVERY block before launching any: a zero-frame call of the entry runs all of its argument checks
     // (configuration, section count, layout, NULL buffers) and launches nothing, so a bad block is reported before
     // any block's state has advanced.
@@ -243,6 +244,8 @@ int multi_biquad(idsp_multi *m, Fn entry, const Cfg *cfg, size_t n, void *const 
             last_block() = int(g);
             return fail(IDSP_EINVAL, "state, x or y of block %zu is NULL (%zu lanes)", g, hi - lo);
         }
+        // the probe runs with block g's device current, like the launch below: an entry is free to touch HIP state in its checks
+        IDSP_HIP_TRY(hipSetDevice(m->devices[g]));
         const int rc = entry(cfg, n, state[g], x[g], y[g], hi - lo, 0, layout, m->streams[g]);
         if (rc < 0) {
             last_block() = int(g);

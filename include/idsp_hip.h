@@ -52,9 +52,11 @@ extern "C" {
 #endif
 
 /* 1: round-1 surface.  2: + the `_pitch` twins, idsp_multi_*, idsp_last_kernel, idsp_device_sync,
- * idsp_multi_last_block; dispatch switches honoured only with IDSP_DIAG=1.  A host binding should refuse a
- * library whose idsp_version() is lower than the version it was generated from. */
-#define IDSP_ABI_VERSION 2
+ * idsp_multi_last_block; dispatch switches honoured only with IDSP_DIAG=1.  3: + `Lockin<C>` with biquad arms and
+ * the external-LO forms (idsp_lockin_*_biquad*, *_lo_*), the f64 half-band / FIR entries.  Versions only ADD symbols:
+ * a host binding refuses a library whose idsp_version() is LOWER than the version it was generated from and accepts
+ * any higher one (the rule of idsp_amd/_lib.py, __graft_entry__.py and rust/idsp-hip). */
+#define IDSP_ABI_VERSION 3
 
 typedef enum idsp_status {
     IDSP_OK = 0,

@@ -612,24 +612,26 @@ static int fm_rows_f32_df2t(const idsp_biquad_f32 *cfg, size_t n, uint32_t *st, 
 typedef struct {
     int kind; const void *cfg; size_t n; void *state; const void *x; void *y;
     size_t lanes, frames; int layout; size_t l0, l1; int reps; int cpu;
+    int rc; /* first non-zero status of this block's passes (a failed scratch allocation in the FRAME_MAJOR drivers) */
 } mt_job;
 
-static void mt_run_block(const mt_job *j)
+static void mt_run_block(mt_job *j)
 {
-    for (int r = 0; r < j->reps; r++) {
+    j->rc = IDSP_OK;
+    for (int r = 0; r < j->reps && j->rc == IDSP_OK; r++) {
         if (j->kind == 0) {
             if (j->layout == IDSP_FRAME_MAJOR)
-                fm_rows_i32_df1((const idsp_biquad_i32 *)j->cfg, j->n, (uint32_t *)j->state, (const int32_t *)j->x,
+                j->rc = fm_rows_i32_df1((const idsp_biquad_i32 *)j->cfg, j->n, (uint32_t *)j->state, (const int32_t *)j->x,
                                 (int32_t *)j->y, j->lanes, j->frames, j->l0, j->l1);
             else
-                idsp_ref_biquad_i32_df1_range((const idsp_biquad_i32 *)j->cfg, j->n, j->state, (const int32_t *)j->x,
+                j->rc = idsp_ref_biquad_i32_df1_range((const idsp_biquad_i32 *)j->cfg, j->n, j->state, (const int32_t *)j->x,
                                               (int32_t *)j->y, j->lanes, j->frames, j->layout, j->l0, j->l1);
         } else {
             if (j->layout == IDSP_FRAME_MAJOR)
-                fm_rows_f32_df2t((const idsp_biquad_f32 *)j->cfg, j->n, (uint32_t *)j->state, (const float *)j->x,
+                j->rc = fm_rows_f32_df2t((const idsp_biquad_f32 *)j->cfg, j->n, (uint32_t *)j->state, (const float *)j->x,
                                  (float *)j->y, j->lanes, j->frames, j->l0, j->l1);
             else
-                idsp_ref_biquad_f32_df2t_range((const idsp_biquad_f32 *)j->cfg, j->n, j->state, (const float *)j->x,
+                j->rc = idsp_ref_biquad_f32_df2t_range((const idsp_biquad_f32 *)j->cfg, j->n, j->state, (const float *)j->x,
                                                (float *)j->y, j->lanes, j->frames, j->layout, j->l0, j->l1);
         }
     }
@@ -673,9 +675,9 @@ int idsp_ref_biquad_mt_reps(int kind, const void *cfg, size_t n, void *state, co
     if (kind < 0 || kind > 1 || threads < 1 || threads > 4096 || reps < 1) return IDSP_EINVAL;
     if (kind == 0 && !frac_ok_i32((const idsp_biquad_i32 *)cfg, n)) return IDSP_EINVAL;
     if (threads == 1) {
-        mt_job j = {kind, cfg, n, state, x, y, lanes, frames, layout, 0, lanes, reps, -1};
+        mt_job j = {kind, cfg, n, state, x, y, lanes, frames, layout, 0, lanes, reps, -1, IDSP_OK};
         mt_run_block(&j);
-        return IDSP_OK;
+        return j.rc;
     }
     cpu_set_t allowed;
     int ncpu = 0, cpus[CPU_SETSIZE];
@@ -688,14 +690,16 @@ int idsp_ref_biquad_mt_reps(int kind, const void *cfg, size_t n, void *state, co
     for (int t = 0; t < threads; t++) {
         mt_job j = {kind, cfg, n, state, x, y, lanes, frames, layout,
                     lanes * (size_t)t / (size_t)threads, lanes * (size_t)(t + 1) / (size_t)threads, reps,
-                    ncpu > 0 ? cpus[t % ncpu] : -1};
+                    ncpu > 0 ? cpus[t % ncpu] : -1, IDSP_OK};
         jobs[t] = j;
         started[t] = pthread_create(&tid[t], NULL, mt_worker, &jobs[t]) == 0;
         if (!started[t]) mt_run_block(&jobs[t]);     /* could not start a thread: do the block here */
     }
     for (int t = 0; t < threads; t++) if (started[t]) pthread_join(tid[t], NULL);
+    rc = IDSP_OK;
+    for (int t = 0; t < threads && rc == IDSP_OK; t++) rc = jobs[t].rc;  /* a block that failed must not read as a result */
     free(tid); free(jobs); free(started);
-    return IDSP_OK;
+    return rc;
 }
 
 int idsp_ref_biquad_i32_df1_mt(const idsp_biquad_i32 *cfg, size_t n, void *state, const int32_t *x,

@@ -12,7 +12,7 @@
  * loop that follows the reference line by line (citations at each function in
  * idsp_oracle.c).
  *
- * Pinning status (see DESIGN.md "Oracle"):
+ * Pinning status:
  *   pinned by reference known-answer tests (tests/golden/ref_kat.json):
  *     i32 DF1 biquad + float->Q quantisation, BiquadClamp, DF2T identity,
  *     DF1Dither doctest, HbfDec KAT + response lengths, cossin error bounds,

@@ -46,8 +46,12 @@ impl core::fmt::Display for Error {
 impl std::error::Error for Error {}
 
 fn check(rc: c_int) -> Result<(), Error> {
-    if rc >= 0 {
+    if rc == 0 {
         return Ok(());
+    }
+    if rc > 0 {
+        // a positive status is a callback's stop code returned verbatim by idsp_multi_for_each: not a success
+        return Err(Error { code: rc, message: String::from("stopped early by the callback (idsp_multi_last_block() tells where)") });
     }
     // SAFETY: idsp_last_error returns a pointer to a NUL-terminated thread-local buffer owned by the library.
     let message = unsafe { core::ffi::CStr::from_ptr(sys::idsp_last_error()) }.to_string_lossy().into_owned();

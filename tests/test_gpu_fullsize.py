@@ -324,7 +324,7 @@ def _subset(lanes, step):
 
 
 C2_VARIANTS = [
-    # op, state words, dtype, clamp record?  (the processors DESIGN section 5 quotes C2-shape throughput for)
+    # op, state words, dtype, clamp record?  (the processors profiles/NOTES.md section 5 quotes C2-shape throughput for)
     ("biquad_i32_df1_clamp", 4, np.int32, True),
     ("biquad_i32_dither", 5, np.int32, False),
     ("biquad_i32_dither_clamp", 5, np.int32, True),

@@ -2,7 +2,7 @@
 Force it (IDSP_DIAG=1 + IDSP_LDS_COST / IDSP_LDS_MIN_WAVES, read once per process -> subprocess) for the heavy and the
 two-word-output processors too and check them against the oracle: lock-in (Complex out, LUT in LDS),
 8-section cascade, dither, Normal, a 4-section chain; and check every clamp variant, f32 DF1 and f32 DF2T
-(the processors DESIGN section 5 quotes throughput for on this kernel) out of place and in place.
+(the processors profiles/NOTES.md section 5 quotes throughput for on this kernel) out of place and in place.
 Without IDSP_DIAG=1 the switches must be ignored (second test)."""
 import os
 import subprocess

@@ -28,7 +28,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # Kernels that are KNOWN to use scratch, with the reason (regular expressions on the demangled-ish symbol name).
 ALLOWED = [
     # LaneMajor Cic decimator: a 4-tile register ring that spills 0.6-1.4 KB per thread; rings of 3 or 2 tiles without
-    # spills measured slower at 16384 lanes, left as it is
+    # spills measured slower at 16384 lanes (profiles/NOTES.md §7), left as it is
     (r"cic_dec_lm_kernel", "Cic LaneMajor decimator register ring (measured faster than the spill-free forms)"),
 ]
 

@@ -21,7 +21,7 @@ int fail(int code, const char *, ...) { return code; }
 void note_kernel(const char *, const char *) {}
 }  // namespace idsp
 
-// The LDS-DMA twin of stream_lane_major_staged that was measured and not kept: ring of NB slots of 64 lanes x LB
+// The LDS-DMA twin of stream_lane_major_staged that was measured and not kept (profiles/NOTES.md section 3): ring of NB slots of 64 lanes x LB
 // bytes filled by global_load_lds_dwordx4 (hand-counted vmcnt), optional touch-prefetch of PF-byte chunks (PF).
 namespace idsp {
 template <bool NT>

@@ -1,6 +1,6 @@
 // cossin() formulations on gfx950: issue cost per evaluation and bit-exactness against the shipped one
 // (idsp_amd/csrc/dds_dev.h: cossin_dev, a restatement of src/cossin.rs:14-67).  The C4 lock-in is VALU-issue
-// bound and cossin is the largest single item of its per-sample instruction budget.
+// bound and cossin is the largest single item of its per-sample instruction budget (profiles/NOTES.md §3, §5).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fwrapv -Iinclude -Iidsp_amd/csrc tools/ubench_cossin.hip -o build/ubench_cossin
 //   build/ubench_cossin            (prints cycles per evaluation and SIMD at 1 / 2 / 4 waves per SIMD)
 #include <hip/hip_runtime.h>
