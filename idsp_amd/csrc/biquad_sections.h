@@ -72,7 +72,11 @@ __device__ __forceinline__ int64_t sum5(const SecI32 &c, int32_t x0, int32_t x1,
 template <bool CLAMP>
 struct Df1I32 {
     static constexpr bool kClamp = CLAMP;
+#ifdef IDSP_EXP_DF1_RING  // experiment: ring depth of the plain i32 DF1 (co-residency of two workgroups per CU against the ring's LDS)
+    static constexpr int LDS_RING = CLAMP ? 4 : IDSP_EXP_DF1_RING;
+#else
     static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements (plain: 5, 6, 7 within 1.5 %)
+#endif
     static constexpr bool LDS_RUN = false;
     static constexpr int LDS_MAX_N = 3;     // serial sections up to which the LDS-DMA kernel beats the register window
     using T = int32_t;
