@@ -393,6 +393,9 @@ __global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float 
     constexpr int LEAD = RING / kSlots;    // rounds of settled queue a FAST round needs on either side
     const int lid = threadIdx.x;
     const size_t lane = blockIdx.x;
+#ifdef IDSP_EXP_HBF_CLK
+    const long long clk_s0 = clock64(), clk_r0 = wall_clock64();  // shader-clock cycles against the 100 MHz counter
+#endif
     float *ring = smem_lm, *str = smem_lm + RW;
     WC wc;
     wc.init(str, lid);
@@ -572,6 +575,10 @@ __global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float 
     lds_wave_sync();
     wait_vmcnt<0>();  // the requests past the end of the data are still landing: they must not outlive the wave's LDS
     wc.store_state(st, lanes, lane);
+#ifdef IDSP_EXP_HBF_CLK
+    if (lid == 0 && (lane == 0 || lane == lanes / 2 || lane + 1 == lanes))
+        printf("clk lm lane %d: %lld shader cycles in %lld x 10 ns\n", int(lane), clock64() - clk_s0, wall_clock64() - clk_r0);
+#endif
 }
 
 // ============================================================================================== FRAME_MAJOR
@@ -606,6 +613,9 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
     const size_t group = (blockIdx.x % 8) * per + blockIdx.x / 8;  // every XCD a contiguous eighth of the lane groups
     if (group >= ngroups) return;
     const size_t lane0 = group * kFmLanes, lane = lane0 + w;
+#ifdef IDSP_EXP_HBF_CLK
+    const long long clk_s0 = clock64(), clk_r0 = wall_clock64();
+#endif
     char *ringb = reinterpret_cast<char *>(smem_fm);
     float *str = smem_fm + kFmRows * kFmPitch / 4 + w * up4(L::words);
     float *tile = smem_fm + kFmRows * kFmPitch / 4 + kFmLanes * up4(L::words);
@@ -736,6 +746,10 @@ __global__ __launch_bounds__(kFmLanes *kW) void hbf_dec_ring_fm(uint32_t *st, co
     lds_barrier();    // every wave's column of the last tile
     store_tile(rounds - 1, n_last / R);
     wc.store_state(st, lanes, lane);
+#ifdef IDSP_EXP_HBF_CLK
+    if (threadIdx.x == 0 && (group == 0 || group == ngroups / 2 || group + 1 == ngroups))
+        printf("clk fm group %d: %lld shader cycles in %lld x 10 ns\n", int(group), clock64() - clk_s0, wall_clock64() - clk_r0);
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------------- host

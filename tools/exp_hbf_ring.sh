@@ -21,6 +21,12 @@ if [ "${1:-run}" = build ]; then
       idsp_amd/csrc/hbf_wave_dec.o idsp_amd/csrc/hbf_wave_int.o idsp_amd/csrc/api_util.o build/exp_hbf_ring/hbf_ring_dec_$n.o
   done
   ls -la build/exp_hbf_ring/*.so
+elif [ "$1" = full ]; then
+  # whole engine with the variant object in place of hbf_ring_dec.o (for IDSP_HIP_LIB: parity runs of a variant that is meant to be correct)
+  n=$2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 --offload-compress -shared -fPIC -o build/exp_hbf_ring/full_$n.so \
+    $(ls idsp_amd/csrc/*.o | grep -v hbf_ring_dec.o) build/exp_hbf_ring/hbf_ring_dec_$n.o
+  ls -la build/exp_hbf_ring/full_$n.so
 else
   O=gpurun_out/${OUT:-exp_hbf_ring.jsonl}; mkdir -p gpurun_out; : > $O
   echo '{"variant": "product"}' >> $O
