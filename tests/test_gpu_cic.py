@@ -75,3 +75,55 @@ def test_cic_lane_major_tile_kernels(bes, kind, dtype):
             assert rco == 0 and rcg == 0, H.engine().err()
             assert np.array_equal(yo, yg), (vpc, lanes, frames, cfg.order, cfg.comb_delay)
             assert np.array_equal(so, sg)
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64], ids=["i32", "i64"])
+def test_cic_decimator_wave_per_lane(bes, dtype):
+    """LANE_MAJOR decimators with whole 16-byte pieces per chunk and 64 or more chunks take the wave-per-lane kernel
+    (cic_ring.h: frames integrated in parallel, a scan over the wave): every piece count, every order and comb delay,
+    whole and ragged blocks, FAST rounds in the middle (5 blocks and more), continuation from the written-back state
+    (chunked == whole), lane counts that are not multiples of anything."""
+    ob, gb = bes
+    rng = np.random.default_rng(140 + (1 if dtype == np.int64 else 0))
+    epv = 16 // np.dtype(dtype).itemsize
+    shapes = [(1, 3, 64), (2, 5, 65), (4, 7, 127), (8, 2, 128), (4, 33, 200), (2, 1, 449), (1, 9, 64 * 7), (8, 3, 64 * 6 + 1), (4, 4, 1000)]
+    orders = [1, 2, 3, 4, 5, 6, 3, 3, 3]
+    for (ppt, lanes, frames), n in zip(shapes, orders):
+        R = ppt * epv
+        cfg = _abi.Cic(n, int(rng.integers(1, 5)), R - 1)
+        words = K.state_words(gb, cfg, dtype)
+        init = K.random_state(rng, words, lanes)
+        so, sg, sw = init.copy(), init.copy(), init.copy()
+        xs = []
+        for part in range(2):
+            x = K.samples(rng, dtype, lanes * frames * R)
+            xs.append(x.reshape(lanes, frames * R))
+            rco, yo = K.run(ob, "dec", dtype, cfg, so, x, lanes, frames, K.LM)
+            rcg, yg = K.run(gb, "dec", dtype, cfg, sg, x, lanes, frames, K.LM)
+            assert rco == 0 and rcg == 0, H.engine().err()
+            assert H.engine().fn["last_kernel"]().decode().startswith("cic_dec_ring[LaneMajor]")
+            assert np.array_equal(yo, yg), (ppt, lanes, frames, cfg.order, cfg.comb_delay, part)
+            assert np.array_equal(so, sg), (ppt, lanes, frames, cfg.order, cfg.comb_delay, part)
+        # both parts in one call from the same initial state: same final state
+        xw = np.ascontiguousarray(np.concatenate(xs, axis=1)).reshape(-1)
+        rcw, yw = K.run(gb, "dec", dtype, cfg, sw, xw, lanes, 2 * frames, K.LM)
+        assert rcw == 0 and np.array_equal(sw, sg)
+
+
+def test_cic_decimator_wave_per_lane_extremes(bes):
+    """Wrapping: full-scale inputs through order 6 at rate 32 overflow every integrator many times over."""
+    ob, gb = bes
+    for dtype, ppt in ((np.int32, 8), (np.int64, 8)):
+        epv = 16 // np.dtype(dtype).itemsize
+        R, lanes, frames = ppt * epv, 2, 256
+        cfg = _abi.Cic(6, 4, R - 1)
+        words = K.state_words(gb, cfg, dtype)
+        info = np.iinfo(dtype)
+        x = np.full(lanes * frames * R, info.max, dtype)
+        x[1::3] = info.min
+        so = np.full((words, lanes), 0xFFFFFFFF, np.uint32)
+        sg = so.copy()
+        rco, yo = K.run(ob, "dec", dtype, cfg, so, x, lanes, frames, K.LM)
+        rcg, yg = K.run(gb, "dec", dtype, cfg, sg, x, lanes, frames, K.LM)
+        assert rco == 0 and rcg == 0
+        assert np.array_equal(yo, yg) and np.array_equal(so, sg)

@@ -432,6 +432,7 @@ def main():
             cic("dec", torch.int32, 3, 15, 16384, 4096, layout, it, "cic")
             cic("int", torch.int32, 3, 15, 16384, 4096, layout, it, "cic")
         cic("dec", torch.int64, 3, 15, 16384, 2048, FM, it, "cic")
+        cic("dec", torch.int64, 3, 15, 16384, 2048, LM, it, "cic")
         cic("dec", torch.int32, 3, 63, 16384, 1024, FM, it, "cic")
         cic("dec", torch.int32, 3, 15, 65536, 1024, FM, it, "cic")
     if want("c4"):
