@@ -486,13 +486,15 @@ int run_orders(const idsp_cic *cfg, void *state, const T *x, T *y, size_t lanes,
     const dim3 grid(unsigned((lanes + kBlock - 1) / kBlock)), block(kBlock);
     uint32_t *st = static_cast<uint32_t *>(state);
     hipStream_t s = as_stream(stream);
-    if constexpr (DEC) {
-        // LANE_MAJOR decimators with whole 16-byte pieces per chunk and at least 64 chunks: one wave per lane (cic_ring.h)
-        if (layout == IDSP_LANE_MAJOR) {
-            const int rr = cic_ring_dec(cfg, st, x, y, lanes, frames, s);
-            if (rr == 0) return launch_status();
-            if (rr == 2) return IDSP_EHIP;
-        }
+    // whole 16-byte pieces per chunk and at least 64 chunks: one wave per lane (cic_ring.h; the decimator in LANE_MAJOR only)
+    if (layout == IDSP_LANE_MAJOR || !DEC) {
+        int rr;
+        if constexpr (DEC)
+            rr = cic_ring_dec(cfg, st, x, y, lanes, frames, s);
+        else
+            rr = cic_ring_int(cfg, st, x, y, lanes, frames, layout == IDSP_LANE_MAJOR, s);
+        if (rr == 0) return launch_status();
+        if (rr == 2) return IDSP_EHIP;
     }
     // vectors per chunk when the chunk is a whole number of 16-byte vectors and the rows are aligned
     using V = Vec16<T>;

@@ -257,10 +257,330 @@ __global__ __launch_bounds__(kW) void cic_dec_ring_lm(const ScanCoef<T, N> coef,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ interpolator
+// `Cic<T, N, M>` interpolator (src/cic.rs:160-182 under `Interpolator`, adapters.rs:27-35), LANE_MAJOR, one wave per lane.
+// The combs run at the low rate across threads first; a frame then integrates R copies of its held value `zoh`, which from
+// zero is h * zoh with h = R steps of the chain on input 1 (host, u64).  Same scan as the decimator; thread t then
+// replays its R steps from the true state behind frame t - 1 and owns the frame's R outputs = PPT 16-byte pieces.  They go
+// through a padded LDS tile (pitch PPT + 1 pieces: conflict-free writes) and leave as PPT stores of one whole KiB each.
+template <class T, int N>
+struct IntCoef {
+    ScanCoef<T, N> scan;
+    typename std::make_unsigned<T>::type h[N];  // the chain after R steps on constant input 1 from zero
+};
+
+template <class T, int N, int PPT>
+__global__ __launch_bounds__(kW) void cic_int_ring_lm(const IntCoef<T, N> coef, const int m, uint32_t *st, const T *x, T *y,
+                                                       const size_t lanes, const size_t frames)
+{
+    using UT = typename std::make_unsigned<T>::type;
+    constexpr int VW = sizeof(T) / 4;
+    constexpr int SPP = 16 / int(sizeof(T));
+    constexpr int R = PPT * SPP;
+    constexpr int PITCH = (PPT + 1) * 16;  // bytes per frame in the tile
+    static_assert(PPT == 1 || PPT == 2 || PPT == 4 || PPT == 8, "16-byte pieces per frame");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_cic[];
+    char *const tile = reinterpret_cast<char *>(smem_cic);
+    const int lid = threadIdx.x;
+    const size_t lane = blockIdx.x;
+
+    auto ldv = [&](int v) -> UT {
+        if constexpr (VW == 1)
+            return UT(st[size_t(v) * lanes + lane]);
+        else
+            return UT(uint64_t(st[size_t(2 * v) * lanes + lane]) | (uint64_t(st[size_t(2 * v + 1) * lanes + lane]) << 32));
+    };
+    auto stv = [&](int v, UT val) {
+        if constexpr (VW == 1) {
+            st[size_t(v) * lanes + lane] = uint32_t(val);
+        } else {
+            st[size_t(2 * v) * lanes + lane] = uint32_t(val);
+            st[size_t(2 * v + 1) * lanes + lane] = uint32_t(uint64_t(val) >> 32);
+        }
+    };
+    UT S[N], zoh = ldv(0);
+#pragma unroll
+    for (int n = 0; n < N; n++) S[n] = ldv(1 + N * m + n);
+    UT cprev[N], cold[N];
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        cprev[n] = lid >= kW - m ? ldv(1 + n * m + (lid - (kW - m))) : UT(0);
+        cold[n] = cprev[n];
+    }
+
+    const T *const xl = x + lane * frames;
+    char *const yl = reinterpret_cast<char *>(y + lane * frames * R);
+    const size_t rounds = (frames + kW - 1) / kW;
+    // output mover: in store k, thread j moves piece 64 k + j of the block = piece j % PPT of frame (64 k + j) / PPT
+    int rd[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) rd[k] = ((k * kW + lid) / PPT) * PITCH + ((k * kW + lid) % PPT) * 16;
+
+    UT xn = lid < int(frames < size_t(kW) ? frames : size_t(kW)) ? UT(xl[lid]) : UT(0);
+    int nlast = 0;
+    for (size_t c = 0; c < rounds; c++) {
+        nlast = int(frames - c * kW < size_t(kW) ? frames - c * kW : size_t(kW));
+        UT v = xn;
+        {  // the next block's input: a block ahead, behind this block's stores in the queue
+            const size_t f = (c + 1) * kW + lid;
+            xn = f < frames ? UT(xl[f]) : UT(0);
+        }
+        // combs (src/cic.rs:166-171)
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+            const UT a = lane_get(v, lid - m), b = lane_get(cprev[n], lid - m);
+            cold[n] = cprev[n];
+            cprev[n] = v;
+            v -= lid >= m ? a : b;
+        }
+        zoh = lane_read(v, nlast - 1);
+        // the frame's map: A^R (state) + h v; thread 0 carries the incoming state
+        UT z[N];
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {
+            UT acc = S[i];
+#pragma unroll
+            for (int j = 0; j < i; j++) acc += coef.scan.g[0][i - j - 1] * S[j];
+            z[i] = (lid == 0 ? acc : UT(0)) + coef.h[i] * v;
+        }
+#pragma unroll
+        for (int k = 0; k < kSteps; k++) {
+            const int d = 1 << k;
+            UT w[N];
+#pragma unroll
+            for (int n = 0; n < N; n++) {
+                w[n] = lane_get(z[n], lid - d);
+                if (lid < d) w[n] = 0;
+            }
+#pragma unroll
+            for (int i = N - 1; i >= 0; i--) {
+                UT acc = w[i];
+#pragma unroll
+                for (int j = 0; j < i; j++) acc += coef.scan.g[k][i - j - 1] * w[j];
+                z[i] += acc;
+            }
+        }
+        // the state this frame starts from, and the block's successor state
+        UT pz[N];
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+            const UT p = lane_get(z[n], lid - 1);
+            pz[n] = lid == 0 ? S[n] : p;
+        }
+#pragma unroll
+        for (int n = 0; n < N; n++) S[n] = lane_read(z[n], nlast - 1);
+        // the frame's R outputs (src/cic.rs:174-180), PPT pieces into the tile
+        static_for_k<0, PPT>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            UT o[SPP];
+#pragma unroll
+            for (int e = 0; e < SPP; e++) {
+                UT t = v;
+#pragma unroll
+                for (int n = 0; n < N; n++) {
+                    pz[n] += t;
+                    t = pz[n];
+                }
+                o[e] = t;
+            }
+            u32x4 pc;
+            if constexpr (VW == 1)
+                pc = u32x4{uint32_t(o[0]), uint32_t(o[1]), uint32_t(o[2]), uint32_t(o[3])};
+            else
+                pc = u32x4{uint32_t(o[0]), uint32_t(uint64_t(o[0]) >> 32), uint32_t(o[1]), uint32_t(uint64_t(o[1]) >> 32)};
+            *reinterpret_cast<u32x4 *>(tile + lid * PITCH + i * 16) = pc;
+        });
+        lds_wave_sync();
+        char *dst = yl + c * size_t(kW * PPT * 16) + size_t(lid) * 16;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const u32x4 pc = *reinterpret_cast<const u32x4 *>(tile + rd[k]);
+            if ((k * kW + lid) / PPT < nlast) __builtin_nontemporal_store(pc, reinterpret_cast<u32x4 *>(dst + k * 1024));
+        }
+        lds_wave_sync();  // the tile has been read: the next block may overwrite it
+    }
+
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        const int p = nlast + lid - m;
+        const UT a = lane_get(cprev[n], p), b = lane_get(cold[n], p);
+        if (lid < m) stv(1 + n * m + lid, p >= 0 ? a : b);
+    }
+    if (lid == 0) {
+        stv(0, zoh);
+#pragma unroll
+        for (int n = 0; n < N; n++) stv(1 + N * m + n, S[n]);
+    }
+}
+
+// FRAME_MAJOR interpolator: x[f * lanes + l], y[(f * lanes + l) * R + r].  16 lanes = 16 waves per workgroup; the
+// arithmetic is the LANE_MAJOR kernel's.  A block's inputs (64 frames x 16 lanes) arrive as one 4- or 8-byte load per
+// thread — 64-byte runs — through a [64][17] LDS tile; the outputs of frame f, all 16 lanes, are 16 R sizeof(T)
+// contiguous bytes of y: they are collected in a [64 frames][16 lanes x R + one piece of padding] tile (conflict-free
+// 16-byte writes) and leave as whole-KiB stores.  Two workgroup barriers per block.
+constexpr int kFmLanes = 16;
+
+template <class T, int N, int PPT>
+__global__ __launch_bounds__(kFmLanes *kW) void cic_int_ring_fm(const IntCoef<T, N> coef, const int m, uint32_t *st, const T *x, T *y,
+                                                                 const size_t lanes, const size_t frames)
+{
+    using UT = typename std::make_unsigned<T>::type;
+    constexpr int VW = sizeof(T) / 4;
+    constexpr int SPP = 16 / int(sizeof(T));
+    constexpr int R = PPT * SPP;
+    constexpr int ROWP = kFmLanes * PPT;           // pieces per output row
+    constexpr int PITCH = (ROWP + 1) * 16;         // bytes per tile row
+    constexpr int XP = kFmLanes + 1;               // elements per input-tile row
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_cic[];
+    char *const tile = reinterpret_cast<char *>(smem_cic);
+    UT *const xin = reinterpret_cast<UT *>(tile + kW * PITCH);
+    const int lid = threadIdx.x % kW, w = __builtin_amdgcn_readfirstlane(threadIdx.x / kW);
+    const int q = threadIdx.x;
+    const size_t ngroups = lanes / kFmLanes, per = (ngroups + 7) / 8;
+    const size_t group = (blockIdx.x % 8) * per + blockIdx.x / 8;  // every XCD a contiguous eighth of the lane groups
+    if (group >= ngroups) return;
+    const size_t lane0 = group * kFmLanes, lane = lane0 + w;
+
+    auto ldv = [&](int v) -> UT {
+        if constexpr (VW == 1)
+            return UT(st[size_t(v) * lanes + lane]);
+        else
+            return UT(uint64_t(st[size_t(2 * v) * lanes + lane]) | (uint64_t(st[size_t(2 * v + 1) * lanes + lane]) << 32));
+    };
+    auto stv = [&](int v, UT val) {
+        if constexpr (VW == 1) {
+            st[size_t(v) * lanes + lane] = uint32_t(val);
+        } else {
+            st[size_t(2 * v) * lanes + lane] = uint32_t(val);
+            st[size_t(2 * v + 1) * lanes + lane] = uint32_t(uint64_t(val) >> 32);
+        }
+    };
+    UT S[N], zoh = ldv(0);
+#pragma unroll
+    for (int n = 0; n < N; n++) S[n] = ldv(1 + N * m + n);
+    UT cprev[N], cold[N];
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        cprev[n] = lid >= kW - m ? ldv(1 + n * m + (lid - (kW - m))) : UT(0);
+        cold[n] = cprev[n];
+    }
+
+    const size_t rounds = (frames + kW - 1) / kW;
+    // input mover: thread q fetches frame q / 16, lane q % 16 of the block
+    const int xf = q / kFmLanes, xlane = q % kFmLanes;
+    auto fetch = [&](size_t c) -> UT {
+        const size_t f = c * kW + xf;
+        return f < frames ? UT(x[f * lanes + lane0 + xlane]) : UT(0);
+    };
+    // output mover: in pass k, thread q moves piece k * 1024 + q of the block's [64][ROWP] pieces
+    int rrow[PPT], rcol[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        rrow[k] = (k * kFmLanes * kW + q) / ROWP;
+        rcol[k] = (k * kFmLanes * kW + q) % ROWP;
+    }
+    const size_t yrow = lanes * size_t(R) * sizeof(T);  // bytes per frame row of y
+    char *const ybase = reinterpret_cast<char *>(y) + lane0 * size_t(R) * sizeof(T);
+
+    UT xn = fetch(0);
+    int nlast = 0;
+    for (size_t c = 0; c < rounds; c++) {
+        nlast = int(frames - c * kW < size_t(kW) ? frames - c * kW : size_t(kW));
+        xin[xf * XP + xlane] = xn;
+        xn = fetch(c + 1);
+        lds_barrier();  // the input tile is complete; everybody has finished reading the output tile of the block before
+        UT v = xin[lid * XP + w];
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+            const UT a = lane_get(v, lid - m), b = lane_get(cprev[n], lid - m);
+            cold[n] = cprev[n];
+            cprev[n] = v;
+            v -= lid >= m ? a : b;
+        }
+        zoh = lane_read(v, nlast - 1);
+        UT z[N];
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {
+            UT acc = S[i];
+#pragma unroll
+            for (int j = 0; j < i; j++) acc += coef.scan.g[0][i - j - 1] * S[j];
+            z[i] = (lid == 0 ? acc : UT(0)) + coef.h[i] * v;
+        }
+#pragma unroll
+        for (int k = 0; k < kSteps; k++) {
+            const int d = 1 << k;
+            UT ww[N];
+#pragma unroll
+            for (int n = 0; n < N; n++) {
+                ww[n] = lane_get(z[n], lid - d);
+                if (lid < d) ww[n] = 0;
+            }
+#pragma unroll
+            for (int i = N - 1; i >= 0; i--) {
+                UT acc = ww[i];
+#pragma unroll
+                for (int j = 0; j < i; j++) acc += coef.scan.g[k][i - j - 1] * ww[j];
+                z[i] += acc;
+            }
+        }
+        UT pz[N];
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+            const UT p = lane_get(z[n], lid - 1);
+            pz[n] = lid == 0 ? S[n] : p;
+        }
+#pragma unroll
+        for (int n = 0; n < N; n++) S[n] = lane_read(z[n], nlast - 1);
+        static_for_k<0, PPT>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            UT o[SPP];
+#pragma unroll
+            for (int e = 0; e < SPP; e++) {
+                UT t = v;
+#pragma unroll
+                for (int n = 0; n < N; n++) {
+                    pz[n] += t;
+                    t = pz[n];
+                }
+                o[e] = t;
+            }
+            u32x4 pc;
+            if constexpr (VW == 1)
+                pc = u32x4{uint32_t(o[0]), uint32_t(o[1]), uint32_t(o[2]), uint32_t(o[3])};
+            else
+                pc = u32x4{uint32_t(o[0]), uint32_t(uint64_t(o[0]) >> 32), uint32_t(o[1]), uint32_t(uint64_t(o[1]) >> 32)};
+            *reinterpret_cast<u32x4 *>(tile + lid * PITCH + (w * PPT + i) * 16) = pc;
+        });
+        lds_barrier();  // the output tile is complete; everybody has read its input
+        char *dst = ybase + c * size_t(kW) * yrow;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const u32x4 pc = *reinterpret_cast<const u32x4 *>(tile + rrow[k] * PITCH + rcol[k] * 16);
+            if (rrow[k] < nlast) __builtin_nontemporal_store(pc, reinterpret_cast<u32x4 *>(dst + size_t(rrow[k]) * yrow + rcol[k] * 16));
+        }
+    }
+
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        const int p = nlast + lid - m;
+        const UT a = lane_get(cprev[n], p), b = lane_get(cold[n], p);
+        if (lid < m) stv(1 + n * m + lid, p >= 0 ? a : b);
+    }
+    if (lid == 0) {
+        stv(0, zoh);
+#pragma unroll
+        for (int n = 0; n < N; n++) stv(1 + N * m + n, S[n]);
+    }
+}
+
 }  // namespace cicr
 
 // 0: a ring kernel was launched; 1: shape not covered (the caller falls back to cic_kernels.h); 2: HIP error
 int cic_ring_dec(const idsp_cic *cfg, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, hipStream_t stream);
 int cic_ring_dec(const idsp_cic *cfg, uint32_t *st, const int64_t *x, int64_t *y, size_t lanes, size_t frames, hipStream_t stream);
+int cic_ring_int(const idsp_cic *cfg, uint32_t *st, const int32_t *x, int32_t *y, size_t lanes, size_t frames, bool lane_major,
+                 hipStream_t stream);
+int cic_ring_int(const idsp_cic *cfg, uint32_t *st, const int64_t *x, int64_t *y, size_t lanes, size_t frames, bool lane_major,
+                 hipStream_t stream);
 
 }  // namespace idsp
