@@ -346,7 +346,7 @@ def main():
         # lane counts that are not multiples of 256 (reference: any N in `Lanes<C>`, dsp-process/src/compose.rs:468): 65000 and
         # 100000 are multiples of 4 (LDS-DMA kernel with a ragged last block), 65537 is not (its last lane on a second stream); their
         # 256-multiples beside them
-        for lanes in (65536, 65000, 65537, 65532, 65540, 69632, 73728, 73731, 99840, 100000, 100001, 131072, 131076, 131073, 147456, 32769, 16385):
+        for lanes in (65536, 65000, 65537, 65532, 65540, 69632, 73728, 73731, 99840, 100000, 100001, 131072, 131076, 131073, 147456, 32768, 32769, 32771, 16384, 16385, 8193, 40001):
             biquad("biquad_i32_df1", torch.int32, 4, lanes, 4096, FM, 1, it, "ragged")
         for lanes in (65000, 65537, 100000):
             biquad("biquad_i32_df1", torch.int32, 4, lanes, 4096, LM, 1, it, "ragged")
