@@ -26,11 +26,11 @@ run() {  # name, command...
   rocprofv3 --pmc $SQ2 -d $O/$n/sq2 -o p -- "$@" > $O/$n.sq2.log 2>&1
   python tools/rocpd_summary.py stats $(find $O/$n/trace -name '*results.db' | head -1) > $O/${n}_kernel_stats.csv
   python tools/rocpd_summary.py pmc $(find $O/$n/fetch $O/$n/write $O/$n/sq $O/$n/sq2 -name '*results.db') > $O/${n}_pmc.csv
-  grep -h "^{" $O/$n.trace.log | tail -3 > $O/${n}_lines_under_rocprof.jsonl
+  grep -h "^{" $O/$n.trace.log | tail -12 > $O/${n}_lines_under_rocprof.jsonl
   rm -rf $O/$n  # the sqlite databases are large; the summaries are what gets committed
 }
 WHAT=${2:-all}
-# usage: collect_profiles_r04.sh [tag] [all | comma list of c2,c2df,c2lm,c5,c5s8,c3,c3lm,c4,c4lm]
+# usage: collect_profiles_r04.sh [tag] [all | comma list of c2,c2df,c2lm,c5,c5s8,c3,c3lm,c4,c4lm,cic]
 want() { [ "$WHAT" = all ] || echo ",$WHAT," | grep -q ",$1,"; }
 want c2 && run c2 python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --steps 100 --warmup 5
 want c2df && run c2_driverflags python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --steps 20 --warmup 5
@@ -42,4 +42,6 @@ want c3 && run c3 python bench.py --config c3 --no-cpu --steps 20 --warmup 5
 want c3lm && run c3_lanemajor python bench.py --config c3 --layout lane --no-cpu --steps 20 --warmup 5
 want c4 && run c4 python bench.py --config c4 --no-cpu --steps 20 --warmup 5
 want c4lm && run c4_lanemajor python bench.py --config c4 --layout lane --no-cpu --steps 20 --warmup 5
-for n in c2 c2_driverflags c2_lanemajor c5 c5_shard8 c3 c3_lanemajor c4 c4_lanemajor; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done
+# the Cic kernels at 16384 lanes x 4096 chunks of 16 (tools/perf_configs.py --only cic: one shape per kernel name)
+want cic && run cic python tools/perf_configs.py --only cic --iters 20
+for n in c2 c2_driverflags c2_lanemajor c5 c5_shard8 c3 c3_lanemajor c4 c4_lanemajor cic; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done
