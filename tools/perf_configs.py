@@ -448,6 +448,9 @@ def main():
         dds(65536, 4096, FM, it, "dds")
         cossin(1 << 27, it, "cossin")
         atan2(1 << 27, it, "atan2")
+    if sel and "ew" in sel:  # the element-wise entries alone
+        cossin(1 << 27, it, "cossin")
+        atan2(1 << 27, it, "atan2")
     if want("c4") or want("fm"):
         fm_disc(65536, 4096, FM, it, "fm")
         fm_disc(65536, 4096, LM, it, "fm")
