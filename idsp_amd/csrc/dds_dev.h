@@ -160,6 +160,10 @@ struct LpParams {
 
 template <int N, int K>
 struct LpBank {
+    using Params = LpParams;
+    static constexpr int kArmWords = 2 * N * K;  // state words of one arm
+    static constexpr bool kSixWaves = true;      // the six-wave form of lockin_waves_kernel is instantiated for this bank
+    static const char *name() { return nullptr; }
     int64_t s[K][N];
     __device__ __forceinline__ void load(const uint32_t *st, size_t lanes, size_t lane, int word0)
     {

@@ -15,6 +15,10 @@
 #include "dds_dev.h"
 
 namespace idsp {
+
+int lockin_waves_biquad_iq(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                           int layout, hipStream_t s);  // lockin_waves_biquad.hip
+
 namespace {
 
 typedef int32_t cplx_i32 __attribute__((ext_vector_type(2)));
@@ -273,6 +277,12 @@ int idsp_lockin_i32_biquad_process(const idsp_biquad_i32 *sections, size_t n, vo
     for (size_t k = 0; k < n; k++)
         if (sections[k].frac < 0 || sections[k].frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, sections[k].frac);
     if (lanes == 0 || frames == 0) return IDSP_OK;
+    // the multi-wave lock-in kernel with the biquad chain as its arm functor (lockin_waves_biquad.hip): FrameMajor always, LaneMajor
+    // for whole 16-frame batches on 16-byte aligned rows (IDSP_DIAG=1 IDSP_LOCKIN_NO_WAVES=1: the one-thread-per-lane kernels below)
+    static const bool no_waves = diag_env("IDSP_LOCKIN_NO_WAVES") != nullptr;
+    const bool lm_ok = frames % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0;
+    if (!no_waves && lanes < (size_t(1) << 28) && (layout == IDSP_FRAME_MAJOR || lm_ok))
+        return lockin_waves_biquad_iq(sections, n, state, x, y, lanes, frames, layout, as_stream(stream));
 #define IDSP_CALL(NS) run_biquad_phase<NS>(sections, state, x, y, lanes, frames, layout, as_stream(stream))
     IDSP_BY_SECTIONS(IDSP_CALL)
 #undef IDSP_CALL

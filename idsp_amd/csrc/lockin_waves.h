@@ -106,8 +106,11 @@ __device__ unsigned long long g_lw_wg[4096][8][3];  // [workgroup][wave]: s_memr
 
 constexpr int kLwFmRing = 5, kLwFmAhead = 4;  // FrameMajor DMA: LDS input ring slots, batches requested ahead
 
-template <int N, int K, int W, int IN, int MODE, int B>
-__global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN == IN_LM_REG || IN == IN_LM_DMA ? 2 : 10))) void lockin_waves_kernel(const LpParams prm, uint32_t *st, const int32_t *x,
+// Bank: the arm filter `C` of `Lockin<C>` (src/lockin.rs:11-15) as a register-resident functor — Params (by value in kernel arguments),
+// kArmWords state words per arm, load / store / step; `LpBank<N, K>` (dds_dev.h) for `[Lowpass<N>; K]`, `BqBank<NS>`
+// (lockin_waves_biquad.hip) for `[Biquad<Q32<F>>; NS]`.
+template <class Bank, int W, int IN, int MODE, int B>
+__global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN == IN_LM_REG || IN == IN_LM_DMA ? 2 : 10))) void lockin_waves_kernel(const typename Bank::Params prm, uint32_t *st, const int32_t *x,
                                                                  typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames)
 {
     using Out = typename LwOut<MODE>::type;
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     fill_cossin_circle(ctab, threadIdx.x, W * kWave);
     if (MODE == MODE_ARG && threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
     const uint32_t acc0 = st[la], inc = st[lanes + la];
-    LpBank<N, K> bank;
-    if (arm_wave) bank.load(st, lanes, la, 2 + (r ? 2 * N * K : 0));
+    Bank bank;
+    if (arm_wave) bank.load(st, lanes, la, 2 + (r ? Bank::kArmWords : 0));
     // The state loads must have landed HERE, in a way the compiler's wait-count pass sees: it cannot see the DMA requests, and a
     // first use of a state register inside the steady-state loop would be protected by `s_waitcnt vmcnt(0)` on every interval,
     // draining the input ring each time (lane_stream.h, stream_frame_major_lds).  vmcnt(0), expcnt / lgkmcnt untouched:
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #endif
     if (active && arm_wave) {
         if (r == 0) st[lane] = acc0 + inc * uint32_t(frames);
-        bank.store(st, lanes, lane, 2 + (r ? 2 * N * K : 0));
+        bank.store(st, lanes, lane, 2 + (r ? Bank::kArmWords : 0));
     }
 }
 
@@ -735,30 +738,27 @@ int launch_lockin_stages(const LpParams &p, void *state, const int32_t *x, void 
     return launch_status();
 }
 
-template <int MODE, int N, int K, int IN, int B>
-int launch_lockin_waves_in(const LpParams &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
+template <int MODE, class Bank, int IN, int B>
+int launch_lockin_waves_in(const typename Bank::Params &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
                            size_t frames, int waves, hipStream_t s)
 {
     const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
-    note_kernel(waves == 6 ? "lockin_waves_kernel[6 waves per 64 lanes]" : "lockin_waves_kernel[4 waves per 64 lanes]");
-    if (waves == 6)
-        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
-    else
-        hipLaunchKernelGGL((lockin_waves_kernel<N, K, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
+    note_kernel(waves == 6 ? "lockin_waves_kernel[6 waves per 64 lanes]" : "lockin_waves_kernel[4 waves per 64 lanes]", Bank::name());
+    if constexpr (Bank::kSixWaves) {
+        if (waves == 6) {
+            hipLaunchKernelGGL((lockin_waves_kernel<Bank, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
+            return launch_status();
+        }
+    }
+    hipLaunchKernelGGL((lockin_waves_kernel<Bank, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
     return launch_status();
 }
 
-template <int MODE, int N, int K>
-int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, void *yv, size_t lanes, size_t frames, int layout,
-                           int waves, hipStream_t s)
+// batch length and input form for a bank on the multi-wave kernel (`waves` from lockin_waves_for, dds.hip)
+template <int MODE, class Bank>
+int launch_lockin_waves_bank(const typename Bank::Params &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
+                             size_t frames, int layout, int waves, hipStream_t s)
 {
-    using Out = typename LwOut<MODE>::type;
-    uint32_t *st = static_cast<uint32_t *>(state);
-    Out *y = static_cast<Out *>(yv);
-    if constexpr (K == 2) {
-        if (const int groups = lockin_stage_groups(x, lanes, frames, layout, K, MODE == MODE_ARG))
-            return launch_lockin_stages<MODE, N>(p, state, x, yv, lanes, frames, groups, s);
-    }
     static const bool no_dma = diag_env("IDSP_LOCKIN_NO_DMA") != nullptr;
     // 16-frame batches halve the barriers per frame: 0.37 -> 0.35 ms (Complex<i32>), 0.61 -> 0.59 ms (arg) at 32768 lanes x 4096
     // frames, but 1.06 -> 1.19 ms (arg) at 65536 lanes, where the longer intervals cost more than the barriers
@@ -779,14 +779,26 @@ int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, voi
         // at 32768 lanes x 4096 frames, 0.94 -> 0.86 at 65536; its 32 KiB ring halves the workgroups a CU can hold, which
         // costs the 6-wave form and the arg read-out more than the input gains (tools/exp_lockin_lm.py)
         if (!no_dma && waves == 4 && MODE != MODE_ARG)
-            return launch_lockin_waves_in<MODE, N, K, IN_LM_DMA, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
-        return launch_lockin_waves_in<MODE, N, K, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
+            return launch_lockin_waves_in<MODE, Bank, IN_LM_DMA, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
+        return launch_lockin_waves_in<MODE, Bank, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
     }
     if (!no_dma && lanes % kWave == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
-        if (b16) return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s);
-        return launch_lockin_waves_in<MODE, N, K, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s);
+        if (b16) return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s);
+        return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s);
     }
-    return launch_lockin_waves_in<MODE, N, K, IN_FM_REG, kLwB>(p, st, x, y, lanes, frames, waves, s);
+    return launch_lockin_waves_in<MODE, Bank, IN_FM_REG, kLwB>(p, st, x, y, lanes, frames, waves, s);
+}
+
+template <int MODE, int N, int K>
+int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, void *yv, size_t lanes, size_t frames, int layout,
+                           int waves, hipStream_t s)
+{
+    using Out = typename LwOut<MODE>::type;
+    if constexpr (K == 2) {
+        if (const int groups = lockin_stage_groups(x, lanes, frames, layout, K, MODE == MODE_ARG))
+            return launch_lockin_stages<MODE, N>(p, state, x, yv, lanes, frames, groups, s);
+    }
+    return launch_lockin_waves_bank<MODE, LpBank<N, K>>(p, static_cast<uint32_t *>(state), x, static_cast<Out *>(yv), lanes, frames, layout, waves, s);
 }
 
 template <int MODE>

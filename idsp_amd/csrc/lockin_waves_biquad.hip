@@ -1,0 +1,66 @@
+// lockin_waves_biquad.hip — `Lockin<[Biquad<Q32<F>>; n]>`, phase form (src/lockin.rs:30-39 over src/iir/biquad.rs:366-383), on the
+// multi-wave lock-in kernel of lockin_waves.h: the biquad chain is one more arm functor (`Bank`) beside `[Lowpass<N>; K]`.  Round 4;
+// the one-thread-per-lane form (lockin_generic.hip) stays for the shapes the multi-wave kernel does not take.
+#include "biquad_sections.h"
+#include "lockin_waves.h"
+
+namespace idsp {
+namespace {
+
+// n serial DF1 sections, state words {x0, x1, y0, y1} per section at `word0` (the record of idsp_lockin_biquad_state_words)
+template <int NS>
+struct BqBank {
+    using Params = bq::ChainParams<bq::SecI32, NS>;
+    static constexpr int kArmWords = 4 * NS;
+    static constexpr bool kSixWaves = false;  // four waves per 64 lanes only: the arm waves are the long path with biquad arms
+    static const char *name() { return NS == 1 ? "[Biquad; 1]" : NS == 2 ? "[Biquad; 2]" : NS == 3 ? "[Biquad; 3]" : "[Biquad; 4]"; }
+    uint32_t s[NS][4];
+    __device__ __forceinline__ void load(const uint32_t *st, size_t lanes, size_t lane, int word0)
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) s[k][w] = st[size_t(word0 + k * 4 + w) * lanes + lane];
+    }
+    __device__ __forceinline__ void store(uint32_t *st, size_t lanes, size_t lane, int word0) const
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) st[size_t(word0 + k * 4 + w) * lanes + lane] = s[k][w];
+    }
+    __device__ __forceinline__ int32_t step(const Params &p, int32_t x)
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++) x = bq::Df1I32<false>::step(p.sec[k], s[k], x);
+        return x;
+    }
+};
+
+template <int NS>
+int run(const idsp_biquad_i32 *sec, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+{
+    typename BqBank<NS>::Params p;
+    for (int k = 0; k < NS; k++) {
+        for (int i = 0; i < 5; i++) p.sec[k].ba[i] = sec[k].ba[i];
+        p.sec[k].frac = sec[k].frac;
+        p.sec[k].u = 0, p.sec[k].mn = INT32_MIN, p.sec[k].mx = INT32_MAX;
+    }
+    return launch_lockin_waves_bank<MODE_IQ, BqBank<NS>>(p, static_cast<uint32_t *>(state), x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, 4, s);
+}
+
+}  // namespace
+
+// the caller (lockin_generic.hip) has validated the arguments and asked lockin_waves_for() whether the shape is the kernel's
+int lockin_waves_biquad_iq(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
+                           int layout, hipStream_t s)
+{
+    switch (n) {
+        case 1: return run<1>(sec, state, x, y, lanes, frames, layout, s);
+        case 2: return run<2>(sec, state, x, y, lanes, frames, layout, s);
+        case 3: return run<3>(sec, state, x, y, lanes, frames, layout, s);
+        default: return run<4>(sec, state, x, y, lanes, frames, layout, s);
+    }
+}
+
+}  // namespace idsp

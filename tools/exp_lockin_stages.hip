@@ -63,7 +63,7 @@ int run(size_t lanes, size_t frames)
     CHK(hipMemcpy(st_b, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
     CHK(hipMemset(ya, 0x55, lanes * frames * sizeof(Out)));
     CHK(hipMemset(yb, 0xAA, lanes * frames * sizeof(Out)));
-    auto ka = lockin_waves_kernel<N, 2, WA, IN_FM_DMA, MODE, BA>;
+    auto ka = lockin_waves_kernel<LpBank<N, 2>, WA, IN_FM_DMA, MODE, BA>;
     auto kb = lockin_stages_kernel<N, MODE, G, R>;
     const dim3 ga(unsigned(lanes / 64)), ba(WA * 64), gb(unsigned(lanes / (64 * G))), bb((4 + R) * G * 64);
     // two consecutive calls each (state carried over), then compare

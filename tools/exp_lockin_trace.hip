@@ -38,7 +38,7 @@ int run(size_t lanes, size_t frames, const char *name)
     for (size_t i = 0; i < hs.size(); i++) hs[i] = uint32_t(i * 2654435761u);
     CHK(hipMemcpy(st, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
     CHK(hipMemset(x, 1, lanes * frames * 4));
-    auto k = lockin_waves_kernel<2, 2, W, IN_FM_DMA, MODE, B>;
+    auto k = lockin_waves_kernel<LpBank<2, 2>, W, IN_FM_DMA, MODE, B>;
     int occ = 0;
     CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, W * 64, 0));
     hipFuncAttributes fa;

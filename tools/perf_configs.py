@@ -309,6 +309,42 @@ def fm_disc(lanes, frames, layout, iters, tag):
     report(f"{tag}:fm_disc {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample", 12 * lanes * frames, med, mn)
 
 
+def lockin_generic(form, n, lanes, frames, layout, iters, tag):
+    """`Lockin<C>` with biquad arms: form "phase" (idsp_lockin_i32_biquad_process), "lo" (i32, external LO), "lo_f32"
+    (the ddc_lockin graph); algorithmic bytes per sample: 4 in + 8 out (+ 8 of LO)"""
+    f32 = form == "lo_f32"
+    if f32:
+        q = _abi.BiquadF32()
+        call("biquad_f32_from_sos_f64", (C.c_double * 6)(*lowpass_sos(0.01)), C.byref(q))
+        cfg = (_abi.BiquadF32 * n)(*([q] * n))
+        x = torch.randn(lanes * frames, dtype=torch.float32, device=dev)
+        lo = torch.randn(2 * lanes * frames, dtype=torch.float32, device=dev)
+        y = torch.empty(2 * lanes * frames, dtype=torch.float32, device=dev)
+    else:
+        q = _abi.BiquadI32()
+        call("biquad_i32_from_sos", (C.c_double * 6)(*lowpass_sos(0.01)), 30, C.byref(q))
+        cfg = (_abi.BiquadI32 * n)(*([q] * n))
+        x = torch.randint(-(1 << 28), 1 << 28, (lanes * frames,), dtype=torch.int32, device=dev)
+        lo = torch.randint(-(1 << 31), (1 << 31) - 1, (2 * lanes * frames,), dtype=torch.int64, device=dev).to(torch.int32)
+        y = torch.empty(2 * lanes * frames, dtype=torch.int32, device=dev)
+    words = call("lockin_biquad_state_words", n, 1 if form == "phase" else 0)
+    st = torch.zeros((words, lanes), dtype=torch.int32, device=dev)
+    if form == "phase":
+        st[1] = torch.randint(-(1 << 31), (1 << 31) - 1, (lanes,), dtype=torch.int64, device=dev).to(torch.int32)
+
+        def run():
+            call("lockin_i32_biquad_process", C.cast(cfg, C.c_void_p), n, p(st), p(x), p(y), lanes, frames, layout, sptr())
+    else:
+        entry = "lockin_f32_biquad_lo_process" if f32 else "lockin_i32_biquad_lo_process"
+
+        def run():
+            call(entry, C.cast(cfg, C.c_void_p), n, p(st), p(x), p(lo), p(y), lanes, frames, layout, sptr())
+
+    med, mn = timeit(run, iters)
+    report(f"{tag}:lockin<biquad x{n}> {form} {'LM' if layout else 'FM'} {lanes}x{frames}", lanes * frames, "sample",
+           (12 if form == "phase" else 20) * lanes * frames, med, mn)
+
+
 def copy_ref(nbytes, iters):
     a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
     b = torch.empty_like(a)
@@ -448,6 +484,14 @@ def main():
         dds(65536, 4096, FM, it, "dds")
         cossin(1 << 27, it, "cossin")
         atan2(1 << 27, it, "atan2")
+    if want("lockinc"):  # `Lockin<C>` with biquad arms at the C4 shape (thread-per-lane stream kernels)
+        for layout in (FM, LM):
+            lockin_generic("phase", 1, 32768, 4096, layout, it, "C4g")
+            lockin_generic("lo", 1, 32768, 4096, layout, it, "C4g")
+            lockin_generic("lo_f32", 1, 32768, 4096, layout, it, "C4g")
+        lockin_generic("phase", 2, 32768, 4096, FM, it, "C4g")
+        lockin_generic("lo_f32", 2, 32768, 4096, FM, it, "C4g")
+        lockin_generic("phase", 1, 65536, 4096, FM, it, "C4g")
     if sel and "ew" in sel:  # the element-wise entries alone
         cossin(1 << 27, it, "cossin")
         atan2(1 << 27, it, "atan2")
