@@ -163,7 +163,9 @@ struct LpBank {
     using Params = LpParams;
     static constexpr int kArmWords = 2 * N * K;  // state words of one arm
     static constexpr bool kSixWaves = true;      // the six-wave form of lockin_waves_kernel is instantiated for this bank
+    static constexpr bool kExtLo = false;        // phase form: `Accu` -> cossin inside the kernel
     static const char *name() { return nullptr; }
+    static __device__ __forceinline__ int32_t mix(int32_t lo, int32_t x) { return __mulhi(lo, x); }  // src/lockin.rs:34-37
     int64_t s[K][N];
     __device__ __forceinline__ void load(const uint32_t *st, size_t lanes, size_t lane, int word0)
     {

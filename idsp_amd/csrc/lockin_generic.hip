@@ -16,13 +16,29 @@
 
 namespace idsp {
 
+// lockin_waves_biquad.hip: the multi-wave lock-in kernel with the biquad chain as its arm functor
 int lockin_waves_biquad_iq(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
-                           int layout, hipStream_t s);  // lockin_waves_biquad.hip
+                           int layout, hipStream_t s);
+int lockin_waves_biquad_lo(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes,
+                           size_t frames, int layout, hipStream_t s);
+int lockin_waves_lowpass_lo(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames,
+                            int layout, hipStream_t s);  // lockin_waves_lo.hip
+int lockin_waves_biquad_lo_f32(const idsp_biquad_f32 *sec, size_t n, void *state, const float *x, const float *lo, float *y, size_t lanes,
+                               size_t frames, int layout, hipStream_t s);
 
 namespace {
 
 typedef int32_t cplx_i32 __attribute__((ext_vector_type(2)));
 typedef float cplx_f32 __attribute__((ext_vector_type(2)));
+
+// Shapes the multi-wave kernel takes: FrameMajor always, LaneMajor for whole 16-frame batches on 16-byte aligned rows (as for
+// the lowpass arms, dds.hip lockin_waves_for).  IDSP_DIAG=1 IDSP_LOCKIN_NO_WAVES=1: the one-thread-per-lane kernels of this file.
+inline bool waves_take(const void *x, const void *y, size_t lanes, size_t frames, int layout)
+{
+    static const bool no_waves = diag_env("IDSP_LOCKIN_NO_WAVES") != nullptr;
+    const bool lm_ok = frames % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0;
+    return !no_waves && lanes < (size_t(1) << 28) && (layout == IDSP_FRAME_MAJOR || lm_ok);
+}
 
 // n serial sections on one arm, state words at `word0` (section-major, {x0,x1,y0,y1} each)
 template <class Sec, int NS>
@@ -277,12 +293,7 @@ int idsp_lockin_i32_biquad_process(const idsp_biquad_i32 *sections, size_t n, vo
     for (size_t k = 0; k < n; k++)
         if (sections[k].frac < 0 || sections[k].frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, sections[k].frac);
     if (lanes == 0 || frames == 0) return IDSP_OK;
-    // the multi-wave lock-in kernel with the biquad chain as its arm functor (lockin_waves_biquad.hip): FrameMajor always, LaneMajor
-    // for whole 16-frame batches on 16-byte aligned rows (IDSP_DIAG=1 IDSP_LOCKIN_NO_WAVES=1: the one-thread-per-lane kernels below)
-    static const bool no_waves = diag_env("IDSP_LOCKIN_NO_WAVES") != nullptr;
-    const bool lm_ok = frames % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0;
-    if (!no_waves && lanes < (size_t(1) << 28) && (layout == IDSP_FRAME_MAJOR || lm_ok))
-        return lockin_waves_biquad_iq(sections, n, state, x, y, lanes, frames, layout, as_stream(stream));
+    if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_biquad_iq(sections, n, state, x, y, lanes, frames, layout, as_stream(stream));
 #define IDSP_CALL(NS) run_biquad_phase<NS>(sections, state, x, y, lanes, frames, layout, as_stream(stream))
     IDSP_BY_SECTIONS(IDSP_CALL)
 #undef IDSP_CALL
@@ -296,6 +307,7 @@ int idsp_lockin_i32_lo_process(const idsp_lockin_i32 *cfg, void *state, const in
     int rc = check_lo_args(cfg, state, x, lo, y, lanes, frames, layout);
     if (rc) return rc;
     if (lanes == 0 || frames == 0) return IDSP_OK;
+    if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_lowpass_lo(cfg, state, x, lo, y, lanes, frames, layout, as_stream(stream));
     LpLoParams p;
     p.lp = lp_params(cfg);
     p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, frames};
@@ -324,6 +336,7 @@ int idsp_lockin_i32_biquad_lo_process(const idsp_biquad_i32 *sections, size_t n,
     for (size_t k = 0; k < n; k++)
         if (sections[k].frac < 0 || sections[k].frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, sections[k].frac);
     if (lanes == 0 || frames == 0) return IDSP_OK;
+    if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_biquad_lo(sections, n, state, x, lo, y, lanes, frames, layout, as_stream(stream));
 #define IDSP_CALL(NS) run_biquad_lo_i32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream))
     IDSP_BY_SECTIONS(IDSP_CALL)
 #undef IDSP_CALL
@@ -336,6 +349,7 @@ int idsp_lockin_f32_biquad_lo_process(const idsp_biquad_f32 *sections, size_t n,
     int rc = check_lo_args(sections, state, x, lo, y, lanes, frames, layout);
     if (rc) return rc;
     if (lanes == 0 || frames == 0) return IDSP_OK;
+    if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_biquad_lo_f32(sections, n, state, x, lo, y, lanes, frames, layout, as_stream(stream));
 #define IDSP_CALL(NS) run_biquad_lo_f32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream))
     IDSP_BY_SECTIONS(IDSP_CALL)
 #undef IDSP_CALL

@@ -111,8 +111,13 @@ constexpr int kLwFmRing = 5, kLwFmAhead = 4;  // FrameMajor DMA: LDS input ring 
 // (lockin_waves_biquad.hip) for `[Biquad<Q32<F>>; NS]`.
 template <class Bank, int W, int IN, int MODE, int B>
 __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN == IN_LM_REG || IN == IN_LM_DMA ? 2 : 10))) void lockin_waves_kernel(const typename Bank::Params prm, uint32_t *st, const int32_t *x,
-                                                                 typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames)
+                                                                 typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames,
+                                                                 const int32_t *lo_ext)
 {
+    // Bank::kExtLo: the oscillator is not `Accu` -> cossin but a per-sample `Complex` the caller supplies (src/lockin.rs:17-27):
+    // lo_ext[index(f, l) * 2 + {re, im}], same layout as x.  The record then has no accumulator words, no table is built, and the
+    // read-out waves fetch their share of the next batch's LO one interval ahead into registers.  Bank::mix is the mixer product
+    // (i32: the high word, dsp-fixedpoint/src/lib.rs:449-456; f32: one rounded multiply on the bit patterns).
     using Out = typename LwOut<MODE>::type;
     constexpr bool LMD = IN == IN_LM_DMA, LM = IN == IN_LM_REG || LMD, DMA = IN == IN_FM_DMA;
     // Where the mixer multiply `x * lo` (src/lockin.rs:34-37) runs: with the input in LDS (both DMA forms) the read-out waves
@@ -126,7 +131,9 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     constexpr int P = W - 2, C = B / P;  // read-out waves; each takes frames r C .. r C + C - 1 of a batch
     constexpr int RS = B + 4;            // row pitch in words
     static_assert(B % P == 0 && B % 8 == 0 && (C == 2 || C % 4 == 0), "batch splits evenly over the read-out waves, into 4-row DMA groups per arm wave, into vectors");
-    __shared__ __attribute__((aligned(16))) uint32_t ctab[kCosCircleWords];
+    constexpr bool EXT = Bank::kExtLo;
+    constexpr int SB = EXT ? 0 : 2;  // state words before the arms: accu.state, accu.step
+    __shared__ __attribute__((aligned(16))) uint32_t ctab[EXT ? 4 : kCosCircleWords];
     __shared__ uint32_t tab[32];
     // rows[buffer][I / Q][lane]: batch n lives in buffer n % 3 — written by the read-out waves (LO or mixed samples) during
     // interval n - 1, turned into the arm outputs IN PLACE by the arm waves during interval n, read back by the read-out waves
@@ -166,11 +173,12 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     const size_t lane = size_t(blockIdx.x) * kWave + lid;
     const bool active = lane < lanes;
     const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
-    fill_cossin_circle(ctab, threadIdx.x, W * kWave);
+    if constexpr (!EXT) fill_cossin_circle(ctab, threadIdx.x, W * kWave);
     if (MODE == MODE_ARG && threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
-    const uint32_t acc0 = st[la], inc = st[lanes + la];
+    uint32_t acc0 = 0, inc = 0;
+    if constexpr (!EXT) acc0 = st[la], inc = st[lanes + la];
     Bank bank;
-    if (arm_wave) bank.load(st, lanes, la, 2 + (r ? Bank::kArmWords : 0));
+    if (arm_wave) bank.load(st, lanes, la, SB + (r ? Bank::kArmWords : 0));
     // The state loads must have landed HERE, in a way the compiler's wait-count pass sees: it cannot see the DMA requests, and a
     // first use of a state register inside the steady-state loop would be protected by `s_waitcnt vmcnt(0)` on every interval,
     // draining the input ring each time (lane_stream.h, stream_frame_major_lds).  vmcnt(0), expcnt / lgkmcnt untouched:
@@ -243,6 +251,19 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #endif
     int slot_issue = 0, slot_read = 0;  // FM DMA ring positions of the next request (arm waves) / the next batch mixed (read-out waves)
 
+    // external LO: frames r C .. r C + C - 1 of batch n for this thread's lane, one interval ahead (frames past the end: zero)
+    typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+    i32x2 lon[EXT ? C : 1];
+    auto lo_fetch = [&](size_t n) {
+        if constexpr (EXT) {
+            const i32x2 *l2 = reinterpret_cast<const i32x2 *>(lo_ext);
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const size_t f = n * B + size_t(r * C + j);
+                lon[j] = f < frames ? (LM ? l2[la * frames + f] : l2[f * lanes + la]) : i32x2{0, 0};
+            }
+        }
+    };
     // ---- read-out waves, first half of an interval: cos / sin (and, with the input in LDS, the mixer) of batch n into `dstb`
     auto lo_stage = [&](size_t n, int dstb) {
         int32_t re[C], im[C], xv[C];
@@ -261,22 +282,31 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
             }
         }
         LW_T(0);
-        // all table reads of the batch first, behind one wait (see lockin_stages_kernel)
-        uint32_t pj[C];
-        CosCircleEntry ent[C];
+        if constexpr (EXT) {
 #pragma unroll
-        for (int j = 0; j < C; j++) {
-            pj[j] = phase + inc * uint32_t(r * C + j + 1);
-            ent[j] = cossin_circle_fetch(pj[j], ctab);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < C; j++) {
+                re[j] = MIXR ? Bank::mix(lon[j].x, xv[j]) : lon[j].x;
+                im[j] = MIXR ? Bank::mix(lon[j].y, xv[j]) : lon[j].y;
+            }
+            lo_fetch(n + 1);  // this wave's share of the batch after: in flight during the interval
+        } else {
+            // all table reads of the batch first, behind one wait (see lockin_stages_kernel)
+            uint32_t pj[C];
+            CosCircleEntry ent[C];
 #pragma unroll
-        for (int j = 0; j < C; j++) {
-            const Cplx lo = cossin_circle_finish(pj[j], ent[j]);
-            re[j] = MIXR ? __mulhi(lo.re, xv[j]) : lo.re;
-            im[j] = MIXR ? __mulhi(lo.im, xv[j]) : lo.im;
+            for (int j = 0; j < C; j++) {
+                pj[j] = phase + inc * uint32_t(r * C + j + 1);
+                ent[j] = cossin_circle_fetch(pj[j], ctab);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const Cplx lo = cossin_circle_finish(pj[j], ent[j]);
+                re[j] = MIXR ? Bank::mix(lo.re, xv[j]) : lo.re;
+                im[j] = MIXR ? Bank::mix(lo.im, xv[j]) : lo.im;
+            }
+            phase += inc * uint32_t(B);
         }
-        phase += inc * uint32_t(B);
         LW_T(1);
         row_store<C>(&rows[dstb][0][lid * RS + r * C], re);
         row_store<C>(&rows[dstb][1][lid * RS + r * C], im);
@@ -407,7 +437,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
                 if constexpr (MIXR)
                     v[b] = bank.step(prm, v[b]);
                 else
-                    v[b] = bank.step(prm, __mulhi(v[b], xv[b]));
+                    v[b] = bank.step(prm, Bank::mix(v[b], xv[b]));
             }
         }
         LW_T(2);
@@ -449,6 +479,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
         }
     }
     __syncthreads();  // tables, first input batches
+    if (!arm_wave) lo_fetch(0);
     if (!arm_wave) lo_stage(0, 0);
     __syncthreads();
     const size_t nfull = frames / B;
@@ -532,8 +563,10 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     }
 #endif
     if (active && arm_wave) {
-        if (r == 0) st[lane] = acc0 + inc * uint32_t(frames);
-        bank.store(st, lanes, lane, 2 + (r ? Bank::kArmWords : 0));
+        if constexpr (!EXT) {
+            if (r == 0) st[lane] = acc0 + inc * uint32_t(frames);
+        }
+        bank.store(st, lanes, lane, SB + (r ? Bank::kArmWords : 0));
     }
 }
 
@@ -740,24 +773,24 @@ int launch_lockin_stages(const LpParams &p, void *state, const int32_t *x, void 
 
 template <int MODE, class Bank, int IN, int B>
 int launch_lockin_waves_in(const typename Bank::Params &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
-                           size_t frames, int waves, hipStream_t s)
+                           size_t frames, int waves, hipStream_t s, const int32_t *lo)
 {
     const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
     note_kernel(waves == 6 ? "lockin_waves_kernel[6 waves per 64 lanes]" : "lockin_waves_kernel[4 waves per 64 lanes]", Bank::name());
     if constexpr (Bank::kSixWaves) {
         if (waves == 6) {
-            hipLaunchKernelGGL((lockin_waves_kernel<Bank, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames);
+            hipLaunchKernelGGL((lockin_waves_kernel<Bank, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames, lo);
             return launch_status();
         }
     }
-    hipLaunchKernelGGL((lockin_waves_kernel<Bank, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames);
+    hipLaunchKernelGGL((lockin_waves_kernel<Bank, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames, lo);
     return launch_status();
 }
 
 // batch length and input form for a bank on the multi-wave kernel (`waves` from lockin_waves_for, dds.hip)
 template <int MODE, class Bank>
 int launch_lockin_waves_bank(const typename Bank::Params &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
-                             size_t frames, int layout, int waves, hipStream_t s)
+                             size_t frames, int layout, int waves, hipStream_t s, const int32_t *lo = nullptr)
 {
     static const bool no_dma = diag_env("IDSP_LOCKIN_NO_DMA") != nullptr;
     // 16-frame batches halve the barriers per frame: 0.37 -> 0.35 ms (Complex<i32>), 0.61 -> 0.59 ms (arg) at 32768 lanes x 4096
@@ -779,14 +812,14 @@ int launch_lockin_waves_bank(const typename Bank::Params &p, uint32_t *st, const
         // at 32768 lanes x 4096 frames, 0.94 -> 0.86 at 65536; its 32 KiB ring halves the workgroups a CU can hold, which
         // costs the 6-wave form and the arg read-out more than the input gains (tools/exp_lockin_lm.py)
         if (!no_dma && waves == 4 && MODE != MODE_ARG)
-            return launch_lockin_waves_in<MODE, Bank, IN_LM_DMA, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
-        return launch_lockin_waves_in<MODE, Bank, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s);
+            return launch_lockin_waves_in<MODE, Bank, IN_LM_DMA, kLwBLm>(p, st, x, y, lanes, frames, waves, s, lo);
+        return launch_lockin_waves_in<MODE, Bank, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s, lo);
     }
     if (!no_dma && lanes % kWave == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
-        if (b16) return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s);
-        return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s);
+        if (b16) return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s, lo);
+        return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s, lo);
     }
-    return launch_lockin_waves_in<MODE, Bank, IN_FM_REG, kLwB>(p, st, x, y, lanes, frames, waves, s);
+    return launch_lockin_waves_in<MODE, Bank, IN_FM_REG, kLwB>(p, st, x, y, lanes, frames, waves, s, lo);
 }
 
 template <int MODE, int N, int K>

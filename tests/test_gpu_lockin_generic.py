@@ -106,3 +106,44 @@ def test_ddc_lockin_example_recovers_dc_iq_on_hip():
     for l in range(lanes):
         assert abs(got[l, :, 0].mean() - exps[l][0]) < 3e-3 and abs(got[l, :, 1].mean() - exps[l][1]) < 3e-3
         assert np.sqrt(((got[l] - np.array(exps[l])) ** 2).sum(axis=1).mean()) < 6e-3
+
+
+def test_biquad_arms_run_on_the_multi_wave_kernel():
+    """Which kernel: FrameMajor always, LaneMajor for whole 16-frame batches on aligned rows -> `lockin_waves_kernel` with the biquad
+    chain as its arm functor (lockin_waves_biquad.hip); every other LaneMajor shape -> the one-thread-per-lane stream kernels."""
+    import os
+
+    if os.environ.get("IDSP_LOCKIN_NO_WAVES"):
+        pytest.skip("forced onto the stream kernels")
+    e = H.engine()
+    rng = np.random.default_rng(77)
+    arr, _ = G.sections_i32(2, rng)
+    arrf, _ = G.sections_f32(2, rng)
+    for lanes, frames, layout, waves in ((200, 37, FM, True), (128, 64, LM, True), (128, 40, LM, False)):
+        x = dev(rng.integers(-(1 << 28), 1 << 28, lanes * frames, dtype=np.int32))
+        lo = dev(rng.integers(-(1 << 31), (1 << 31) - 1, lanes * frames * 2, dtype=np.int64).astype(np.int32))
+        y = torch.empty(lanes * frames * 2, dtype=torch.int32, device=DEV)
+        st = torch.zeros((2 + 16, lanes), dtype=torch.int32, device=DEV)
+        assert e.stream("lockin_i32_biquad_process", arr, 2, st, x, y, lanes, frames, layout) == 0
+        assert e.last_kernel().startswith("lockin_waves_kernel[4 waves per 64 lanes]<[Biquad; 2]") == waves, e.last_kernel()
+        assert G.call_lo(e, "lockin_i32_biquad_lo_process", arr, 2, st[2:], x, lo, y, lanes, frames, layout, True) == 0
+        assert e.last_kernel().startswith("lockin_waves_kernel[4 waves per 64 lanes]<[Biquad; 2], LO") == waves, e.last_kernel()
+        xf, lof, yf = x.view(torch.float32), lo.view(torch.float32), y.view(torch.float32)
+        assert G.call_lo(e, "lockin_f32_biquad_lo_process", arrf, 2, st[2:], xf, lof, yf, lanes, frames, layout, True) == 0
+        assert e.last_kernel().startswith("lockin_waves_kernel[4 waves per 64 lanes]<[Biquad<f32>; 2], LO") == waves, e.last_kernel()
+    torch.cuda.synchronize()
+
+
+def test_stream_kernel_forms_stay_covered():
+    """The one-thread-per-lane processors of lockin_generic.hip are the fall-back for LaneMajor shapes only now: replay this file with
+    the multi-wave kernel switched off so that their FrameMajor forms keep meeting the oracle too."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("IDSP_LOCKIN_NO_WAVES"):
+        pytest.skip("inner run")
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_LOCKIN_NO_WAVES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_lockin_generic.py", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
