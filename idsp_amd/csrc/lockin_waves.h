@@ -34,10 +34,23 @@ enum { IN_FM_REG = 0, IN_FM_DMA = 1, IN_LM_REG = 2, IN_LM_DMA = 3 };
 // LaneMajor DMA: ring slots of one PAIR of batches (8 KiB) each, pairs requested ahead.  Three slots keep the workgroup at
 // 70 KiB of LDS, so that two of them share a CU (four slots: 78 KiB, measured slower: 0.457 against 0.42-0.44 ms at C4)
 constexpr int kLwRing = 3, kLwAhead = 2;
+// LaneMajor: batches a read-out thread holds in registers and stores together.  Round 4 (tools/exp_lockin_ablate.hip): with the
+// global stores switched off the LaneMajor kernel runs as fast as the FrameMajor one (0.22 ms at C4), with the input requests
+// switched off it is the stores that cost (0.38 against 0.265 ms), and they cost nothing extra at a row pitch of 32 KiB + 512 B:
+// every lane writes the same offset of its row at the same time, and at a power-of-two pitch those lines meet in the memory
+// channels.  Four lines (512 bytes) per lane in one burst: 0.38 -> 0.254 ms without the requests, 0.436 -> 0.357 with them, eight
+// 0.348; two, three or six lines per burst change nothing.  (Round 2 had measured "no gain at 4" on the form that left 16-byte pieces.)
 #ifndef IDSP_LW_OUT_GROUP
-#define IDSP_LW_OUT_GROUP 1
+#define IDSP_LW_OUT_GROUP 8
 #endif
-constexpr int kLwOutGroup = IDSP_LW_OUT_GROUP;  // LaneMajor: batches a read-out thread stores together
+constexpr int kLwLineGroup = IDSP_LW_OUT_GROUP;  // the whole-line form (8-byte elements, two read-out waves); external LO: 4
+constexpr int kLwPieceGroup = 1;                 // the 16-byte-piece form
+// The other half of the same finding: workgroups that start together stay in phase, and all of them read line p and write line
+// q of their rows at the same time.  A start-up stagger over the CUs of an XCD — workgroup b waits ((b >> 4) % 4) steps of
+// `skew` ticks (10 ns each; workgroup b runs on XCD b % 8) — buys more than it costs: 0.357 -> 0.328-0.335 ms at C4 for steps of
+// 5-13 us and moduli 3-8, including the 15-40 us the last group waits (shifts 0-2 and 6-8, i.e. phases per XCD or per
+// workgroup pair, gain nothing).  Which launches: launch_lockin_waves_in.
+constexpr unsigned kLwSkewTicks = 600;
 #ifndef IDSP_LW_LM_LINES
 #define IDSP_LW_LM_LINES 1  // LaneMajor, 8-byte elements: whole 128-byte lines per store instruction
 #endif
@@ -106,13 +119,34 @@ __device__ unsigned long long g_lw_wg[4096][8][3];  // [workgroup][wave]: s_memr
 
 constexpr int kLwFmRing = 5, kLwFmAhead = 4;  // FrameMajor DMA: LDS input ring slots, batches requested ahead
 
+// tools/exp_lockin_ablate.hip: the same kernel without its global stores / without its input requests (conditions that are
+// never true at run time, so that the instruction stream stays)
+#ifdef IDSP_LW_ABL_NOSTORE
+#define LW_ST_ON (frames == 1)
+#else
+#define LW_ST_ON true
+#endif
+#ifdef IDSP_LW_ABL_NOLOAD
+#define LW_LD_ON (frames == 1)
+#else
+#define LW_LD_ON true
+#endif
+#ifdef IDSP_LW_ABL_PLAINSTORE
+#define LW_NT_STORE(v, p) (*(p) = (v))
+#else
+#define LW_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+#ifdef IDSP_LW_ABL_SKEW
+__device__ unsigned g_lw_skew[4096];  // workgroup b starts g_lw_skew[b] ticks of 10 ns late (instead of the `skew` argument's pattern)
+#endif
+
 // Bank: the arm filter `C` of `Lockin<C>` (src/lockin.rs:11-15) as a register-resident functor — Params (by value in kernel arguments),
 // kArmWords state words per arm, load / store / step; `LpBank<N, K>` (dds_dev.h) for `[Lowpass<N>; K]`, `BqBank<NS>`
 // (lockin_waves_biquad.hip) for `[Biquad<Q32<F>>; NS]`.
 template <class Bank, int W, int IN, int MODE, int B>
 __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN == IN_LM_REG || IN == IN_LM_DMA ? 2 : 10))) void lockin_waves_kernel(const typename Bank::Params prm, uint32_t *st, const int32_t *x,
                                                                  typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames,
-                                                                 const int32_t *lo_ext)
+                                                                 const int32_t *lo_ext, const unsigned skew)
 {
     // Bank::kExtLo: the oscillator is not `Accu` -> cossin but a per-sample `Complex` the caller supplies (src/lockin.rs:17-27):
     // lo_ext[index(f, l) * 2 + {re, im}], same layout as x.  The record then has no accumulator words, no table is built, and the
@@ -120,6 +154,14 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     // (i32: the high word, dsp-fixedpoint/src/lib.rs:449-456; f32: one rounded multiply on the bit patterns).
     using Out = typename LwOut<MODE>::type;
     constexpr bool LMD = IN == IN_LM_DMA, LM = IN == IN_LM_REG || LMD, DMA = IN == IN_FM_DMA;
+#ifdef IDSP_LW_ABL_SKEW
+    if (const long long d = g_lw_skew[blockIdx.x % 4096]) {
+#else
+    if (const long long d = (long long)(skew) * ((blockIdx.x >> 4) & 3u)) {
+#endif
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
     // Where the mixer multiply `x * lo` (src/lockin.rs:34-37) runs: with the input in LDS (both DMA forms) the read-out waves
     // apply it while they hold cos / sin, and the rows carry the mixed samples — the arm waves are then the two lowpass
     // chains and nothing else (14 VALU instructions per frame for [Lowpass<2>; 2]); with register prefetch the input lives in
@@ -211,6 +253,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     // (whole groups: wave-uniform row base in SGPRs + this thread's constant 32-bit offset, no per-request address arithmetic)
     const uint32_t dma_off = uint32_t(lid / 16) * uint32_t(lanes) * 4u + uint32_t(lid % 16) * 16u;  // launcher: 3 lanes * 4 < 2^32
     auto dma = [&](size_t n, int slot) {
+        if (!LW_LD_ON) return;
 #pragma unroll
         for (int g = 0; g < B / 8; g++) {
             const int r0 = r * (B / 2) + 4 * g;  // first of the 4 rows this instruction moves
@@ -233,6 +276,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     // operations per arm wave.
     auto dma_lm = [&](size_t pair) {
         if constexpr (LMD) {
+            if (!LW_LD_ON) return;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int j = 4 * r + g;
@@ -320,31 +364,41 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
         else
             return int64_t(uint64_t(int64_t(re) * re) + uint64_t(int64_t(im) * im));  // wraps for (MIN, MIN) as in release
     };
-    // LaneMajor: a read-out thread keeps its pieces of kLwOutGroup batches in registers and stores them together (kept as a
-    // knob: measured equal at 1 and 4, the form is not bound by its output run length)
+    // LaneMajor: a read-out thread keeps its pieces of kLwOutGroup batches in registers and stores them together
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int GV = int(sizeof(Out)) * C / 16;  // 16-byte vectors a read-out thread writes per batch (LaneMajor)
+    constexpr bool LINES = LM && sizeof(Out) == 8 && P == 2 && B == 16 && IDSP_LW_LM_LINES;
+    // (eight lines: 0.334 -> 0.325 ms at C4 with 224 registers; the external-LO forms also hold the next batch's LO and keep four)
+    constexpr int kLwOutGroup = !LINES ? kLwPieceGroup : Bank::kExtLo && kLwLineGroup > 4 ? 4 : kLwLineGroup;
     u32x4 held[LM ? kLwOutGroup : 1][LM ? GV : 1];
     // ---- read-out waves, second half: the arm outputs of the batch that starts at frame f0 (buffer srcb) become output elements.
     // `slot` (static): position of the batch inside its output group; `flush`: last batch of the call
     auto out_stage = [&](size_t f0, int srcb, int nb, auto full, auto slot_tag, bool flush) {
-        if constexpr (LM && sizeof(Out) == 8 && P == 2 && B == 16 && kLwOutGroup == 1 && IDSP_LW_LM_LINES) {
+        if constexpr (LINES) {
             // Whole 128-byte lines per store instruction (round 3, later): a batch of 8-byte elements is one line per lane.  Read-out
             // wave r takes lanes 32 r .. 32 r + 31; in instruction v thread t holds frames 2 (t % 8), 2 (t % 8) + 1 of lane
             // 32 r + 8 v + t / 8, so the 8 threads of a lane write its line and one instruction writes 8 whole lines (the form below
             // leaves two 16-byte pieces in each of 32 lines per instruction).  The arm outputs come out of the rows as 8-byte reads.
+            constexpr int slot = decltype(slot_tag)::value;
             const int piece = lid % 8;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int ll = r * 32 + v * 8 + lid / 8;
-                const size_t gl = size_t(blockIdx.x) * kWave + size_t(ll);
                 int32_t re[2], im[2];
                 row_load<2>(&rows[srcb][0][ll * RS + 2 * piece], re);
                 row_load<2>(&rows[srcb][1][ll * RS + 2 * piece], im);
                 const uint64_t u0 = __builtin_bit_cast(uint64_t, element(re[0], im[0])), u1 = __builtin_bit_cast(uint64_t, element(re[1], im[1]));
-                if (gl < lanes)
-                    __builtin_nontemporal_store(u32x4{uint32_t(u0), uint32_t(u0 >> 32), uint32_t(u1), uint32_t(u1 >> 32)},
-                                                reinterpret_cast<u32x4 *>(y + gl * frames + f0) + piece);
+                held[slot][v] = u32x4{uint32_t(u0), uint32_t(u0 >> 32), uint32_t(u1), uint32_t(u1 >> 32)};
+            }
+            if (slot == kLwOutGroup - 1 || flush) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const size_t gl = size_t(blockIdx.x) * kWave + size_t(r * 32 + v * 8 + lid / 8);
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(y + gl * frames + (f0 - size_t(slot) * B)) + piece;
+#pragma unroll
+                    for (int q = 0; q <= slot; q++)
+                        if (gl < lanes && LW_ST_ON) LW_NT_STORE(held[q][v], dst + q * 8);
+                }
             }
         } else if constexpr (LM) {
             // read-out wave r writes lanes r * 64 / P ..: P adjacent threads cover the B frames of one lane, so that one store
@@ -389,7 +443,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
             const uint32_t off = lane32 * uint32_t(sizeof(Out));
 #pragma unroll
             for (int j = 0; j < C; j++) {
-                if ((decltype(full)::value || r * C + j < nb) && active)
+                if ((decltype(full)::value || r * C + j < nb) && active && LW_ST_ON)
                     nt_store<true>(reinterpret_cast<Out *>(row + size_t(off)), element(re[j], im[j]));  // 8-byte elements leave as one 2-word vector
                 row += lanes * sizeof(Out);
             }
@@ -498,7 +552,9 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #ifndef IDSP_LW_PRIO
 #define IDSP_LW_PRIO 3
 #endif
-    auto interval = [&](size_t n, int nb, auto full, auto slot_tag) {
+    // The two roles run the intervals in loops of their own (round 4): inside one loop the arm state and the read-out waves' held
+    // output vectors are all loop-carried values of the same thread and their registers add up; in two loops they overlay.
+    auto interval = [&](size_t n, int nb, auto full, auto slot_tag, auto arm_tag) {
 #ifdef IDSP_LW_PRIO_BY_ROLE  // experiment: a fixed priority per role (arm waves IDSP_LW_PRIO_BY_ROLE, read-out waves 0) instead of the alternation
         if (n == 0) {
             if (arm_wave)
@@ -514,7 +570,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
                 __builtin_amdgcn_s_setprio(0);
         }
 #endif
-        if (arm_wave) {
+        if constexpr (decltype(arm_tag)::value) {
             arm_stage(n, cur, nb, full);
         } else {
             if (n + 1 < nbatch) lo_stage(n + 1, next3(cur));
@@ -524,30 +580,39 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
         LW_T(5);
         cur = next3(cur);
     };
-    if constexpr (LM) {
-        // whole batches only (launcher): batch n - 1 leaves in interval n, its group slot (n - 1) % kLwOutGroup is static
-        interval(0, B, std::true_type{}, Slot0{});
-        size_t n = 1;
-        while (n < nfull)
-            static_for<kLwOutGroup>([&](auto q) {
-                if (n < nfull) {
-                    interval(n, B, std::true_type{}, q);
-                    n++;
-                }
-            });
-        if (!arm_wave)
-            static_for<kLwOutGroup>([&](auto q) {
-                if (int((nfull - 1) % kLwOutGroup) == decltype(q)::value) out_stage((nfull - 1) * B, prev3(cur), B, std::true_type{}, q, true);
-            });
-    } else {
-        for (size_t n = 0; n < nfull; n++) interval(n, B, std::true_type{}, Slot0{});
-        if (tail) {
-            interval(nfull, tail, std::false_type{}, Slot0{});
-            if (!arm_wave) out_stage(nfull * B, prev3(cur), tail, std::false_type{}, Slot0{}, true);
-        } else if (!arm_wave) {
-            out_stage((nfull - 1) * B, prev3(cur), B, std::true_type{}, Slot0{}, true);
+    auto run_role = [&](auto arm_tag) {
+        constexpr bool ARM = decltype(arm_tag)::value;
+        if constexpr (LM && ARM) {
+            for (size_t n = 0; n < nfull; n++) interval(n, B, std::true_type{}, Slot0{}, arm_tag);  // whole batches only (launcher)
+        } else if constexpr (LM) {
+            // batch n - 1 leaves in interval n, its group slot (n - 1) % kLwOutGroup is static
+            interval(0, B, std::true_type{}, Slot0{}, arm_tag);
+            size_t n = 1;
+            while (n < nfull)
+                static_for<kLwOutGroup>([&](auto q) {
+                    if (n < nfull) {
+                        interval(n, B, std::true_type{}, q, arm_tag);
+                        n++;
+                    }
+                });
+            if constexpr (!ARM)
+                static_for<kLwOutGroup>([&](auto q) {
+                    if (int((nfull - 1) % kLwOutGroup) == decltype(q)::value) out_stage((nfull - 1) * B, prev3(cur), B, std::true_type{}, q, true);
+                });
+        } else {
+            for (size_t n = 0; n < nfull; n++) interval(n, B, std::true_type{}, Slot0{}, arm_tag);
+            if (tail) {
+                interval(nfull, tail, std::false_type{}, Slot0{}, arm_tag);
+                if constexpr (!ARM) out_stage(nfull * B, prev3(cur), tail, std::false_type{}, Slot0{}, true);
+            } else if constexpr (!ARM) {
+                out_stage((nfull - 1) * B, prev3(cur), B, std::true_type{}, Slot0{}, true);
+            }
         }
-    }
+    };
+    if (arm_wave)
+        run_role(std::true_type{});
+    else
+        run_role(std::false_type{});
 #ifdef IDSP_LW_TRACE
     if (lid == 0 && blockIdx.x < 4096) {
         unsigned hw, xcc;
@@ -776,14 +841,20 @@ int launch_lockin_waves_in(const typename Bank::Params &p, uint32_t *st, const i
                            size_t frames, int waves, hipStream_t s, const int32_t *lo)
 {
     const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
+    // start-up stagger (see kLwSkewTicks): LaneMajor launches that fill the chip, long enough for the wait to pay
+    // (IDSP_DIAG=1 IDSP_LOCKIN_NO_SKEW=1: none)
+    static const bool no_skew = diag_env("IDSP_LOCKIN_NO_SKEW") != nullptr;
+    // (one workgroup per CU: 16384 x 4096 0.217 -> 0.225 ms with it; 32768 lanes x 2048 frames 0.187 -> 0.179, x 4096 0.350 -> 0.323,
+    // x 16384 1.335 -> 1.358: long calls drift apart by themselves; 65536 x 4096 0.696 -> 0.640)
+    const unsigned skew = (IN == IN_LM_REG || IN == IN_LM_DMA) && !no_skew && grid.x >= 512 && frames >= 2048 && frames <= 8192 ? kLwSkewTicks : 0u;
     note_kernel(waves == 6 ? "lockin_waves_kernel[6 waves per 64 lanes]" : "lockin_waves_kernel[4 waves per 64 lanes]", Bank::name());
     if constexpr (Bank::kSixWaves) {
         if (waves == 6) {
-            hipLaunchKernelGGL((lockin_waves_kernel<Bank, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames, lo);
+            hipLaunchKernelGGL((lockin_waves_kernel<Bank, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames, lo, skew);
             return launch_status();
         }
     }
-    hipLaunchKernelGGL((lockin_waves_kernel<Bank, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames, lo);
+    hipLaunchKernelGGL((lockin_waves_kernel<Bank, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames, lo, skew);
     return launch_status();
 }
 
