@@ -147,12 +147,12 @@ def wrap64(v: int) -> int:
 
 def c2_input_host(frames: int, lanes: int, layout: str, rank: int):
     """SURVEY.md §8d C2 stream (PCG64): i32 uniform in [-2^24, 2^24); FRAME_MAJOR `[frames][lanes]`
-    (LANE_MAJOR runs draw `[lanes][frames]` from the same generator)."""
+    (LANE_MAJOR: the same tensor transposed, so that the layout-independent checksums on file hold for both)."""
     import numpy as np
 
     rng = np.random.default_rng(CONFIGS["c2"]["seed"] if rank == 0 else [CONFIGS["c2"]["seed"], rank])
-    shape = (frames, lanes) if layout == "frame" else (lanes, frames)
-    return rng.integers(-(1 << 24), 1 << 24, size=shape, dtype=np.int32)
+    x = rng.integers(-(1 << 24), 1 << 24, size=(frames, lanes), dtype=np.int32)
+    return x if layout == "frame" else np.ascontiguousarray(x.T)
 
 
 def _c5_hash(idx, xp):
@@ -267,7 +267,9 @@ def expected_checksums():
 
 def expected_for(cfg_name: str, layout: str, rank: int, lane_lo: int, lanes: int, overridden: bool):
     """[y checksum, state checksum] the oracle gives for this rank's input, or None if not on file."""
-    if overridden or layout != "frame":
+    # the wrapping sums do not depend on the order of the words, and every config's LaneMajor input is the FrameMajor tensor
+    # transposed: one table serves both layouts (C5's blocks are FrameMajor lane blocks: FrameMajor only)
+    if overridden or (layout != "frame" and cfg_name == "c5"):
         return None
     tab = expected_checksums().get(cfg_name)
     if not tab:
@@ -788,6 +790,18 @@ def rank_main(args, engine_factory=HipEngine):
             subs[name], e = run_config(name, args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
                                        min(args.warmup, 3), min(args.settle_ms, 100.0), 0, 0)
             e.free()
+    lm_subs = {}
+    if args.config == "c2" and args.layout == "frame" and not getattr(args, "no_lane_major", False) and not (args.lanes or args.frames):
+        # LaneMajor (`[lane][frame]`, the reference's native lane view, dsp-process/src/view.rs:176-196) of C2, C3 and C4: the same
+        # tensors transposed, own timed region, roofline and integrity each
+        families = getattr(engine_factory, "FAMILIES", ("biquad",))
+        lm_args = argparse.Namespace(**{**vars(args), "layout": "lane"})
+        for name, skip in (("c2", False), ("c3", args.no_c3), ("c4", args.no_c4)):
+            if skip or CONFIGS[name].get("family", "biquad") not in families:
+                continue
+            lm_subs[name], e = run_config(name, lm_args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
+                                          min(args.warmup, 3), min(args.settle_ms, 100.0), 0, 0)
+            e.free()
     if rank == 0:
         line["rccl_ranks"] = rccl_ranks
         line["backend"] = "nccl (RCCL)" if backend == "nccl" else backend
@@ -803,6 +817,9 @@ def rank_main(args, engine_factory=HipEngine):
             keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config",
                     "roofline", "ranks", "integrity")
             line[name] = {k: sl[k] for k in keep}
+        if lm_subs:
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "integrity")
+            line["lane_major"] = {name: {k: sl[k] for k in keep} for name, sl in lm_subs.items()}
         if world == 1 and not args.no_cpu and CONFIGS[args.config].get("family", "biquad") == "biquad":
             cb = cpu_baseline(args.config, CONFIGS[args.config], x_host, args.layout)
             integ = line["integrity"]
@@ -834,6 +851,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=0, help="override the samples per lane (diagnostics)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 strong-scaling sub-object of the default run")
+    ap.add_argument("--no-lane-major", action="store_true", help="skip the LaneMajor sub-objects (C2, C3, C4) of the default run")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 (HbfDec /16) sub-object of the default run")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (lock-in) sub-object of the default run")
     ap.add_argument("--c5-lanes", type=int, default=0, help="total lanes of the C5 sub-object (diagnostics; default 2^20)")

@@ -766,6 +766,17 @@ struct LmSide {
 // the first LW threads own a lane: a launch of few lanes then spreads over LW / 64 times as many waves (SIMDs) — below
 // 65536 lanes a 64-lane wave per SIMD leaves most of the chip without a wave, and the per-lane recurrence is a serial
 // chain that one wave cannot speed up.
+// tools/exp_lm_ablate.sh: the kernel without its loads / stores (conditions never true at run time: timing only)
+#ifdef IDSP_EXP_LM_NOLOAD
+#define IDSP_EXP_LM_LD_ON (frames == 1)
+#else
+#define IDSP_EXP_LM_LD_ON true
+#endif
+#ifdef IDSP_EXP_LM_NOSTORE
+#define IDSP_EXP_LM_ST_ON (frames == 1)
+#else
+#define IDSP_EXP_LM_ST_ON true
+#endif
 template <class P, int LW = kWave, int LB = kLmRun>
 __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
 #pragma unroll
             for (int j = 0; j < NII; j++) {
                 const int pc = mpci ^ (NII % 16 == 0 ? j & 15 : (mqi + j) & 15);  // mqi is a multiple of NII: a constant when 16 | NII
-                if ((decltype(whole)::value || size_t(mqi + j) < nrows) && (decltype(full)::value || pc < nq * IW))
+                if ((decltype(whole)::value || size_t(mqi + j) < nrows) && (decltype(full)::value || pc < nq * IW) && IDSP_EXP_LM_LD_ON)
                     stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + j * xrowb) + size_t(xoff + uint32_t(pc * 16))));
             }
         }
@@ -916,7 +927,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
         for (int j = 0; j < NIO; j++) {
             const int pc = mpco ^ (NIO % 16 == 0 ? j & 15 : (mqo + j) & 15);
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot_out + j * 1024 + lid * 16);
-            if ((decltype(whole)::value || size_t(mqo + j) < nrows) && (decltype(full)::value || pc < nq * OW))
+            if ((decltype(whole)::value || size_t(mqo + j) < nrows) && (decltype(full)::value || pc < nq * OW) && IDSP_EXP_LM_ST_ON)
                 __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + j * yrowb) + size_t(yoff + uint32_t(pc * 16))));
             if (j % 8 == 7) asm volatile("" ::: "memory");  // at most 8 pieces between LDS and the store (the staged tile holds PI)
         }

@@ -123,7 +123,10 @@ def test_expected_checksums_on_file_cover_every_rank_and_split():
             tot = [bench.wrap64(tot[0] + e[0]), bench.wrap64(tot[1] + e[1])]
         assert tot == bench.expected_for("c5", "frame", 0, 0, 1 << 20, False)
     assert bench.expected_for("c2", "frame", 3, 0, 65536, False) is not None
-    assert bench.expected_for("c2", "lane", 0, 0, 65536, False) is None and bench.expected_for("c2", "frame", 0, 0, 65536, True) is None
+    # LaneMajor runs the same tensor transposed and the sums do not depend on the order: one table for both layouts (C5: FrameMajor blocks)
+    assert bench.expected_for("c2", "lane", 0, 0, 65536, False) == bench.expected_for("c2", "frame", 0, 0, 65536, False)
+    assert bench.expected_for("c5", "lane", 0, 0, 1 << 20, False) is None and bench.expected_for("c2", "frame", 0, 0, 65536, True) is None
+    assert np.array_equal(bench.c2_input_host(5, 7, "lane", 0), bench.c2_input_host(5, 7, "frame", 0).T)
 
 
 def test_c3_c4_inputs_are_the_same_on_host_and_device_code_paths_and_their_checksums_are_on_file():
