@@ -32,9 +32,9 @@ run() {  # name, command...
 WHAT=${2:-all}
 # usage: collect_profiles_r04.sh [tag] [all | comma list of c2,c2df,c2lm,c5,c5s8,c3,c3lm,c4,c4lm,cic]
 want() { [ "$WHAT" = all ] || echo ",$WHAT," | grep -q ",$1,"; }
-want c2 && run c2 python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --steps 100 --warmup 5
-want c2df && run c2_driverflags python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --steps 20 --warmup 5
-want c2lm && run c2_lanemajor python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --layout lane --steps 100 --warmup 5
+want c2 && run c2 python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --no-lane-major --steps 100 --warmup 5
+want c2df && run c2_driverflags python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --no-lane-major --steps 20 --warmup 5
+want c2lm && run c2_lanemajor python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --no-lane-major --layout lane --steps 100 --warmup 5
 want c5 && run c5 python bench.py --config c5 --no-cpu --steps 20 --warmup 5
 want c5s8 && run c5_shard8 python bench.py --config c5 --lanes 131072 --no-cpu --steps 50 --warmup 5
 # C3 / C4 from bench.py alone: one kernel name = one shape (FRAME_MAJOR, the layout of the driver's line), then LANE_MAJOR
