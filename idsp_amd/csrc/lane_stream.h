@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
     // xcd_contiguous (rows off the 64-byte grid): XCD j = blockIdx % 8 takes the j-th contiguous eighth of the lane blocks, so that the
     // 128-byte lines two neighbouring waves share are fetched and written through one L2 (see stream_frame_major_lds, XCDC)
     size_t wg = blockIdx.x;
-    if (xcd_contiguous) {
+    if (xcd_contiguous & 1) {
         const size_t q = gridDim.x / 8, r = gridDim.x % 8, j = blockIdx.x % 8;
         wg = j * q + (j < r ? j : r) + blockIdx.x / 8;
     }
@@ -1056,12 +1056,25 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
     u32x4 stage[NI];
     // FULL: all TF frames of the tile exist (else nf of them).  `mine` masks the pieces of missing lanes (last wave only; one
     // code path for whole and partial waves: the predicate is a loop-invariant exec mask, and the kernel compiles once)
-    auto fetch = [&](size_t v, auto full, int nf) __attribute__((always_inline)) {
+    auto fetch_as = [&](size_t v, auto full, int nf, auto nt) __attribute__((always_inline)) {
         const char *src = xbase + v * TF * xrowb;
 #pragma unroll
         for (int j = 0; j < NI; j++)
             if (mine && (decltype(full)::value || j * RPI + mrow < nf))
-                stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + size_t(j * RPI) * xrowb) + size_t(xoff)));
+                stage[j] = decltype(nt)::value ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + size_t(j * RPI) * xrowb) + size_t(xoff)))
+                                               : *reinterpret_cast<const u32x4 *>(uniform_ptr(src + size_t(j * RPI) * xrowb) + size_t(xoff));
+    };
+    // Rows off the 64-byte grid (xcd_contiguous & 2): the 128-byte lines at both ends of a wave's row piece are shared with the
+    // neighbouring waves, and with nontemporal accesses each of the two fetches them from memory and writes its part back alone;
+    // plain loads and stores let the second wave hit, and the two parts meet, in the L2 the XCD-contiguous order gives them in
+    // common: 32769 lanes x 4096 frames 0.363 -> 0.268 ms, 32772 0.351 -> 0.278, 40001 0.489 -> 0.356 (round 4; plain stores
+    // alone 0.341 / 0.312 / 0.418; aligned rows lose 4 % with plain accesses and keep the nontemporal ones).
+    const bool plain = (xcd_contiguous & 2) != 0;
+    auto fetch = [&](size_t v, auto full, int nf) __attribute__((always_inline)) {
+        if (plain)
+            fetch_as(v, full, nf, std::false_type{});
+        else
+            fetch_as(v, full, nf, std::true_type{});
     };
     auto hand_over = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -1102,15 +1115,26 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
             }
         }
     };
-    auto store = [&](size_t v, auto full, int nf) __attribute__((always_inline)) {
+    auto store_as = [&](size_t v, auto full, int nf, auto nt) __attribute__((always_inline)) {
         char *dst = ybase + v * TF * yrowb;
 #pragma unroll
         for (int j = 0; j < NI; j++) {
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
-            if (mine && (decltype(full)::value || j * RPI + mrow < nf))
-                __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + size_t(j * RPI) * yrowb) + size_t(yoff)));
+            if (mine && (decltype(full)::value || j * RPI + mrow < nf)) {
+                u32x4 *dp = reinterpret_cast<u32x4 *>(uniform_ptr(dst + size_t(j * RPI) * yrowb) + size_t(yoff));
+                if constexpr (decltype(nt)::value)
+                    __builtin_nontemporal_store(v4, dp);
+                else
+                    *dp = v4;
+            }
             if (j % 8 == 7) asm volatile("" ::: "memory");
         }
+    };
+    auto store = [&](size_t v, auto full, int nf) __attribute__((always_inline)) {
+        if (plain)
+            store_as(v, full, nf, std::false_type{});
+        else
+            store_as(v, full, nf, std::true_type{});
     };
     using Full = std::true_type;
     using Part = std::false_type;
@@ -1491,7 +1515,9 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     // rows off the 64-byte grid: XCD-contiguous lane blocks (IDSP_DIAG=1 IDSP_STAGED_NO_XCDC=1: the plain order)
                     static const bool no_xcdc = diag_env("IDSP_STAGED_NO_XCDC") != nullptr;
                     const unsigned grid = unsigned((lanes + LW - 1) / LW);
-                    const int xcdc = !no_xcdc && grid >= 64 && off64;
+                    // ... and plain instead of nontemporal accesses there (bit 1; IDSP_DIAG=1 IDSP_STAGED_NT=1: nontemporal everywhere)
+                    static const bool all_nt = diag_env("IDSP_STAGED_NT") != nullptr;
+                    const int xcdc = (!no_xcdc && grid >= 64 && off64 ? 1 : 0) | (!all_nt && off64 ? 2 : 0);
                     hipLaunchKernelGGL((stream_frame_major_staged<P, LW>), dim3(grid), dim3(kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp, xcdc);
                     return launch_status();
                 };
