@@ -1505,7 +1505,9 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 // lanes (16384 lanes at pitch 16385: 0.19 ms with 64 lanes per wave, 0.27 with 32, 0.23 on the register-window kernel;
                 // 8192 lanes 0.175 / 0.147 / 0.21 — tools/exp_fm_unaligned_small.py, profiles/r03_exp_fm_unaligned_small.jsonl)
                 const bool off64 = (xl * sz) % 64 != 0 || (yl * sz) % 64 != 0 || reinterpret_cast<uintptr_t>(x) % 64 != 0 || reinterpret_cast<uintptr_t>(y) % 64 != 0;
-                const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= (off64 ? 12288 : 24576) ? 64 : lanes >= 8192 ? 32 : 16;
+                // (round 4, with plain accesses on such rows the 32-lane form wins again up to ~25000 lanes: 16385 lanes 0.217 -> 0.182 ms,
+                // 12292 0.202 -> 0.163, 20484 0.240 -> 0.200, 24580 0.249 -> 0.223; 26628 0.255 with 64 against 0.268 with 32)
+                const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= (off64 ? 25600 : 24576) ? 64 : lanes >= 8192 ? 32 : 16;
                 auto go = [&](auto lw_tag) {
                     constexpr int LW = decltype(lw_tag)::value;
                     constexpr size_t bytes = size_t(kFmStagedTile) + size_t(P::LDS_WORDS) * 4;

@@ -43,7 +43,8 @@ def test_whole_pieces_on_rows_off_the_grid(gpu):
     shapes = [(65536, 33, 65537, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (65536, 20, 65544, 1, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (65000, 19, 65003, 2, "stream_frame_major_lds[XCD-contiguous blocks]<"),
-              (16384, 130, 16387, 0, "stream_frame_major_staged[64 lanes/wave]<"),
+              (16384, 130, 16387, 0, "stream_frame_major_staged[32 lanes/wave]<"),  # round 4: plain accesses on such rows, 64 from 25600 lanes
+              (28672, 40, 28675, 1, "stream_frame_major_staged[64 lanes/wave]<"),
               (4096, 257, 4099, 3, "stream_frame_major_staged[16 lanes/wave]<"),
               (69632, 18, 69633, 0, "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)<")]
     for i, (lanes, frames, pitch, off, want) in enumerate(shapes):
