@@ -368,6 +368,152 @@ __global__ __launch_bounds__(kWave *(NF + 1)) __attribute__((amdgpu_waves_per_eu
 }
 
 
+// FM discriminator on role waves, LANE_MAJOR (round 4).  Same roles as above — four front waves with eight frames of a 32-frame
+// tile each, a fifth wave with the deemphasis biquad one tile behind — but every global access moves whole 128-byte lines, as in
+// the LaneMajor lock-in (lockin_waves.h): the input tile (two lines of 16 `Complex<i32>` per lane) arrives by LDS-DMA one tile
+// ahead, eight threads per line, pieces swizzled so that a thread's ds_read_b128 of its own row are conflict free; a front-wave
+// thread reads its eight samples and the one before them from LDS (wave 0 carries the last sample of the tile before in a
+// register), a barrier frees the slot and the requests of the next tile fly during the arithmetic (one slot: 34 KiB of LDS, four
+// workgroups per CU — with two slots and one barrier per tile, 51 KiB and three: 0.98 ms); the discriminator values go into one ROW per lane (pitch 36 words), the biquad wave
+// turns its row into outputs in place and the wave then re-reads the rows line-wise — eight threads per lane — and stores eight
+// whole lines per instruction.  Two workgroup barriers per tile.  Whole tiles on 16-byte aligned rows; everything else stays on
+// the tile kernel (stream_lane_major<FmDiscProc>), whose 64 different lines per access are what it is bound by (1.25 ms at
+// 65536 lanes x 4096 frames; the FrameMajor role kernel with per-thread vectors on LaneMajor rows: 2.30 ms, round 3).
+#ifdef IDSP_FMD_ABL_NOSTORE  // tools/exp_lm_ablate.sh (UNIT=dds): timing variants, conditions never true at run time
+#define IDSP_FMD_ST_ON (frames == 1)
+#else
+#define IDSP_FMD_ST_ON true
+#endif
+#ifdef IDSP_FMD_ABL_NOLOAD
+#define IDSP_FMD_LD_ON (frames == 1)
+#else
+#define IDSP_FMD_LD_ON true
+#endif
+__global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDiscProc::Params prm, uint32_t *st, const cplx_bits *x, int32_t *y,
+                                                                     const size_t lanes, const size_t frames, const unsigned skew,
+                                                                     const unsigned skew_shift, const unsigned skew_mod)
+{
+    constexpr int NF = 4, FPW = 8, T = NF * FPW, RS = T + 4;
+    // start-up stagger (lockin_waves.h, "lanes in phase"): workgroup b waits ((b >> shift) % mod) * skew ticks of 10 ns
+    if (const long long d = (long long)(skew) * ((blockIdx.x >> skew_shift) % skew_mod)) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) int32_t tile[2][kWave * RS];
+    __shared__ __attribute__((aligned(16))) uint32_t xs[2][kWave * 32];  // [line of the tile][64 rows x 128 bytes]: ONE slot, 34 KiB in all, four workgroups per CU
+    __shared__ uint32_t tab[32];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave), lid = int(threadIdx.x) % kWave;
+    if (threadIdx.x < 32) tab[threadIdx.x] = d_atan2_table[threadIdx.x];
+    const size_t lane = size_t(blockIdx.x) * kWave + lid;
+    const bool active = lane < lanes;
+    const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
+    const size_t ntiles = frames / T;             // launcher: whole tiles
+    if (wave < NF) {
+        const uint32_t has_prev0 = st[la];
+        cplx_bits carry = {int32_t(st[lanes + la]), int32_t(st[2 * lanes + la])};  // wave 0: the sample before the tile
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the state has landed before the first DMA request is counted
+        // instruction j = 4 wave + g of the 16 of a tile: line j / 8 of the tile, rows of lanes j % 8 + 8 (lid / 8), piece (lid % 8) ^ (j % 8)
+        auto dma = [&](size_t k) {
+            if (!IDSP_FMD_LD_ON) return;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int j = 4 * wave + g, line = j >> 3, jj = j & 7;
+                size_t gl = size_t(blockIdx.x) * kWave + size_t(jj + 8 * (lid / 8));
+                gl = gl < lanes ? gl : lanes - 1;
+                glds16(x + gl * frames + k * T + size_t(line * 16 + ((lid % 8) ^ jj) * 2),
+                       uint32_t(reinterpret_cast<uintptr_t>(&xs[line][jj * 256])));
+            }
+        };
+        const uint32_t own = uint32_t((lid % 8) * 8 + lid / 8) * 128, sw = uint32_t(lid % 8);  // own row; piece p sits at 16 (p ^ sw)
+        auto piece = [&](int line, int p) {
+            return *reinterpret_cast<const i32x4 *>(reinterpret_cast<const char *>(&xs[line][0]) + own + ((uint32_t(p) ^ sw) * 16));
+        };
+        auto disc = [&](cplx_bits c, cplx_bits pv) __attribute__((always_inline)) {
+            const int32_t cim = int32_t(0u - uint32_t(pv.y));
+            const int64_t re = int64_t(uint64_t(int64_t(c.x) * pv.x) - uint64_t(int64_t(c.y) * cim));
+            const int64_t im = int64_t(uint64_t(int64_t(c.x) * cim) + uint64_t(int64_t(c.y) * pv.x));
+            return int32_t(uint32_t(atan2_dev(int32_t(im >> 32), int32_t(re >> 32), tab)) - uint32_t(prm.carrier));
+        };
+        dma(0);
+        wait_vmcnt<0>();
+        lds_barrier();  // the table, tile 0
+        const int line = wave >> 1, p0 = (wave & 1) * 4;
+        for (size_t k = 0; k < ntiles; k++) {
+            const int slot = int(k & 1);
+            cplx_bits cur[FPW + 1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const i32x4 a = piece(line, p0 + q);
+                cur[1 + 2 * q] = cplx_bits{a.x, a.y}, cur[2 + 2 * q] = cplx_bits{a.z, a.w};
+            }
+            if (wave == 0) {
+                cur[0] = carry;
+                const i32x4 a = piece(1, 7);  // frame 31 of this tile: the sample before the next one
+                carry = cplx_bits{a.z, a.w};
+            } else {
+                const i32x4 a = wave == 2 ? piece(0, 7) : piece(line, p0 - 1);
+                cur[0] = cplx_bits{a.z, a.w};
+            }
+            lds_barrier();  // every front wave holds its samples of tile k: the slot is free
+            if (k + 1 < ntiles) dma(k + 1);
+            int32_t d[FPW];
+#pragma unroll
+            for (int j = 0; j < FPW; j++) d[j] = disc(cur[j + 1], cur[j]);
+            if (k == 0 && wave == 0) d[0] = has_prev0 ? d[0] : 0;  // `prev` was None: 0 (fm_disc.rs:33-35)
+            i32x4 *row = reinterpret_cast<i32x4 *>(&tile[slot][lid * RS + wave * FPW]);
+            row[0] = i32x4{d[0], d[1], d[2], d[3]};
+            row[1] = i32x4{d[4], d[5], d[6], d[7]};
+            wait_vmcnt<0>();  // this wave's share of tile k + 1 has landed (it had the whole interval)
+            lds_barrier();    // tile k complete, tile k + 1 in LDS; the biquad wave has finished tile k - 1
+        }
+        if (wave == 0 && active) {
+            const cplx_bits last = x[lane * frames + frames - 1];
+            st[lane] = 1u;
+            st[lanes + lane] = uint32_t(last.x);
+            st[2 * lanes + lane] = uint32_t(last.y);
+        }
+    } else {
+        uint32_t s[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) s[w] = st[size_t(3 + w) * lanes + la];
+        lds_barrier();  // pairs with the front waves' first barrier
+        for (size_t k = 0; k <= ntiles; k++) {
+            if (k < ntiles) lds_barrier();  // the front waves' slot hand-over of interval k
+            if (k == 0) {
+                lds_barrier();  // tile 0 complete
+                continue;
+            }
+            const size_t kt = k - 1;  // the tile this wave turns into outputs during interval k
+            int32_t *rowp = &tile[kt & 1][lid * RS];
+            int32_t v[T];
+#pragma unroll
+            for (int q = 0; q < T / 4; q++) {
+                const i32x4 a = reinterpret_cast<const i32x4 *>(rowp)[q];
+                v[4 * q] = a.x, v[4 * q + 1] = a.y, v[4 * q + 2] = a.z, v[4 * q + 3] = a.w;
+            }
+#pragma unroll
+            for (int f = 0; f < T; f++) v[f] = bq::Df1I32<false>::step(prm.sec, s, v[f]);
+#pragma unroll
+            for (int q = 0; q < T / 4; q++) reinterpret_cast<i32x4 *>(rowp)[q] = i32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            // line-wise: in instruction u thread t holds frames 4 (t % 8) .. of lane 8 u + t / 8 (LDS operations of one wave stay in order)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ll = u * 8 + lid / 8;
+                const size_t gl = size_t(blockIdx.x) * kWave + size_t(ll);
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(&tile[kt & 1][ll * RS + (lid % 8) * 4]);
+                if (gl < lanes && IDSP_FMD_ST_ON) __builtin_nontemporal_store(a, reinterpret_cast<i32x4 *>(y + gl * frames + kt * T) + lid % 8);
+            }
+            if (k < ntiles) lds_barrier();  // tile k complete
+        }
+        if (active) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) st[size_t(3 + w) * lanes + lane] = s[w];
+        }
+    }
+}
+
+
 }  // namespace
 }  // namespace idsp
 
@@ -496,6 +642,23 @@ int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int
             hipLaunchKernelGGL((fm_disc_waves_kernel<4>), dim3(grid), dim3(kWave * 5), 0, as_stream(stream), p, static_cast<uint32_t *>(state),
                                reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, lanes, lanes);
         }
+        return launch_status();
+    }
+    // LANE_MAJOR, whole 32-frame tiles on 16-byte aligned rows: the line-wise role kernel (IDSP_DIAG=1 IDSP_FM_DISC_LM_WAVES=0: never)
+    static const bool no_lm_waves = diag_size("IDSP_FM_DISC_LM_WAVES", 1) == 0;
+    if (layout == IDSP_LANE_MAJOR && !no_lm_waves && frames % 32 == 0 && lanes < (size_t(1) << 28) &&
+        (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0) {
+        note_kernel("fm_disc_waves_lm_kernel");
+        // Start-up stagger (lockin_waves.h, "lanes in phase"): arithmetic alone 0.535 ms at 65536 lanes x 4096 frames, with the requests
+        // 0.60, with the stores 0.555 — and with both 0.92: every lane reads and writes the same offset of its rows at the same time.
+        // Four groups of CUs 12 us apart: 0.926 -> 0.834 ms (6 us 0.884, 24 us 0.827, 48 us 0.97; groups per XCD or per
+        // workgroup pair nothing; tools/exp_fm_disc_skew.sh).  IDSP_DIAG=1 IDSP_FMD_SKEW / _SHIFT / _MOD override.
+        static const size_t sk_forced = diag_size("IDSP_FMD_SKEW", ~size_t(0));
+        static const unsigned sk_shift = unsigned(diag_size("IDSP_FMD_SKEW_SHIFT", 4)), sk_mod = unsigned(diag_size("IDSP_FMD_SKEW_MOD", 4));
+        const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
+        const unsigned sk_ticks = sk_forced != ~size_t(0) ? unsigned(sk_forced) : grid >= 512 && frames >= 2048 && frames <= 8192 ? 1200u : 0u;
+        hipLaunchKernelGGL(fm_disc_waves_lm_kernel, dim3(grid), dim3(kWave * 5), 0, as_stream(stream), p,
+                           static_cast<uint32_t *>(state), reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, sk_ticks, sk_shift, sk_mod ? sk_mod : 1u);
         return launch_status();
     }
     return launch_stream<FmDiscProc>(p, state, reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, layout, as_stream(stream));

@@ -104,6 +104,30 @@ def test_fm_disc_role_waves_frame_major(gpu):
 
 
 @pytest.mark.gpu
+def test_fm_disc_role_waves_lane_major(gpu):
+    """`fm_disc_waves_lm_kernel` (round 4): LaneMajor rows of whole 32-frame tiles — input lines by LDS-DMA, output lines stored
+    eight threads per lane.  One to many tiles, lanes around the 64-lane workgroups (ragged last workgroup), continuation across
+    calls, lanes that start without a previous sample; frame counts that are not whole tiles stay on the tile kernel."""
+    ob, gb = OracleBackend(), GpuBackend()
+    rng = np.random.default_rng(73)
+    for lanes, frames in [(64, 32), (1, 64), (65, 96), (130, 32), (200, 160), (63, 1024), (4096, 64), (20000, 96), (64, 40), (70, 33)]:
+        cfg = _cfg(rng)
+        init = np.zeros((7, lanes), np.uint32)
+        init[0, ::3] = 1
+        init[1:] = rng.integers(0, 1 << 32, size=(6, lanes), dtype=np.uint64).astype(np.uint32)
+        so, sg = init.copy(), init.copy()
+        for part in range(3):
+            x = _x(rng, lanes * frames)
+            rco, yo = ob.cfgcall("fm_disc_i32", cfg, so, x, (lanes * frames,), np.int32, lanes, frames, LM)
+            rcg, yg = gb.cfgcall("fm_disc_i32", cfg, sg, x, (lanes * frames,), np.int32, lanes, frames, LM)
+            assert rco == 0 and rcg == 0, H.engine().err()
+            k = gpu.fn["last_kernel"]().decode()
+            aligned = not os.environ.get("IDSP_TEST_MISALIGN")  # tests/test_gpu_misaligned.py replays this file on buffers 4 / 8 bytes off
+            assert k.startswith("fm_disc_waves_lm_kernel") == (frames % 32 == 0 and aligned), (k, frames)
+            assert np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames, part)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("waves", ["3", "0"])
 def test_fm_disc_other_forms(gpu, waves):
     """three front waves, and the one-thread-per-lane stream kernel the role waves replaced (diagnostic switch, own process)"""

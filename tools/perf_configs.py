@@ -501,6 +501,8 @@ def main():
         if sel and "fm" in sel:
             for lanes in (8192, 16384, 32768, 131072):
                 fm_disc(lanes, 4096, FM, it, "fm")
+            for lanes in (16384, 32768, 131072):
+                fm_disc(lanes, 4096, LM, it, "fm")
 
 
 if __name__ == "__main__":
