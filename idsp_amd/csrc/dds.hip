@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDis
 {
     constexpr int NF = 4, FPW = 8, T = NF * FPW, RS = T + 4;
     // start-up stagger (lockin_waves.h, "lanes in phase"): workgroup b waits ((b >> shift) % mod) * skew ticks of 10 ns
-    if (const long long d = (long long)(skew) * ((blockIdx.x >> skew_shift) % skew_mod)) {
+    if (const long long d = blockIdx.x < 1024 ? (long long)(skew) * ((blockIdx.x >> skew_shift) % skew_mod) : 0) {  // the first round only
         const long long t0 = wall_clock64();
         while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
     }

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #ifdef IDSP_LW_ABL_SKEW
     if (const long long d = g_lw_skew[blockIdx.x % 4096]) {
 #else
-    if (const long long d = (long long)(skew) * ((blockIdx.x >> 4) & 3u)) {
+    if (const long long d = blockIdx.x < 1024 ? (long long)(skew) * ((blockIdx.x >> 4) & 3u) : 0) {  // the first workgroups only: later rounds start out of phase anyway
 #endif
         const long long t0 = wall_clock64();
         while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
