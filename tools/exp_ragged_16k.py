@@ -1,3 +1,5 @@
+"""i32 DF1 FrameMajor x 4096 frames at lane counts (LANES=a,b,...) around 16384 whose rows start off the 64-byte grid: which
+lanes-per-wave form of the staged kernel (IDSP_DIAG=1 IDSP_FM_LANES_PER_WAVE=16/32/64) wins with plain accesses (round 4)."""
 import sys, os, torch
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
 import perf_configs as P
