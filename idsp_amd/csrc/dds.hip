@@ -397,7 +397,8 @@ __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDis
     // start-up stagger (lockin_waves.h, "lanes in phase"): workgroup b waits ((b >> shift) % mod) * skew ticks of 10 ns
     if (const long long d = blockIdx.x < 1024 ? (long long)(skew) * ((blockIdx.x >> skew_shift) % skew_mod) : 0) {  // the first round only
         const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+        // (bounded: an s_sleep(8) is at least 0.2 us = 20 ticks, so d / 8 rounds are more than enough even if the counter stood still)
+        for (long long spins = d / 8 + 16; spins > 0 && wall_clock64() - t0 < d; spins--) __builtin_amdgcn_s_sleep(8);
     }
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) int32_t tile[2][kWave * RS];

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     if (const long long d = blockIdx.x < 1024 ? (long long)(skew) * ((blockIdx.x >> 4) & 3u) : 0) {  // the first workgroups only: later rounds start out of phase anyway
 #endif
         const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+        // (bounded: an s_sleep(8) is at least 0.2 us = 20 ticks, so d / 8 rounds are more than enough even if the counter stood still)
+        for (long long spins = d / 8 + 16; spins > 0 && wall_clock64() - t0 < d; spins--) __builtin_amdgcn_s_sleep(8);
     }
     // Where the mixer multiply `x * lo` (src/lockin.rs:34-37) runs: with the input in LDS (both DMA forms) the read-out waves
     // apply it while they hold cos / sin, and the rows carry the mixed samples — the arm waves are then the two lowpass
