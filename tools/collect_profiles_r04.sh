@@ -44,4 +44,6 @@ want c4 && run c4 python bench.py --config c4 --no-cpu --steps 20 --warmup 5
 want c4lm && run c4_lanemajor python bench.py --config c4 --layout lane --no-cpu --steps 20 --warmup 5
 # the Cic kernels at 16384 lanes x 4096 chunks of 16 (tools/perf_configs.py --only cic: one shape per kernel name)
 want cic && run cic python tools/perf_configs.py --only cic --iters 20
-for n in c2 c2_driverflags c2_lanemajor c5 c5_shard8 c3 c3_lanemajor c4 c4_lanemajor cic; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done
+# the LaneMajor fm_disc role kernel at 65536 lanes x 4096 frames
+want fmlm && run fm_disc_lanemajor python tools/perf_configs.py --only fmlm --iters 20
+for n in c2 c2_driverflags c2_lanemajor c5 c5_shard8 c3 c3_lanemajor c4 c4_lanemajor cic fm_disc_lanemajor; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done

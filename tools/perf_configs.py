@@ -495,6 +495,8 @@ def main():
     if sel and "ew" in sel:  # the element-wise entries alone
         cossin(1 << 27, it, "cossin")
         atan2(1 << 27, it, "atan2")
+    if sel and "fmlm" in sel:  # the LaneMajor fm_disc kernel alone, one shape (profiling passes)
+        fm_disc(65536, 4096, LM, it, "fm")
     if want("c4") or want("fm"):
         fm_disc(65536, 4096, FM, it, "fm")
         fm_disc(65536, 4096, LM, it, "fm")
