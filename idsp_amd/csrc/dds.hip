@@ -259,6 +259,16 @@ struct FmDiscProc {
 // same order: results are those of FmDiscProc bit for bit.
 // (registers: left alone the compiler spends 245 VGPRs on hoisted loads and ONE workgroup fits a CU — 1.01 ms at the C2 shape,
 // slower than the stream kernel; four workgroups per CU need <= 96)
+#ifdef IDSP_FMD_ABL_NOSTORE  // tools/exp_lm_ablate.sh (UNIT=dds): timing variants, conditions never true at run time
+#define IDSP_FMD_ST_ON (frames == 1)
+#else
+#define IDSP_FMD_ST_ON true
+#endif
+#ifdef IDSP_FMD_ABL_NOLOAD
+#define IDSP_FMD_LD_ON (frames == 1)
+#else
+#define IDSP_FMD_LD_ON true
+#endif
 #ifndef IDSP_FMD_WPE
 #define IDSP_FMD_WPE 5
 #endif
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(kWave *(NF + 1)) __attribute__((amdgpu_waves_per_eu
             for (int j = 0; j <= FPW; j++) {
                 if (j == 0 && f0 == 0) {
                     dst[0] = prev0;  // frame -1 is the state's `prev`
-                } else if (decltype(full)::value || j0 + j - 1 < ntail) {
+                } else if ((decltype(full)::value || j0 + j - 1 < ntail) && IDSP_FMD_LD_ON) {
                     dst[j] = nt_load<true>(xp + (f0 + j - 1) * xl);
                 }
             }
@@ -349,7 +359,8 @@ __global__ __launch_bounds__(kWave *(NF + 1)) __attribute__((amdgpu_waves_per_eu
             for (int f = 0; f < T; f++) {
                 // (no `if (active)`: an idle thread of the last workgroup shadows lane `lanes - 1` — same input, same state, the
                 // same value to the same address — and a predicate per store is a branch per sample in the ISA)
-                nt_store<true>(yp + (k * T + f) * yl, bq::Df1I32<false>::step(prm.sec, s, v[f]));
+                const int32_t o = bq::Df1I32<false>::step(prm.sec, s, v[f]);
+                if (IDSP_FMD_ST_ON) nt_store<true>(yp + (k * T + f) * yl, o);
             }
             lds_barrier();
         }
@@ -379,16 +390,6 @@ __global__ __launch_bounds__(kWave *(NF + 1)) __attribute__((amdgpu_waves_per_eu
 // whole lines per instruction.  Two workgroup barriers per tile.  Whole tiles on 16-byte aligned rows; everything else stays on
 // the tile kernel (stream_lane_major<FmDiscProc>), whose 64 different lines per access are what it is bound by (1.25 ms at
 // 65536 lanes x 4096 frames; the FrameMajor role kernel with per-thread vectors on LaneMajor rows: 2.30 ms, round 3).
-#ifdef IDSP_FMD_ABL_NOSTORE  // tools/exp_lm_ablate.sh (UNIT=dds): timing variants, conditions never true at run time
-#define IDSP_FMD_ST_ON (frames == 1)
-#else
-#define IDSP_FMD_ST_ON true
-#endif
-#ifdef IDSP_FMD_ABL_NOLOAD
-#define IDSP_FMD_LD_ON (frames == 1)
-#else
-#define IDSP_FMD_LD_ON true
-#endif
 __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDiscProc::Params prm, uint32_t *st, const cplx_bits *x, int32_t *y,
                                                                      const size_t lanes, const size_t frames, const unsigned skew,
                                                                      const unsigned skew_shift, const unsigned skew_mod)
