@@ -325,6 +325,17 @@ struct LdsRunOf<P, std::void_t<decltype(P::LDS_RUN)>> {
     static constexpr bool value = P::LDS_RUN;
 };
 
+// tools/exp_lm_ablate.sh: stream_lane_major_staged and stream_frame_major_lds without their loads / stores (conditions never true at run time: timing only)
+#ifdef IDSP_EXP_LM_NOLOAD
+#define IDSP_EXP_LM_LD_ON (frames == 1)
+#else
+#define IDSP_EXP_LM_LD_ON true
+#endif
+#ifdef IDSP_EXP_LM_NOSTORE
+#define IDSP_EXP_LM_ST_ON (frames == 1)
+#else
+#define IDSP_EXP_LM_ST_ON true
+#endif
 #ifndef IDSP_XCDC_LOAD_NT
 #define IDSP_XCDC_LOAD_NT 1
 #endif
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
             const int g = wave + 4 * j;
-            if (FULL || g < ns) {
+            if ((FULL || g < ns) && IDSP_EXP_LM_LD_ON) {
                 const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * kFmBlock : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid4;
                 if constexpr (XCDC && !IDSP_XCDC_LOAD_NT)
                     glds16_plain(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
             const int g = wave + 4 * j;
-            if (FULL || g < ns) {
+            if ((FULL || g < ns) && IDSP_EXP_LM_ST_ON) {
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
                     const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid4);
@@ -766,17 +777,6 @@ struct LmSide {
 // the first LW threads own a lane: a launch of few lanes then spreads over LW / 64 times as many waves (SIMDs) — below
 // 65536 lanes a 64-lane wave per SIMD leaves most of the chip without a wave, and the per-lane recurrence is a serial
 // chain that one wave cannot speed up.
-// tools/exp_lm_ablate.sh: the kernel without its loads / stores (conditions never true at run time: timing only)
-#ifdef IDSP_EXP_LM_NOLOAD
-#define IDSP_EXP_LM_LD_ON (frames == 1)
-#else
-#define IDSP_EXP_LM_LD_ON true
-#endif
-#ifdef IDSP_EXP_LM_NOSTORE
-#define IDSP_EXP_LM_ST_ON (frames == 1)
-#else
-#define IDSP_EXP_LM_ST_ON true
-#endif
 template <class P, int LW = kWave, int LB = kLmRun>
 __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
