@@ -336,6 +336,12 @@ struct LdsRunOf<P, std::void_t<decltype(P::LDS_RUN)>> {
 #else
 #define IDSP_EXP_LM_ST_ON true
 #endif
+#ifndef IDSP_EXP_LDS_PLAIN_LD  // experiment: plain instead of nontemporal accesses in every instantiation of the LDS-DMA kernel
+#define IDSP_EXP_LDS_PLAIN_LD 0
+#endif
+#ifndef IDSP_EXP_LDS_PLAIN_ST
+#define IDSP_EXP_LDS_PLAIN_ST 0
+#endif
 #ifndef IDSP_XCDC_LOAD_NT
 #define IDSP_XCDC_LOAD_NT 1
 #endif
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
             const int g = wave + 4 * j;
             if ((FULL || g < ns) && IDSP_EXP_LM_LD_ON) {
                 const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * kFmBlock : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid4;
-                if constexpr (XCDC && !IDSP_XCDC_LOAD_NT)
+                if constexpr ((XCDC && !IDSP_XCDC_LOAD_NT) || IDSP_EXP_LDS_PLAIN_LD)
                     glds16_plain(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
                 else
                     glds16(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
                     const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid4);
                     uint32_t *dst = RUN ? yq + (size_t(g / LPT) * yl + (g % LPT) * kFmBlock) * OW + h * kFmBlock
                                         : yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid4;
-                    if constexpr (XCDC && !IDSP_XCDC_STORE_NT)
+                    if constexpr ((XCDC && !IDSP_XCDC_STORE_NT) || IDSP_EXP_LDS_PLAIN_ST)
                         *reinterpret_cast<u32x4 *>(dst) = v4;
                     else
                         __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst));
