@@ -411,6 +411,12 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
         for (int s = 0; s < LPT; s++) p[s].set_shared(ptab);
     }
+#ifdef IDSP_EXP_LDS_SKEW  // experiment (tools/exp_c5_skew.sh): start-up stagger of persistent launches, ((b >> SHIFT) % MOD) x SKEW ticks of 10 ns
+    if ((lanes + size_t(kFmBlock) * LPT - 1) / (size_t(kFmBlock) * LPT) > gridDim.x) {
+        const long long d_ = (long long)(IDSP_EXP_LDS_SKEW) * ((blockIdx.x >> IDSP_EXP_LDS_SKEW_SHIFT) % IDSP_EXP_LDS_SKEW_MOD), t0_ = wall_clock64();
+        for (long long spins = d_ / 8 + 16; d_ && spins > 0 && wall_clock64() - t0_ < d_; spins--) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     // Persistent over lane blocks: workgroup w walks the (256 LPT)-lane blocks w, w + grid, w + 2 grid, ... one after
     // the other (state load, the whole frame walk, state store per block).
     constexpr size_t kBlockLanes = size_t(kFmBlock) * LPT;
