@@ -391,8 +391,8 @@ __global__ __launch_bounds__(kWave *(NF + 1)) __attribute__((amdgpu_waves_per_eu
 // the tile kernel (stream_lane_major<FmDiscProc>), whose 64 different lines per access are what it is bound by (1.25 ms at
 // 65536 lanes x 4096 frames; the FrameMajor role kernel with per-thread vectors on LaneMajor rows: 2.30 ms, round 3).
 __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDiscProc::Params prm, uint32_t *st, const cplx_bits *x, int32_t *y,
-                                                                     const size_t lanes, const size_t frames, const unsigned skew,
-                                                                     const unsigned skew_shift, const unsigned skew_mod)
+                                                                     const size_t lanes, const size_t frames, const size_t pitch,
+                                                                     const unsigned skew, const unsigned skew_shift, const unsigned skew_mod)
 {
     constexpr int NF = 4, FPW = 8, T = NF * FPW, RS = T + 4;
     // start-up stagger (lockin_waves.h, "lanes in phase"): workgroup b waits ((b >> shift) % mod) * skew ticks of 10 ns
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDis
     const size_t lane = size_t(blockIdx.x) * kWave + lid;
     const bool active = lane < lanes;
     const size_t la = active ? lane : lanes - 1;  // idle threads of the last workgroup shadow a valid lane, stores masked
-    const size_t ntiles = frames / T;             // launcher: whole tiles
+    const size_t ntiles = frames / T;             // launcher: whole tiles of rows `pitch` elements apart (the rest of a row: the tile kernel)
     if (wave < NF) {
         const uint32_t has_prev0 = st[la];
         cplx_bits carry = {int32_t(st[lanes + la]), int32_t(st[2 * lanes + la])};  // wave 0: the sample before the tile
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDis
                 const int j = 4 * wave + g, line = j >> 3, jj = j & 7;
                 size_t gl = size_t(blockIdx.x) * kWave + size_t(jj + 8 * (lid / 8));
                 gl = gl < lanes ? gl : lanes - 1;
-                glds16(x + gl * frames + k * T + size_t(line * 16 + ((lid % 8) ^ jj) * 2),
+                glds16(x + gl * pitch + k * T + size_t(line * 16 + ((lid % 8) ^ jj) * 2),
                        uint32_t(reinterpret_cast<uintptr_t>(&xs[line][jj * 256])));
             }
         };
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDis
             lds_barrier();    // tile k complete, tile k + 1 in LDS; the biquad wave has finished tile k - 1
         }
         if (wave == 0 && active) {
-            const cplx_bits last = x[lane * frames + frames - 1];
+            const cplx_bits last = x[lane * pitch + frames - 1];
             st[lane] = 1u;
             st[lanes + lane] = uint32_t(last.x);
             st[2 * lanes + lane] = uint32_t(last.y);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kWave * 5) void fm_disc_waves_lm_kernel(const FmDis
                 const int ll = u * 8 + lid / 8;
                 const size_t gl = size_t(blockIdx.x) * kWave + size_t(ll);
                 const i32x4 a = *reinterpret_cast<const i32x4 *>(&tile[kt & 1][ll * RS + (lid % 8) * 4]);
-                if (gl < lanes && IDSP_FMD_ST_ON) __builtin_nontemporal_store(a, reinterpret_cast<i32x4 *>(y + gl * frames + kt * T) + lid % 8);
+                if (gl < lanes && IDSP_FMD_ST_ON) __builtin_nontemporal_store(a, reinterpret_cast<i32x4 *>(y + gl * pitch + kt * T) + lid % 8);
             }
             if (k < ntiles) lds_barrier();  // tile k complete
         }
@@ -648,8 +648,11 @@ int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int
     }
     // LANE_MAJOR, whole 32-frame tiles on 16-byte aligned rows: the line-wise role kernel (IDSP_DIAG=1 IDSP_FM_DISC_LM_WAVES=0: never)
     static const bool no_lm_waves = diag_size("IDSP_FM_DISC_LM_WAVES", 1) == 0;
-    if (layout == IDSP_LANE_MAJOR && !no_lm_waves && frames % 32 == 0 && lanes < (size_t(1) << 28) &&
+    // Rows of any multiple of four frames from 32 up: the whole tiles here, the last frames % 32 on the tile kernel behind it (same stream, rows at
+    // the call's pitch, the state carries over as between two calls).
+    if (layout == IDSP_LANE_MAJOR && !no_lm_waves && frames >= 32 && frames % 4 == 0 && lanes < (size_t(1) << 28) &&
         (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0) {
+        const size_t body = frames - frames % 32, tail = frames - body;
         note_kernel("fm_disc_waves_lm_kernel");
         // Start-up stagger (lockin_waves.h, "lanes in phase"): arithmetic alone 0.535 ms at 65536 lanes x 4096 frames, with the requests
         // 0.60, with the stores 0.555 — and with both 0.92: every lane reads and writes the same offset of its rows at the same time.
@@ -660,8 +663,12 @@ int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int
         const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
         const unsigned sk_ticks = sk_forced != ~size_t(0) ? unsigned(sk_forced) : grid >= 512 && frames >= 2048 && frames <= 8192 ? 1200u : 0u;
         hipLaunchKernelGGL(fm_disc_waves_lm_kernel, dim3(grid), dim3(kWave * 5), 0, as_stream(stream), p,
-                           static_cast<uint32_t *>(state), reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, sk_ticks, sk_shift, sk_mod ? sk_mod : 1u);
-        return launch_status();
+                           static_cast<uint32_t *>(state), reinterpret_cast<const cplx_bits *>(x), y, lanes, body, frames, sk_ticks, sk_shift, sk_mod ? sk_mod : 1u);
+        if (int rc = launch_status()) return rc;
+        if (tail == 0) return IDSP_OK;
+        rc = launch_stream<FmDiscProc>(p, state, reinterpret_cast<const cplx_bits *>(x) + body, y + body, lanes, tail, layout, as_stream(stream), Pitch{frames, frames});
+        if (rc == IDSP_OK) note_kernel("fm_disc_waves_lm_kernel + stream_lane_major (last frames % 32)");
+        return rc;
     }
     return launch_stream<FmDiscProc>(p, state, reinterpret_cast<const cplx_bits *>(x), y, lanes, frames, layout, as_stream(stream));
 }
