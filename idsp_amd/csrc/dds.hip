@@ -13,16 +13,18 @@ namespace idsp {
 
 // lockin_waves_{iq,arg,norm_sqr}.hip: one lane's work spread over 4 or 6 waves (lockin_waves.h)
 int lockin_waves_iq(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames, int layout,
-                    int waves, hipStream_t s);
+                    int waves, hipStream_t s, size_t pitch = 0);
 int lockin_waves_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames, int layout,
-                     int waves, hipStream_t s);
+                     int waves, hipStream_t s, size_t pitch = 0);
 int lockin_waves_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames,
-                          int layout, int waves, hipStream_t s);
+                          int layout, int waves, hipStream_t s, size_t pitch = 0);
 
 // lockin_stream_{iq,arg,norm_sqr}.hip, lowpass.hip: the stream processors behind the multi-wave kernels (lockin_stream_procs.h)
-int lockin_stream_iq(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, bool split, hipStream_t s);
-int lockin_stream_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s);
-int lockin_stream_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y, size_t lanes, size_t frames, int layout, hipStream_t s);
+int lockin_stream_iq(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, bool split, hipStream_t s,
+                     size_t pitch = 0);
+int lockin_stream_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s, size_t pitch = 0);
+int lockin_stream_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int64_t *y, size_t lanes, size_t frames, int layout, hipStream_t s,
+                           size_t pitch = 0);
 int lowpass_stream(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s);
 
 namespace {
@@ -50,6 +52,17 @@ inline int lockin_waves_for(const void *x, const void *y, size_t lanes, size_t f
     // (`arm_weight` = order x cascade: with six and more second-order-equivalents per arm the arm waves are the longer path again and the four-wave
     // form with 16-frame batches wins: `[Lowpass<2>; 4]` -> arg at 32768 lanes 0.58 against 0.74 ms, profiles/r03_perf_c4small_32768.jsonl)
     return heavy_readout && lanes <= kSplitMaxLanes && arm_weight < 6 ? 6 : 4;
+}
+
+// LaneMajor rows that are not whole 16-frame batches (round 4): the multi-wave kernel takes the whole batches of every row at the call's
+// row pitch and a stream kernel the last frames % 16 behind it (same stream; the state carries over as between two calls).  Rows
+// must keep their 16-byte alignment: frames % 4 == 0.  Returns the frames of the first part, 0 = the call is not of that kind.
+inline size_t lockin_lm_body(const void *x, const void *y, size_t frames, int layout)
+{
+    static const bool off = diag_env("IDSP_LOCKIN_NO_LM_TAIL") != nullptr;
+    if (off || layout != IDSP_LANE_MAJOR || frames % 16 == 0 || frames % 4 != 0 || frames < 32) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 != 0) return 0;
+    return frames - frames % 16;
 }
 
 // ------------------------------------------------------------- processors
@@ -587,6 +600,14 @@ int idsp_lockin_i32_process(const idsp_lockin_i32 *cfg, void *state, const int32
     if (lanes == 0) return IDSP_OK;
     if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, false))
         return lockin_waves_iq(cfg, state, x, y, lanes, frames, layout, waves, as_stream(stream));
+    if (const size_t body = lockin_lm_body(x, y, frames, layout)) {
+        if (const int waves = lockin_waves_for(x, y, lanes, body, layout, false)) {
+            if ((rc = lockin_waves_iq(cfg, state, x, y, lanes, body, layout, waves, as_stream(stream), frames))) return rc;
+            rc = lockin_stream_iq(cfg, state, x + body, y + 2 * body, lanes, frames - body, layout, false, as_stream(stream), frames);
+            if (rc == IDSP_OK) note_kernel("lockin_waves_kernel + stream kernel (last frames % 16)");
+            return rc;
+        }
+    }
     // too few lanes to give every SIMD a wave: put the I and Q arms on separate threads (both layouts)
     return lockin_stream_iq(cfg, state, x, y, lanes, frames, layout, lanes <= kSplitMaxLanes, as_stream(stream));
 }
@@ -600,6 +621,14 @@ int idsp_lockin_i32_arg(const idsp_lockin_i32 *cfg, void *state, const int32_t *
     if (lanes == 0) return IDSP_OK;
     if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, true, cfg->order * cfg->cascade))
         return lockin_waves_arg(cfg, state, x, y, lanes, frames, layout, waves, as_stream(stream));
+    if (const size_t body = lockin_lm_body(x, y, frames, layout)) {
+        if (const int waves = lockin_waves_for(x, y, lanes, body, layout, true, cfg->order * cfg->cascade)) {
+            if ((rc = lockin_waves_arg(cfg, state, x, y, lanes, body, layout, waves, as_stream(stream), frames))) return rc;
+            rc = lockin_stream_arg(cfg, state, x + body, y + body, lanes, frames - body, layout, as_stream(stream), frames);
+            if (rc == IDSP_OK) note_kernel("lockin_waves_kernel + stream kernel (last frames % 16)");
+            return rc;
+        }
+    }
     return lockin_stream_arg(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 
@@ -612,6 +641,14 @@ int idsp_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int3
     if (lanes == 0) return IDSP_OK;
     if (const int waves = lockin_waves_for(x, y, lanes, frames, layout, false))
         return lockin_waves_norm_sqr(cfg, state, x, y, lanes, frames, layout, waves, as_stream(stream));
+    if (const size_t body = lockin_lm_body(x, y, frames, layout)) {
+        if (const int waves = lockin_waves_for(x, y, lanes, body, layout, false)) {
+            if ((rc = lockin_waves_norm_sqr(cfg, state, x, y, lanes, body, layout, waves, as_stream(stream), frames))) return rc;
+            rc = lockin_stream_norm_sqr(cfg, state, x + body, y + body, lanes, frames - body, layout, as_stream(stream), frames);
+            if (rc == IDSP_OK) note_kernel("lockin_waves_kernel + stream kernel (last frames % 16)");
+            return rc;
+        }
+    }
     return lockin_stream_norm_sqr(cfg, state, x, y, lanes, frames, layout, as_stream(stream));
 }
 

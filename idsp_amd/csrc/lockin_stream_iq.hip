@@ -3,10 +3,10 @@
 
 namespace idsp {
 
-int lockin_stream_iq(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, bool split, hipStream_t s)
+int lockin_stream_iq(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, bool split, hipStream_t s, size_t pitch)
 {
-    if (split) return dispatch_nk<LockinSplitProc, int32_t>(cfg, state, x, y, 2 * lanes, frames, layout, s);
-    return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, s);
+    if (split) return dispatch_nk<LockinSplitProc, int32_t>(cfg, state, x, y, 2 * lanes, frames, layout, s, pitch);
+    return dispatch_nk<LockinProc, Cplx>(cfg, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, s, pitch);
 }
 
 }  // namespace idsp

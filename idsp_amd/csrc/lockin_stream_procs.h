@@ -193,11 +193,12 @@ using LockinNormSqrProc = LockinPolarProc<N, K, 1>;
 
 template <template <int, int> class Proc, class OutT>
 int dispatch_nk(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, OutT *y, size_t lanes, size_t frames,
-                int layout, hipStream_t s)
+                int layout, hipStream_t s, size_t pitch = 0)
 {
+    // pitch (LaneMajor): elements between the rows of x and of y, 0 = dense
     const LpParams p = lp_params(cfg);
 #define IDSP_CASE(N, K) \
-    if (cfg->order == N && cfg->cascade == K) return launch_stream<Proc<N, K>>(p, state, x, y, lanes, frames, layout, s)
+    if (cfg->order == N && cfg->cascade == K) return launch_stream<Proc<N, K>>(p, state, x, y, lanes, frames, layout, s, Pitch{pitch, pitch})
     IDSP_CASE(1, 1);
     IDSP_CASE(1, 2);
     IDSP_CASE(1, 3);

@@ -146,8 +146,10 @@ __device__ unsigned g_lw_skew[4096];  // workgroup b starts g_lw_skew[b] ticks o
 template <class Bank, int W, int IN, int MODE, int B>
 __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN == IN_LM_REG || IN == IN_LM_DMA ? 2 : 10))) void lockin_waves_kernel(const typename Bank::Params prm, uint32_t *st, const int32_t *x,
                                                                  typename LwOut<MODE>::type *y, const size_t lanes, const size_t frames,
-                                                                 const int32_t *lo_ext, const unsigned skew)
+                                                                 const int32_t *lo_ext, const unsigned skew, const size_t pitch)
 {
+    // `pitch`: elements between LaneMajor rows (x, the LO and y alike) — `frames` for a dense tensor, the call's row length when this
+    // launch covers the whole batches of longer rows and a stream kernel takes the rest (round 4; FrameMajor: unused).
     // Bank::kExtLo: the oscillator is not `Accu` -> cossin but a per-sample `Complex` the caller supplies (src/lockin.rs:17-27):
     // lo_ext[index(f, l) * 2 + {re, im}], same layout as x.  The record then has no accumulator words, no table is built, and the
     // read-out waves fetch their share of the next batch's LO one interval ahead into registers.  Bank::mix is the mixer product
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
     auto fetch = [&](size_t f0, auto full) {
         if constexpr (!DMA && !LMD) {
             if constexpr (LM) {
-                const i32x4 *row = reinterpret_cast<const i32x4 *>(x + la * frames + f0);
+                const i32x4 *row = reinterpret_cast<const i32x4 *>(x + la * pitch + f0);
 #pragma unroll
                 for (int v = 0; v < B / 4; v++) {
                     const i32x4 a = row[v];
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
                 size_t gl = size_t(blockIdx.x) * kWave + size_t(j + 8 * (lid / 8));
                 gl = gl < lanes ? gl : lanes - 1;
                 const size_t f = pair * 32 + size_t(((lid % 8) ^ j) * 4);
-                glds16(x + gl * frames + (f + 4 <= frames ? f : 0),
+                glds16(x + gl * pitch + (f + 4 <= frames ? f : 0),
                        uint32_t(reinterpret_cast<uintptr_t>(&xs[0][0])) + uint32_t((pair % kLwRing) * 8192 + j * 1024));
             }
         }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #pragma unroll
             for (int j = 0; j < C; j++) {
                 const size_t f = n * B + size_t(r * C + j);
-                lon[j] = f < frames ? (LM ? l2[la * frames + f] : l2[f * lanes + la]) : i32x2{0, 0};
+                lon[j] = f < frames ? (LM ? l2[la * pitch + f] : l2[f * lanes + la]) : i32x2{0, 0};
             }
         }
     };
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     const size_t gl = size_t(blockIdx.x) * kWave + size_t(r * 32 + v * 8 + lid / 8);
-                    u32x4 *dst = reinterpret_cast<u32x4 *>(y + gl * frames + (f0 - size_t(slot) * B)) + piece;
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(y + gl * pitch + (f0 - size_t(slot) * B)) + piece;
 #pragma unroll
                     for (int q = 0; q <= slot; q++)
                         if (gl < lanes && LW_ST_ON) LW_NT_STORE(held[q][v], dst + q * 8);
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(1, IN
 #pragma unroll
             for (int v = 0; v < GV; v++) held[slot][v] = u32x4{wd[4 * v], wd[4 * v + 1], wd[4 * v + 2], wd[4 * v + 3]};
             if (slot == kLwOutGroup - 1 || flush) {
-                u32x4 *dst = reinterpret_cast<u32x4 *>(y + gl * frames + (f0 - size_t(slot) * B) + part * C);
+                u32x4 *dst = reinterpret_cast<u32x4 *>(y + gl * pitch + (f0 - size_t(slot) * B) + part * C);
 #pragma unroll
                 for (int q = 0; q <= slot; q++)
                     if (gl < lanes) {
@@ -839,9 +841,10 @@ int launch_lockin_stages(const LpParams &p, void *state, const int32_t *x, void 
 
 template <int MODE, class Bank, int IN, int B>
 int launch_lockin_waves_in(const typename Bank::Params &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
-                           size_t frames, int waves, hipStream_t s, const int32_t *lo)
+                           size_t frames, int waves, hipStream_t s, const int32_t *lo, size_t pitch)
 {
     const dim3 grid(unsigned((lanes + kWave - 1) / kWave));
+    if (pitch == 0) pitch = frames;
     // start-up stagger (see kLwSkewTicks): LaneMajor launches that fill the chip, long enough for the wait to pay
     // (IDSP_DIAG=1 IDSP_LOCKIN_NO_SKEW=1: none)
     static const bool no_skew = diag_env("IDSP_LOCKIN_NO_SKEW") != nullptr;
@@ -851,18 +854,18 @@ int launch_lockin_waves_in(const typename Bank::Params &p, uint32_t *st, const i
     note_kernel(waves == 6 ? "lockin_waves_kernel[6 waves per 64 lanes]" : "lockin_waves_kernel[4 waves per 64 lanes]", Bank::name());
     if constexpr (Bank::kSixWaves) {
         if (waves == 6) {
-            hipLaunchKernelGGL((lockin_waves_kernel<Bank, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames, lo, skew);
+            hipLaunchKernelGGL((lockin_waves_kernel<Bank, 6, IN, MODE, B>), grid, dim3(6 * kWave), 0, s, p, st, x, y, lanes, frames, lo, skew, pitch);
             return launch_status();
         }
     }
-    hipLaunchKernelGGL((lockin_waves_kernel<Bank, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames, lo, skew);
+    hipLaunchKernelGGL((lockin_waves_kernel<Bank, 4, IN, MODE, B>), grid, dim3(4 * kWave), 0, s, p, st, x, y, lanes, frames, lo, skew, pitch);
     return launch_status();
 }
 
 // batch length and input form for a bank on the multi-wave kernel (`waves` from lockin_waves_for, dds.hip)
 template <int MODE, class Bank>
 int launch_lockin_waves_bank(const typename Bank::Params &p, uint32_t *st, const int32_t *x, typename LwOut<MODE>::type *y, size_t lanes,
-                             size_t frames, int layout, int waves, hipStream_t s, const int32_t *lo = nullptr)
+                             size_t frames, int layout, int waves, hipStream_t s, const int32_t *lo = nullptr, size_t pitch = 0)
 {
     static const bool no_dma = diag_env("IDSP_LOCKIN_NO_DMA") != nullptr;
     // 16-frame batches halve the barriers per frame: 0.37 -> 0.35 ms (Complex<i32>), 0.61 -> 0.59 ms (arg) at 32768 lanes x 4096
@@ -884,35 +887,35 @@ int launch_lockin_waves_bank(const typename Bank::Params &p, uint32_t *st, const
         // at 32768 lanes x 4096 frames, 0.94 -> 0.86 at 65536; its 32 KiB ring halves the workgroups a CU can hold, which
         // costs the 6-wave form and the arg read-out more than the input gains (tools/exp_lockin_lm.py)
         if (!no_dma && waves == 4 && MODE != MODE_ARG)
-            return launch_lockin_waves_in<MODE, Bank, IN_LM_DMA, kLwBLm>(p, st, x, y, lanes, frames, waves, s, lo);
-        return launch_lockin_waves_in<MODE, Bank, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s, lo);
+            return launch_lockin_waves_in<MODE, Bank, IN_LM_DMA, kLwBLm>(p, st, x, y, lanes, frames, waves, s, lo, pitch);
+        return launch_lockin_waves_in<MODE, Bank, IN_LM_REG, kLwBLm>(p, st, x, y, lanes, frames, waves, s, lo, pitch);
     }
     if (!no_dma && lanes % kWave == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
-        if (b16) return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s, lo);
-        return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s, lo);
+        if (b16) return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, 16>(p, st, x, y, lanes, frames, waves, s, lo, pitch);
+        return launch_lockin_waves_in<MODE, Bank, IN_FM_DMA, kLwB>(p, st, x, y, lanes, frames, waves, s, lo, pitch);
     }
-    return launch_lockin_waves_in<MODE, Bank, IN_FM_REG, kLwB>(p, st, x, y, lanes, frames, waves, s, lo);
+    return launch_lockin_waves_in<MODE, Bank, IN_FM_REG, kLwB>(p, st, x, y, lanes, frames, waves, s, lo, pitch);
 }
 
 template <int MODE, int N, int K>
 int launch_lockin_waves_nk(const LpParams &p, void *state, const int32_t *x, void *yv, size_t lanes, size_t frames, int layout,
-                           int waves, hipStream_t s)
+                           int waves, hipStream_t s, size_t pitch)
 {
     using Out = typename LwOut<MODE>::type;
     if constexpr (K == 2) {
         if (const int groups = lockin_stage_groups(x, lanes, frames, layout, K, MODE == MODE_ARG))
             return launch_lockin_stages<MODE, N>(p, state, x, yv, lanes, frames, groups, s);
     }
-    return launch_lockin_waves_bank<MODE, LpBank<N, K>>(p, static_cast<uint32_t *>(state), x, static_cast<Out *>(yv), lanes, frames, layout, waves, s);
+    return launch_lockin_waves_bank<MODE, LpBank<N, K>>(p, static_cast<uint32_t *>(state), x, static_cast<Out *>(yv), lanes, frames, layout, waves, s, nullptr, pitch);
 }
 
 template <int MODE>
 int launch_lockin_waves(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames, int layout,
-                        int waves, hipStream_t s)
+                        int waves, hipStream_t s, size_t pitch = 0)
 {
     const LpParams p = lp_params(cfg);
 #define IDSP_CASE(N, K) \
-    if (cfg->order == N && cfg->cascade == K) return launch_lockin_waves_nk<MODE, N, K>(p, state, x, y, lanes, frames, layout, waves, s)
+    if (cfg->order == N && cfg->cascade == K) return launch_lockin_waves_nk<MODE, N, K>(p, state, x, y, lanes, frames, layout, waves, s, pitch)
     IDSP_CASE(1, 1);
     IDSP_CASE(1, 2);
     IDSP_CASE(1, 3);

@@ -5,9 +5,9 @@
 namespace idsp {
 
 int lockin_waves_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, void *y, size_t lanes, size_t frames, int layout,
-                         int waves, hipStream_t s)
+                         int waves, hipStream_t s, size_t pitch)
 {
-    return launch_lockin_waves<MODE_NORM_SQR>(cfg, state, x, y, lanes, frames, layout, waves, s);
+    return launch_lockin_waves<MODE_NORM_SQR>(cfg, state, x, y, lanes, frames, layout, waves, s, pitch);
 }
 
 }  // namespace idsp

@@ -149,14 +149,34 @@ def test_dds_and_polar_lockin_on_the_staged_kernel(gpu):
         assert rc == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
         assert kernel_of(H.engine()).startswith("stream_lane_major_staged"), kernel_of(H.engine())
     lc = H.lockin_cfg([[1 << 20, -(1 << 27)]] * 2)
-    for lanes, frames in ((200, 100), (65, 36), (64, 516)):
+    # rows of fewer than 32 frames that are not whole batches: the stream lock-in; from 32 frames (round 4) the multi-wave kernel takes the whole
+    # batches of every row and the stream kernel only the last frames % 16
+    for lanes, frames in ((200, 28), (65, 20), (64, 24), (200, 100), (65, 36), (64, 516)):
         x = rng.integers(-(1 << 28), 1 << 28, size=lanes * frames, dtype=np.int32)
         st = rng.integers(0, 1 << 32, size=(18, lanes), dtype=np.uint64).astype(np.uint32)
         so, sg = st.copy(), st.copy()
         rco, yo = ob.cfgcall("lockin_i32_arg", lc, so, x, (lanes * frames,), np.int32, lanes, frames, LM)
         rcg, yg = gb.cfgcall("lockin_i32_arg", lc, sg, x, (lanes * frames,), np.int32, lanes, frames, LM)
         assert rco == 0 and rcg == 0 and np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames)
-        assert kernel_of(H.engine()).startswith("stream_lane_major_staged"), kernel_of(H.engine())
+        if os.environ.get("IDSP_LOCKIN_NO_LM_TAIL"):  # the round-3 dispatch: the whole call on the stream lock-in (staged kernel from 32 frames)
+            want = "stream_lane_major_staged" if frames >= 32 else "stream_lane_major"
+        else:
+            want = "stream_lane_major" if frames < 32 else "lockin_waves_kernel + stream kernel (last frames % 16)"
+        assert kernel_of(H.engine()).startswith(want), kernel_of(H.engine())
+
+
+def test_polar_lockin_on_the_staged_kernel_without_the_row_split(gpu):
+    """`stream_lane_major_staged<LockinPolarProc>` is what default dispatch took for such rows before round 4; keep it meeting the oracle."""
+    import subprocess
+    import sys
+
+    if os.environ.get("IDSP_LOCKIN_NO_LM_TAIL"):
+        pytest.skip("inner run")
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_LOCKIN_NO_LM_TAIL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_lane_major_staged.py", "-m", "gpu", "-x", "-q", "-k", "polar_lockin_on_the_staged_kernel and dds",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("lw", ["64", "32", "16"])

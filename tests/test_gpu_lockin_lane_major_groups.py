@@ -108,3 +108,27 @@ def test_a_staggered_launch(gpu):
     torch.cuda.synchronize()
     assert is_waves(e), e.last_kernel()
     assert np.array_equal(yg.cpu().numpy(), yo) and np.array_equal(sg.cpu().numpy().view(np.uint32), so)
+
+
+@pytest.mark.parametrize("entry,width,ndt,tdt", [("lockin_i32_process", 2, np.int32, torch.int32), ("lockin_i32_arg", 1, np.int32, torch.int32),
+                                                  ("lockin_i32_norm_sqr", 1, np.int64, torch.int64)])
+def test_rows_that_are_not_whole_batches(gpu, entry, width, ndt, tdt):
+    """LaneMajor rows of 32 + 4 k frames: the whole 16-frame batches of every row on the multi-wave kernel at the call's row pitch, the
+    last frames % 16 on a stream kernel behind it; two calls on one state; frame counts off the 4-frame grid stay on the stream kernels."""
+    o, e = H.oracle(), H.engine()
+    rng = np.random.default_rng(4400 + width + (ndt == np.int64))
+    cfg = H.lockin_cfg([[1 << 22, -(1 << 27)], [1 << 21, -(1 << 26)]])
+    for lanes, frames in [(64, 36), (70, 100), (129, 1000), (64, 2076), (200, 44), (64, 28), (64, 34)]:
+        st = rng.integers(0, 1 << 32, size=(18, lanes), dtype=np.uint64).astype(np.uint32)
+        so, sg = st.copy(), dev(st)
+        for rep in range(2):
+            x = rng.integers(-(1 << 31), (1 << 31) - 1, size=lanes * frames, dtype=np.int64).astype(np.int32)
+            yo = np.empty(lanes * frames * width, ndt)
+            yg = torch.full((lanes * frames * width,), -77, dtype=tdt, device=DEV)
+            assert o.cfgcall(entry, cfg, so, x, yo, lanes, frames, LM) == 0
+            assert e.cfgcall(entry, cfg, sg, dev(x), yg, lanes, frames, LM) == 0, e.err()
+            torch.cuda.synchronize()
+            split = frames >= 32 and frames % 4 == 0
+            assert e.last_kernel().startswith("lockin_waves_kernel + stream kernel (last frames % 16)") == split, (e.last_kernel(), frames)
+            assert np.array_equal(yg.cpu().numpy(), yo), (entry, lanes, frames, rep)
+            assert np.array_equal(sg.cpu().numpy().view(np.uint32), so), (entry, lanes, frames, rep)

@@ -69,12 +69,12 @@ int run(size_t lanes, size_t frames, const char *name, unsigned sk_ticks = 0, un
     CHK(hipEventCreate(&e1));
     const dim3 grid(unsigned(lanes / 64)), block(4 * 64);
     // 250 ms of launches first: the clock settles
-    for (int i = 0; i < 600; i++) hipLaunchKernelGGL(k, grid, block, 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), arg_skew);
+    for (int i = 0; i < 600; i++) hipLaunchKernelGGL(k, grid, block, 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), arg_skew, frames);
     CHK(hipDeviceSynchronize());
     float best = 1e9f, sum = 0;
     for (int rep = 0; rep < 5; rep++) {
         CHK(hipEventRecord(e0));
-        for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k, grid, block, 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), arg_skew);
+        for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k, grid, block, 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), arg_skew, frames);
         CHK(hipEventRecord(e1));
         CHK(hipEventSynchronize(e1));
         float ms = 0;

@@ -68,7 +68,7 @@ int run(size_t lanes, size_t frames)
     const dim3 ga(unsigned(lanes / 64)), ba(WA * 64), gb(unsigned(lanes / (64 * G))), bb((4 + R) * G * 64);
     // two consecutive calls each (state carried over), then compare
     for (int c = 0; c < 2; c++) {
-        hipLaunchKernelGGL(ka, ga, ba, 0, 0, p, st_a, x, ya, lanes, frames, static_cast<const int32_t *>(nullptr), 0u);
+        hipLaunchKernelGGL(ka, ga, ba, 0, 0, p, st_a, x, ya, lanes, frames, static_cast<const int32_t *>(nullptr), 0u, frames);
         hipLaunchKernelGGL(kb, gb, bb, 0, 0, p, st_b, x, yb, lanes, frames);
     }
     CHK(hipDeviceSynchronize());
@@ -85,7 +85,7 @@ int run(size_t lanes, size_t frames)
         for (size_t i = 0; i < ha.size(); i++) nbad += std::memcmp(&ha[i], &hb[i], sizeof(Out)) != 0;
     size_t bad_s = 0;
     for (size_t i = 0; i < sa.size(); i++) bad_s += sa[i] != sb[i];
-    const float ta = time_ms(ka, ga, ba, p, st_a, x, ya, lanes, frames, static_cast<const int32_t *>(nullptr), 0u), tb = time_ms(kb, gb, bb, p, st_b, x, yb, lanes, frames);
+    const float ta = time_ms(ka, ga, ba, p, st_a, x, ya, lanes, frames, static_cast<const int32_t *>(nullptr), 0u, frames), tb = time_ms(kb, gb, bb, p, st_b, x, yb, lanes, frames);
     const double bytes = double(lanes) * double(frames) * (4.0 + sizeof(Out));
     std::printf("{\"N\": %d, \"mode\": %d, \"G\": %d, \"R\": %d, \"waves_form\": \"%dw B%d\", \"lanes\": %zu, \"frames\": %zu, \"y_mismatches\": %zu, \"state_mismatches\": %zu, \"ms_waves\": %.4f, \"ms_stages\": %.4f, "
                 "\"frac_waves\": %.3f, \"frac_stages\": %.3f}\n",

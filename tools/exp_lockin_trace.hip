@@ -47,10 +47,10 @@ int run(size_t lanes, size_t frames, const char *name)
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k, dim3(unsigned(lanes / 64)), dim3(W * 64), 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), 0u);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k, dim3(unsigned(lanes / 64)), dim3(W * 64), 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), 0u, frames);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0));
-    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(k, dim3(unsigned(lanes / 64)), dim3(W * 64), 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), 0u);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(k, dim3(unsigned(lanes / 64)), dim3(W * 64), 0, 0, p, st, x, y, lanes, frames, static_cast<const int32_t *>(nullptr), 0u, frames);
     CHK(hipEventRecord(e1));
     CHK(hipEventSynchronize(e1));
     float ms = 0;
