@@ -685,9 +685,11 @@ int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int
     }
     // LANE_MAJOR, whole 32-frame tiles on 16-byte aligned rows: the line-wise role kernel (IDSP_DIAG=1 IDSP_FM_DISC_LM_WAVES=0: never)
     static const bool no_lm_waves = diag_size("IDSP_FM_DISC_LM_WAVES", 1) == 0;
-    // Rows of any multiple of four frames from 32 up: the whole tiles here, the last frames % 32 on the tile kernel behind it (same stream, rows at
-    // the call's pitch, the state carries over as between two calls).
-    if (layout == IDSP_LANE_MAJOR && !no_lm_waves && frames >= 32 && frames % 4 == 0 && lanes < (size_t(1) << 28) &&
+    // Rows of any multiple of 16 frames from 32 up: the whole tiles here, the last 16 frames of a row that is not whole tiles on the tile kernel
+    // behind it (same stream, rows at the call's pitch, the state carries over as between two calls).  Multiples of 16 keep the input lines on the
+    // 128-byte grid; rows off it lose more to straddled lines than the role waves win (65536 lanes x 4100 / 4104 / 4124 frames: 1.52 / 1.37 / 1.51 ms
+    // against 1.29 on the tile kernel; 4112 frames: 1.01).
+    if (layout == IDSP_LANE_MAJOR && !no_lm_waves && frames >= 32 && frames % 16 == 0 && lanes < (size_t(1) << 28) &&
         (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0) {
         const size_t body = frames - frames % 32, tail = frames - body;
         note_kernel("fm_disc_waves_lm_kernel");

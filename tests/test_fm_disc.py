@@ -107,12 +107,12 @@ def test_fm_disc_role_waves_frame_major(gpu):
 def test_fm_disc_role_waves_lane_major(gpu):
     """`fm_disc_waves_lm_kernel` (round 4): LaneMajor rows of whole 32-frame tiles — input lines by LDS-DMA, output lines stored
     eight threads per lane.  One to many tiles, lanes around the 64-lane workgroups (ragged last workgroup), continuation across
-    calls, lanes that start without a previous sample; rows of 32 + 4 k frames: the whole tiles here, the rest of every row on the tile kernel
+    calls, lanes that start without a previous sample; rows of 32 + 16 k frames: the whole tiles here, the last 16 frames of a row that is not whole tiles on the tile kernel
     behind it; other frame counts stay on the tile kernel."""
     ob, gb = OracleBackend(), GpuBackend()
     rng = np.random.default_rng(73)
-    for lanes, frames in [(64, 32), (1, 64), (65, 96), (130, 32), (200, 160), (63, 1024), (4096, 64), (20000, 96), (64, 40), (70, 33), (65, 100), (64, 36), (130, 28),
-                          (200, 2076)]:
+    for lanes, frames in [(64, 32), (1, 64), (65, 96), (130, 32), (200, 160), (63, 1024), (4096, 64), (20000, 96), (64, 40), (70, 33), (65, 112), (64, 48), (130, 16),
+                          (200, 2064)]:
         cfg = _cfg(rng)
         init = np.zeros((7, lanes), np.uint32)
         init[0, ::3] = 1
@@ -125,8 +125,8 @@ def test_fm_disc_role_waves_lane_major(gpu):
             assert rco == 0 and rcg == 0, H.engine().err()
             k = gpu.fn["last_kernel"]().decode()
             aligned = not os.environ.get("IDSP_TEST_MISALIGN")  # tests/test_gpu_misaligned.py replays this file on buffers 4 / 8 bytes off
-            assert k.startswith("fm_disc_waves_lm_kernel") == (frames >= 32 and frames % 4 == 0 and aligned), (k, frames)
-            assert k.endswith("(last frames % 32)") == (frames >= 32 and frames % 4 == 0 and frames % 32 != 0 and aligned), (k, frames)
+            assert k.startswith("fm_disc_waves_lm_kernel") == (frames >= 32 and frames % 16 == 0 and aligned), (k, frames)
+            assert k.endswith("(last frames % 32)") == (frames >= 32 and frames % 32 == 16 and aligned), (k, frames)
             assert np.array_equal(yo, yg) and np.array_equal(so, sg), (lanes, frames, part)
 
 
