@@ -18,7 +18,7 @@ namespace idsp {
 
 // lockin_waves_biquad.hip: the multi-wave lock-in kernel with the biquad chain as its arm functor
 int lockin_waves_biquad_iq(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
-                           int layout, hipStream_t s);
+                           int layout, hipStream_t s, size_t pitch = 0);
 int lockin_waves_biquad_lo(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes,
                            size_t frames, int layout, hipStream_t s);
 int lockin_waves_lowpass_lo(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames,
@@ -237,11 +237,12 @@ int check_lo_args(const void *cfg, const void *state, const void *x, const void 
 }
 
 template <int NS>
-int run_biquad_phase(const idsp_biquad_i32 *sec, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+int run_biquad_phase(const idsp_biquad_i32 *sec, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s,
+                     size_t pitch = 0)
 {
     typename LockinBiquadProc<NS>::Params p;
     fill_i32<NS>(sec, p.sec);
-    return launch_stream<LockinBiquadProc<NS>>(p, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, s);
+    return launch_stream<LockinBiquadProc<NS>>(p, state, x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, s, Pitch{pitch, pitch});
 }
 template <int NS>
 int run_biquad_lo_i32(const idsp_biquad_i32 *sec, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames,
@@ -294,6 +295,17 @@ int idsp_lockin_i32_biquad_process(const idsp_biquad_i32 *sections, size_t n, vo
         if (sections[k].frac < 0 || sections[k].frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, sections[k].frac);
     if (lanes == 0 || frames == 0) return IDSP_OK;
     if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_biquad_iq(sections, n, state, x, y, lanes, frames, layout, as_stream(stream));
+    // LaneMajor rows of 32 + 4 k frames that are not whole batches: the whole batches of every row on the multi-wave kernel at the call's row
+    // pitch, the last frames % 16 on the stream kernel behind it (as for the lowpass arms, dds.hip lockin_lm_body)
+    if (layout == IDSP_LANE_MAJOR && frames >= 32 && frames % 4 == 0 && frames % 16 != 0 && waves_take(x, y, lanes, frames - frames % 16, layout)) {
+        const size_t body = frames - frames % 16;
+        if ((rc = lockin_waves_biquad_iq(sections, n, state, x, y, lanes, body, layout, as_stream(stream), frames))) return rc;
+#define IDSP_CALL(NS) run_biquad_phase<NS>(sections, state, x + body, y + 2 * body, lanes, frames - body, layout, as_stream(stream), frames)
+        rc = [&]() -> int { IDSP_BY_SECTIONS(IDSP_CALL) }();
+#undef IDSP_CALL
+        if (rc == IDSP_OK) note_kernel("lockin_waves_kernel + stream kernel (last frames % 16)", "[Biquad; n]");
+        return rc;
+    }
 #define IDSP_CALL(NS) run_biquad_phase<NS>(sections, state, x, y, lanes, frames, layout, as_stream(stream))
     IDSP_BY_SECTIONS(IDSP_CALL)
 #undef IDSP_CALL

@@ -105,7 +105,7 @@ int run_lo_f32(const idsp_biquad_f32 *sec, void *state, const float *x, const fl
 }
 
 template <int NS>
-int run(const idsp_biquad_i32 *sec, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s)
+int run(const idsp_biquad_i32 *sec, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames, int layout, hipStream_t s, size_t pitch)
 {
     typename BqBank<NS>::Params p;
     for (int k = 0; k < NS; k++) {
@@ -113,20 +113,20 @@ int run(const idsp_biquad_i32 *sec, void *state, const int32_t *x, int32_t *y, s
         p.sec[k].frac = sec[k].frac;
         p.sec[k].u = 0, p.sec[k].mn = INT32_MIN, p.sec[k].mx = INT32_MAX;
     }
-    return launch_lockin_waves_bank<MODE_IQ, BqBank<NS>>(p, static_cast<uint32_t *>(state), x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, 4, s);
+    return launch_lockin_waves_bank<MODE_IQ, BqBank<NS>>(p, static_cast<uint32_t *>(state), x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, 4, s, nullptr, pitch);
 }
 
 }  // namespace
 
 // the caller (lockin_generic.hip) has validated the arguments and asked lockin_waves_for() whether the shape is the kernel's
 int lockin_waves_biquad_iq(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
-                           int layout, hipStream_t s)
+                           int layout, hipStream_t s, size_t pitch)
 {
     switch (n) {
-        case 1: return run<1>(sec, state, x, y, lanes, frames, layout, s);
-        case 2: return run<2>(sec, state, x, y, lanes, frames, layout, s);
-        case 3: return run<3>(sec, state, x, y, lanes, frames, layout, s);
-        default: return run<4>(sec, state, x, y, lanes, frames, layout, s);
+        case 1: return run<1>(sec, state, x, y, lanes, frames, layout, s, pitch);
+        case 2: return run<2>(sec, state, x, y, lanes, frames, layout, s, pitch);
+        case 3: return run<3>(sec, state, x, y, lanes, frames, layout, s, pitch);
+        default: return run<4>(sec, state, x, y, lanes, frames, layout, s, pitch);
     }
 }
 

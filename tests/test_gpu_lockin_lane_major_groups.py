@@ -132,3 +132,25 @@ def test_rows_that_are_not_whole_batches(gpu, entry, width, ndt, tdt):
             assert e.last_kernel().startswith("lockin_waves_kernel + stream kernel (last frames % 16)") == split, (e.last_kernel(), frames)
             assert np.array_equal(yg.cpu().numpy(), yo), (entry, lanes, frames, rep)
             assert np.array_equal(sg.cpu().numpy().view(np.uint32), so), (entry, lanes, frames, rep)
+
+
+def test_biquad_arm_rows_that_are_not_whole_batches(gpu):
+    """`Lockin<[Biquad; n]>`, phase form: the same row split as for the lowpass arms."""
+    o, e = H.oracle(), H.engine()
+    rng = np.random.default_rng(4500)
+    for n in (1, 3):
+        arr, _ = G.sections_i32(n, rng)
+        for lanes, frames in [(64, 36), (70, 100), (129, 1000), (64, 34)]:
+            st = np.zeros((2 + 8 * n, lanes), np.uint32)
+            st[:2] = rng.integers(0, 1 << 32, (2, lanes), dtype=np.uint64).astype(np.uint32)
+            st[2:] = rng.integers(-(1 << 20), 1 << 20, (8 * n, lanes)).astype(np.int32).view(np.uint32)
+            so, sg = st.copy(), dev(st)
+            for rep in range(2):
+                x = rng.integers(-(1 << 28), 1 << 28, lanes * frames, dtype=np.int32)
+                yo = np.empty(lanes * frames * 2, np.int32)
+                yg = torch.full((lanes * frames * 2,), -77, dtype=torch.int32, device=DEV)
+                assert o.stream("lockin_i32_biquad_process", arr, n, so, x, yo, lanes, frames, LM) == 0
+                assert e.stream("lockin_i32_biquad_process", arr, n, sg, dev(x), yg, lanes, frames, LM) == 0, e.err()
+                torch.cuda.synchronize()
+                assert e.last_kernel().startswith("lockin_waves_kernel + stream kernel (last frames % 16)") == (frames % 4 == 0), e.last_kernel()
+                assert np.array_equal(yg.cpu().numpy(), yo) and np.array_equal(sg.cpu().numpy().view(np.uint32), so), (n, lanes, frames, rep)
