@@ -20,11 +20,11 @@ namespace idsp {
 int lockin_waves_biquad_iq(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, int32_t *y, size_t lanes, size_t frames,
                            int layout, hipStream_t s, size_t pitch = 0);
 int lockin_waves_biquad_lo(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes,
-                           size_t frames, int layout, hipStream_t s);
+                           size_t frames, int layout, hipStream_t s, size_t pitch = 0);
 int lockin_waves_lowpass_lo(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames,
-                            int layout, hipStream_t s);  // lockin_waves_lo.hip
+                            int layout, hipStream_t s, size_t pitch = 0);  // lockin_waves_lo.hip
 int lockin_waves_biquad_lo_f32(const idsp_biquad_f32 *sec, size_t n, void *state, const float *x, const float *lo, float *y, size_t lanes,
-                               size_t frames, int layout, hipStream_t s);
+                               size_t frames, int layout, hipStream_t s, size_t pitch = 0);
 
 namespace {
 
@@ -38,6 +38,14 @@ inline bool waves_take(const void *x, const void *y, size_t lanes, size_t frames
     static const bool no_waves = diag_env("IDSP_LOCKIN_NO_WAVES") != nullptr;
     const bool lm_ok = frames % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0;
     return !no_waves && lanes < (size_t(1) << 28) && (layout == IDSP_FRAME_MAJOR || lm_ok);
+}
+
+// LaneMajor rows of 32 + 4 k frames that are not whole batches (round 4): the frames of the part the multi-wave kernel takes at the call's row pitch
+// (the last frames % 16 follow on a stream kernel, same stream), 0 = the call is not of that kind
+inline size_t lm_body(const void *x, const void *y, size_t lanes, size_t frames, int layout)
+{
+    if (layout != IDSP_LANE_MAJOR || frames < 32 || frames % 4 != 0 || frames % 16 == 0) return 0;
+    return waves_take(x, y, lanes, frames - frames % 16, layout) ? frames - frames % 16 : 0;
 }
 
 // n serial sections on one arm, state words at `word0` (section-major, {x0,x1,y0,y1} each)
@@ -246,23 +254,24 @@ int run_biquad_phase(const idsp_biquad_i32 *sec, void *state, const int32_t *x, 
 }
 template <int NS>
 int run_biquad_lo_i32(const idsp_biquad_i32 *sec, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames,
-                      int layout, hipStream_t s)
+                      int layout, hipStream_t s, size_t pitch = 0)
 {
     using P = LockinBiquadLoProc<bq::Df1I32<false>, NS>;
     typename P::Params p;
     fill_i32<NS>(sec, p.sec);
-    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, frames};
-    return launch_stream<P>(p, state, reinterpret_cast<const typename P::In *>(lo), reinterpret_cast<typename P::Out *>(y), lanes, frames, layout, s);
+    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, pitch ? pitch : frames};
+    return launch_stream<P>(p, state, reinterpret_cast<const typename P::In *>(lo), reinterpret_cast<typename P::Out *>(y), lanes, frames, layout, s,
+                            Pitch{pitch, pitch});
 }
 template <int NS>
 int run_biquad_lo_f32(const idsp_biquad_f32 *sec, void *state, const float *x, const float *lo, float *y, size_t lanes, size_t frames, int layout,
-                      hipStream_t s)
+                      hipStream_t s, size_t pitch = 0)
 {
     using P = LockinBiquadLoProc<bq::Df1F32<false>, NS>;
     typename P::Params p;
     fill_f32<NS>(sec, p.sec);
-    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, frames};
-    return launch_stream<P>(p, state, reinterpret_cast<const typename P::In *>(lo), reinterpret_cast<typename P::Out *>(y), lanes, frames, layout, s);
+    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, pitch ? pitch : frames};
+    return launch_stream<P>(p, state, reinterpret_cast<const typename P::In *>(lo), reinterpret_cast<typename P::Out *>(y), lanes, frames, layout, s, Pitch{pitch, pitch});
 }
 
 }  // namespace
@@ -297,8 +306,7 @@ int idsp_lockin_i32_biquad_process(const idsp_biquad_i32 *sections, size_t n, vo
     if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_biquad_iq(sections, n, state, x, y, lanes, frames, layout, as_stream(stream));
     // LaneMajor rows of 32 + 4 k frames that are not whole batches: the whole batches of every row on the multi-wave kernel at the call's row
     // pitch, the last frames % 16 on the stream kernel behind it (as for the lowpass arms, dds.hip lockin_lm_body)
-    if (layout == IDSP_LANE_MAJOR && frames >= 32 && frames % 4 == 0 && frames % 16 != 0 && waves_take(x, y, lanes, frames - frames % 16, layout)) {
-        const size_t body = frames - frames % 16;
+    if (const size_t body = lm_body(x, y, lanes, frames, layout)) {
         if ((rc = lockin_waves_biquad_iq(sections, n, state, x, y, lanes, body, layout, as_stream(stream), frames))) return rc;
 #define IDSP_CALL(NS) run_biquad_phase<NS>(sections, state, x + body, y + 2 * body, lanes, frames - body, layout, as_stream(stream), frames)
         rc = [&]() -> int { IDSP_BY_SECTIONS(IDSP_CALL) }();
@@ -320,13 +328,18 @@ int idsp_lockin_i32_lo_process(const idsp_lockin_i32 *cfg, void *state, const in
     if (rc) return rc;
     if (lanes == 0 || frames == 0) return IDSP_OK;
     if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_lowpass_lo(cfg, state, x, lo, y, lanes, frames, layout, as_stream(stream));
+    size_t pitch = 0;
+    if (const size_t body = lm_body(x, y, lanes, frames, layout)) {
+        if ((rc = lockin_waves_lowpass_lo(cfg, state, x, lo, y, lanes, body, layout, as_stream(stream), frames))) return rc;
+        pitch = frames, x += body, lo += 2 * body, y += 2 * body, frames -= body;
+    }
     LpLoParams p;
     p.lp = lp_params(cfg);
-    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, frames};
+    p.xw = XWalk{x, layout == IDSP_FRAME_MAJOR ? 1u : 0u, pitch ? pitch : frames};
     const cplx_i32 *l2 = reinterpret_cast<const cplx_i32 *>(lo);
     Cplx *y2 = reinterpret_cast<Cplx *>(y);
 #define IDSP_CASE(N, K) \
-    if (cfg->order == N && cfg->cascade == K) return launch_stream<LockinLoProc<N, K>>(p, state, l2, y2, lanes, frames, layout, as_stream(stream))
+    if (cfg->order == N && cfg->cascade == K) return launch_stream<LockinLoProc<N, K>>(p, state, l2, y2, lanes, frames, layout, as_stream(stream), Pitch{pitch, pitch})
     IDSP_CASE(1, 1);
     IDSP_CASE(1, 2);
     IDSP_CASE(1, 3);
@@ -349,7 +362,12 @@ int idsp_lockin_i32_biquad_lo_process(const idsp_biquad_i32 *sections, size_t n,
         if (sections[k].frac < 0 || sections[k].frac > 31) return fail(IDSP_EINVAL, "section %zu: frac = %d not in 0..31", k, sections[k].frac);
     if (lanes == 0 || frames == 0) return IDSP_OK;
     if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_biquad_lo(sections, n, state, x, lo, y, lanes, frames, layout, as_stream(stream));
-#define IDSP_CALL(NS) run_biquad_lo_i32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream))
+    size_t pitch = 0;
+    if (const size_t body = lm_body(x, y, lanes, frames, layout)) {
+        if ((rc = lockin_waves_biquad_lo(sections, n, state, x, lo, y, lanes, body, layout, as_stream(stream), frames))) return rc;
+        pitch = frames, x += body, lo += 2 * body, y += 2 * body, frames -= body;
+    }
+#define IDSP_CALL(NS) run_biquad_lo_i32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream), pitch)
     IDSP_BY_SECTIONS(IDSP_CALL)
 #undef IDSP_CALL
 }
@@ -362,7 +380,12 @@ int idsp_lockin_f32_biquad_lo_process(const idsp_biquad_f32 *sections, size_t n,
     if (rc) return rc;
     if (lanes == 0 || frames == 0) return IDSP_OK;
     if (waves_take(x, y, lanes, frames, layout)) return lockin_waves_biquad_lo_f32(sections, n, state, x, lo, y, lanes, frames, layout, as_stream(stream));
-#define IDSP_CALL(NS) run_biquad_lo_f32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream))
+    size_t pitch = 0;
+    if (const size_t body = lm_body(x, y, lanes, frames, layout)) {
+        if ((rc = lockin_waves_biquad_lo_f32(sections, n, state, x, lo, y, lanes, body, layout, as_stream(stream), frames))) return rc;
+        pitch = frames, x += body, lo += 2 * body, y += 2 * body, frames -= body;
+    }
+#define IDSP_CALL(NS) run_biquad_lo_f32<NS>(sections, state, x, lo, y, lanes, frames, layout, as_stream(stream), pitch)
     IDSP_BY_SECTIONS(IDSP_CALL)
 #undef IDSP_CALL
 }

@@ -80,7 +80,7 @@ struct BqLoBankF32 {
 
 template <int NS>
 int run_lo(const idsp_biquad_i32 *sec, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames, int layout,
-           hipStream_t s)
+           hipStream_t s, size_t pitch)
 {
     typename BqLoBank<NS>::Params p;
     for (int k = 0; k < NS; k++) {
@@ -88,11 +88,11 @@ int run_lo(const idsp_biquad_i32 *sec, void *state, const int32_t *x, const int3
         p.sec[k].frac = sec[k].frac;
         p.sec[k].u = 0, p.sec[k].mn = INT32_MIN, p.sec[k].mx = INT32_MAX;
     }
-    return launch_lockin_waves_bank<MODE_IQ, BqLoBank<NS>>(p, static_cast<uint32_t *>(state), x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, 4, s, lo);
+    return launch_lockin_waves_bank<MODE_IQ, BqLoBank<NS>>(p, static_cast<uint32_t *>(state), x, reinterpret_cast<Cplx *>(y), lanes, frames, layout, 4, s, lo, pitch);
 }
 template <int NS>
 int run_lo_f32(const idsp_biquad_f32 *sec, void *state, const float *x, const float *lo, float *y, size_t lanes, size_t frames, int layout,
-               hipStream_t s)
+               hipStream_t s, size_t pitch)
 {
     typename BqLoBankF32<NS>::Params p;
     for (int k = 0; k < NS; k++) {
@@ -101,7 +101,7 @@ int run_lo_f32(const idsp_biquad_f32 *sec, void *state, const float *x, const fl
     }
     return launch_lockin_waves_bank<MODE_IQ, BqLoBankF32<NS>>(p, static_cast<uint32_t *>(state), reinterpret_cast<const int32_t *>(x),
                                                               reinterpret_cast<Cplx *>(y), lanes, frames, layout, 4, s,
-                                                              reinterpret_cast<const int32_t *>(lo));
+                                                              reinterpret_cast<const int32_t *>(lo), pitch);
 }
 
 template <int NS>
@@ -131,23 +131,23 @@ int lockin_waves_biquad_iq(const idsp_biquad_i32 *sec, size_t n, void *state, co
 }
 
 int lockin_waves_biquad_lo(const idsp_biquad_i32 *sec, size_t n, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes,
-                           size_t frames, int layout, hipStream_t s)
+                           size_t frames, int layout, hipStream_t s, size_t pitch)
 {
     switch (n) {
-        case 1: return run_lo<1>(sec, state, x, lo, y, lanes, frames, layout, s);
-        case 2: return run_lo<2>(sec, state, x, lo, y, lanes, frames, layout, s);
-        case 3: return run_lo<3>(sec, state, x, lo, y, lanes, frames, layout, s);
-        default: return run_lo<4>(sec, state, x, lo, y, lanes, frames, layout, s);
+        case 1: return run_lo<1>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
+        case 2: return run_lo<2>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
+        case 3: return run_lo<3>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
+        default: return run_lo<4>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
     }
 }
 int lockin_waves_biquad_lo_f32(const idsp_biquad_f32 *sec, size_t n, void *state, const float *x, const float *lo, float *y, size_t lanes,
-                               size_t frames, int layout, hipStream_t s)
+                               size_t frames, int layout, hipStream_t s, size_t pitch)
 {
     switch (n) {
-        case 1: return run_lo_f32<1>(sec, state, x, lo, y, lanes, frames, layout, s);
-        case 2: return run_lo_f32<2>(sec, state, x, lo, y, lanes, frames, layout, s);
-        case 3: return run_lo_f32<3>(sec, state, x, lo, y, lanes, frames, layout, s);
-        default: return run_lo_f32<4>(sec, state, x, lo, y, lanes, frames, layout, s);
+        case 1: return run_lo_f32<1>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
+        case 2: return run_lo_f32<2>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
+        case 3: return run_lo_f32<3>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
+        default: return run_lo_f32<4>(sec, state, x, lo, y, lanes, frames, layout, s, pitch);
     }
 }
 

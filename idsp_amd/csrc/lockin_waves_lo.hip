@@ -14,13 +14,13 @@ struct LpLoBank : LpBank<N, K> {
 }  // namespace
 
 int lockin_waves_lowpass_lo(const idsp_lockin_i32 *cfg, void *state, const int32_t *x, const int32_t *lo, int32_t *y, size_t lanes, size_t frames,
-                            int layout, hipStream_t s)
+                            int layout, hipStream_t s, size_t pitch)
 {
     const LpParams p = lp_params(cfg);
 #define IDSP_CASE(N, K)                                                                                                                    \
     if (cfg->order == N && cfg->cascade == K)                                                                                               \
     return launch_lockin_waves_bank<MODE_IQ, LpLoBank<N, K>>(p, static_cast<uint32_t *>(state), x, reinterpret_cast<Cplx *>(y), lanes, frames, \
-                                                             layout, 4, s, lo)
+                                                             layout, 4, s, lo, pitch)
     IDSP_CASE(1, 1);
     IDSP_CASE(1, 2);
     IDSP_CASE(1, 3);

@@ -154,3 +154,33 @@ def test_biquad_arm_rows_that_are_not_whole_batches(gpu):
                 torch.cuda.synchronize()
                 assert e.last_kernel().startswith("lockin_waves_kernel + stream kernel (last frames % 16)") == (frames % 4 == 0), e.last_kernel()
                 assert np.array_equal(yg.cpu().numpy(), yo) and np.array_equal(sg.cpu().numpy().view(np.uint32), so), (n, lanes, frames, rep)
+
+
+def test_external_lo_rows_that_are_not_whole_batches(gpu):
+    """the external-LO forms (i32 lowpass arms, i32 / f32 biquad arms): whole batches of every row on the multi-wave kernel, the rest on the
+    stream kernel at the call's row pitch (x, LO and y alike)"""
+    o, e = H.oracle(), H.engine()
+    rng = np.random.default_rng(4600)
+    arr, _ = G.sections_i32(2, rng)
+    arrf, _ = G.sections_f32(2, rng)
+    cfg = H.lockin_cfg([[1 << 22, -(1 << 27)], [1 << 21, -(1 << 26)]])
+    lp_words = H.oracle().fn["lockin_state_words"](C.byref(cfg)) - 2
+    for lanes, frames in [(64, 36), (70, 100), (129, 1000)]:
+        x = [rng.integers(-(1 << 28), 1 << 28, lanes * frames, dtype=np.int32) for _ in range(2)]
+        lo = [rng.integers(-(1 << 31), (1 << 31) - 1, lanes * frames * 2, dtype=np.int64).astype(np.int32) for _ in range(2)]
+        xf = [rng.standard_normal(lanes * frames).astype(np.float32) for _ in range(2)]
+        lof = [rng.standard_normal(lanes * frames * 2).astype(np.float32) for _ in range(2)]
+        cases = [("lockin_i32_lo_process", cfg, None, rng.integers(0, 1 << 32, (lp_words, lanes), dtype=np.uint64).astype(np.uint32), x, lo, np.int32),
+                 ("lockin_i32_biquad_lo_process", arr, 2, rng.integers(-(1 << 20), 1 << 20, (16, lanes)).astype(np.int32).view(np.uint32), x, lo, np.int32),
+                 ("lockin_f32_biquad_lo_process", arrf, 2, rng.standard_normal((16, lanes)).astype(np.float32).view(np.uint32), xf, lof, np.float32)]
+        for name, c, n, st0, xs, los, ydt in cases:
+            so, sg = st0.copy(), dev(st0)
+            for rep in range(2):
+                yo = np.empty(lanes * frames * 2, ydt)
+                yg = torch.full((lanes * frames * 2,), -77, dtype=torch.float32 if ydt == np.float32 else torch.int32, device=DEV)
+                rco = G.call_lo(o, name, c, n, so, xs[rep], los[rep], yo, lanes, frames, LM, False)
+                rcg = G.call_lo(e, name, c, n, sg, dev(xs[rep]), dev(los[rep]), yg, lanes, frames, LM, True)
+                torch.cuda.synchronize()
+                assert rco == 0 and rcg == 0, e.err()
+                assert np.array_equal(yg.cpu().numpy().view(np.uint32), yo.view(np.uint32)), (name, lanes, frames, rep, e.last_kernel())
+                assert np.array_equal(sg.cpu().numpy().view(np.uint32), so), (name, lanes, frames, rep)
