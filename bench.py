@@ -24,8 +24,13 @@ Ranks.  `python bench.py --gpus N` with no torchrun environment starts N ranks i
 this file under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`);
 under an external torchrun (WORLD_SIZE set) it is one of the ranks.  One rank per GPU over RCCL (the
 "nccl" backend on ROCm); when the box has fewer GPUs than ranks the ranks share devices and rendezvous
-over gloo — a control-flow check, said so in the line (`ranks_share_device`).  `rccl_ranks` is the
-result of a 1-int SUM all-reduce over the process group.
+over gloo — a control-flow check, said so in the line (`ranks_share_device`).  `group_ranks` is the
+result of a 1-int SUM all-reduce over the process group; `rccl_ranks` repeats it only when that group is an RCCL
+communicator (null over gloo and for a single process without a group).
+
+The default line also carries `inplace` sub-objects (C2 and C5 with y == x: `SplitInplace::inplace`,
+dsp-process/src/process.rs:135-142, the mode the reference itself benchmarks) and ends with a compact `summary`
+({config: [ms per step, roofline fraction, integrity match]}) as its LAST key.
 
 A step = one pass of the hot path over the rank's batch, state carried from step to step like
 consecutive `block()` calls (dsp-process/src/process.rs:122-127).  Inputs are resident in HBM before
@@ -307,8 +312,10 @@ class HipEngine:
         torch.cuda.set_device(local_rank % n)
         return local_rank % n, n
 
+    INPLACE = True  # this engine runs the `y == x` sub-objects (SplitInplace::inplace, dsp-process/src/process.rs:135-142)
+
     def __init__(self, cfg_name: str, cfg: dict, lane_lo: int, lanes: int, frames: int, layout: str, rank: int,
-                 device_index: int):
+                 device_index: int, inplace: bool = False):
         import torch
 
         from idsp_amd import _abi
@@ -360,7 +367,14 @@ class HipEngine:
             self.x = torch.empty(lanes * frames, dtype=torch.float32, device=self.dev)
             xv = self.x.view(frames, lanes) if self.frame_major else self.x.view(lanes, frames)
             blockwise(lambda f0, f1: c5_input(torch, lane_lo, lanes, f0, f1, layout, self.dev), torch, xv, lanes, frames, layout)
-        if self.family == "biquad":
+        self.inplace = bool(inplace) and self.family == "biquad"
+        self.x0 = None
+        if self.inplace:
+            # SplitInplace::inplace (dsp-process/src/process.rs:135-142): one buffer, y == x.  Every pass overwrites its input, so a
+            # pristine copy restores it before each timed launch and before the integrity step (restore outside the event pair)
+            self.y = self.x
+            self.x0 = self.x.clone()
+        elif self.family == "biquad":
             self.y = torch.empty_like(self.x)  # a plain second allocation: no placement tuning
         self.state = torch.zeros((cfg["state_words"], lanes), dtype=torch.int32, device=self.dev)
         self.reset_state()
@@ -383,6 +397,12 @@ class HipEngine:
     def step(self):
         self.call(self.entry, *self._args)
 
+    def restore(self):
+        """In place only: x back to the pristine input, on the launch stream."""
+        if self.x0 is not None:
+            with self.torch.cuda.stream(self.stream):
+                self.x.copy_(self.x0, non_blocking=True)
+
     def sync(self):
         self.stream.synchronize()
         self.torch.cuda.synchronize()
@@ -393,6 +413,15 @@ class HipEngine:
         event pair around EVERY launch inside the timed region: the records cost 2.5-3.4 % of the step —
         tools/exp_bench_gap.py: 0.3555 ms per step with them, 0.3458 without, kernel median 0.3457 — so `value` read lower
         than the engine's back-to-back rate.  The per-launch figures now come from probe_steps(), outside the timed region.)"""
+        if self.inplace:
+            # y == x: every launch works on the restored input; one event pair per launch, the restores between the pairs
+            ev = [(self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+            for a, b in ev:
+                self.restore()
+                a.record(self.stream)
+                self.step()
+                b.record(self.stream)
+            return lambda: [sum(a.elapsed_time(b) for a, b in ev) / max(k, 1)]
         a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
         a.record(self.stream)
         for _ in range(k):
@@ -404,6 +433,7 @@ class HipEngine:
         """k further launches (untimed), each between its own event pair: per-launch durations in ms."""
         ev = [(self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)) for _ in range(k)]
         for a, b in ev:
+            self.restore()
             a.record(self.stream)
             self.step()
             b.record(self.stream)
@@ -418,6 +448,7 @@ class HipEngine:
 
         self.sync()
         self.reset_state()
+        self.restore()
         self.sync()
         self.step()
         self.sync()
@@ -434,7 +465,7 @@ class HipEngine:
         return self.dev if backend == "nccl" else "cpu"
 
     def free(self):
-        self.x = self.y = self.state = None
+        self.x = self.y = self.state = self.x0 = None
         self.torch.cuda.empty_cache()
 
 
@@ -605,12 +636,13 @@ def committed_traffic(config: str, kernel: str):
         return None, None
 
 
-def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, untimed, kernel, total_lanes):
+def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, untimed, kernel, total_lanes, inplace=False):
     samples_all = total_lanes * frames * cfg.get("samples_per_frame", 1)  # (input) samples per step over all ranks
     alg_bytes = algorithmic_bytes(cfg, lanes_rank, frames)
     med = statistics.median(kern_ms) if kern_ms else 0.0
     achieved = alg_bytes / (med * 1e-3) / 1e9 if med > 0 else 0.0
-    traffic, traffic_src = committed_traffic(cfg_name if args.layout == "frame" else cfg_name + "_lane", kernel) if not args.lanes else (None, None)
+    traffic, traffic_src = (committed_traffic(cfg_name if args.layout == "frame" else cfg_name + "_lane", kernel)
+                            if not args.lanes and not inplace else (None, None))
     return {
         "metric": cfg["metric"],
         "value": round(samples_all * args.steps / elapsed / 1e6, 1),
@@ -629,7 +661,9 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
             "lanes_total": total_lanes, "lanes_per_gpu": lanes_rank, "frames": frames,
             "layout": "FrameMajor" if args.layout == "frame" else "LaneMajor",
             "parallelism": f"lane-split x{world}, no data-path collective",
-            "buffers": "two separate plain allocations", "untimed_steps": untimed, "settle_ms": args.settle_ms,
+            "buffers": ("in place, y == x (SplitInplace::inplace); x restored from a pristine copy before every launch, outside the launch's event pair"
+                        if inplace else "two separate plain allocations"),
+            "untimed_steps": untimed, "settle_ms": args.settle_ms,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -639,6 +673,24 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
             "algorithmic_bytes": alg_bytes,
         },
     }
+
+
+def summary_of(line: dict, head: str) -> dict:
+    """{config: [driver-timed ms per step, roofline fraction of the HIP-event launch average, integrity match]} for the head
+    line and every sub-object — compact (a few hundred characters) and the LAST key of the line."""
+    def entry(o):
+        integ = o.get("integrity") or {}
+        return [o["ms_per_step"], o["roofline"]["frac"], integ.get("match")]
+
+    out = {head: entry(line)}
+    for name in ("c3", "c4", "c5"):
+        if name in line:
+            out[name] = entry(line[name])
+    for name, o in (line.get("lane_major") or {}).items():
+        out[name + "_lm"] = entry(o)
+    for name, o in (line.get("inplace") or {}).items():
+        out[name + "_inplace"] = entry(o)
+    return out
 
 
 # ---------------------------------------------------------------------------------------- ranks
@@ -686,7 +738,7 @@ def gather_ints(values, dist, device):
 
 
 def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend, steps, warmup, settle_ms, lanes_override,
-               frames_override):
+               frames_override, inplace=False):
     """One configuration on this rank: build the engine, the timed region, the reductions and the integrity
     step.  Returns (line or None on ranks > 0, engine) — the caller frees the engine."""
     import torch
@@ -697,9 +749,16 @@ def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend
     frames = frames_override or cfg["frames"]
     lane_lo, lanes_rank = job_shard(cfg, rank, world, lanes_override or None)
     total_lanes = (lanes_override or cfg["lanes"]) * (world if cfg["scaling"] == "weak" else 1)  # replicas count as lanes of their own
-    engine = engine_factory(cfg_name, cfg, lane_lo, lanes_rank, frames, args.layout, rank, local)
+    if inplace:
+        engine = engine_factory(cfg_name, cfg, lane_lo, lanes_rank, frames, args.layout, rank, local, inplace=True)
+    else:
+        engine = engine_factory(cfg_name, cfg, lane_lo, lanes_rank, frames, args.layout, rank, local)
     rdev = engine.reduce_device(backend)
     elapsed, kern_ms, untimed = run_timed(engine, steps, warmup, settle_ms, dist)
+    if inplace and kern_ms:
+        # y == x: the wall-clock interval holds the K restores of x as well; the step time of an in-place pass is the sum of the
+        # K launches' own event-pair durations (timed_steps), which is what `value` and `ms_per_step` are built from here
+        elapsed = kern_ms[0] * steps * 1e-3
     per_launch = engine.probe_steps(min(steps, 50)) if hasattr(engine, "probe_steps") else list(kern_ms)  # outside the timed region
     t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     if dist:
@@ -714,7 +773,7 @@ def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend
         return None, engine
     a = argparse.Namespace(**{**vars(args), "steps": steps, "warmup": warmup, "settle_ms": settle_ms,
                               "lanes": lanes_override, "frames": frames_override})
-    line = report(cfg_name, cfg, a, world, lanes_rank, frames, elapsed_max, kern_ms, untimed, engine.kernel_name(), total_lanes)
+    line = report(cfg_name, cfg, a, world, lanes_rank, frames, elapsed_max, kern_ms, untimed, engine.kernel_name(), total_lanes, inplace)
     if per_launch:
         line["roofline"]["per_launch_ms"] = {"median": round(statistics.median(per_launch), 4), "min": round(min(per_launch), 4),
                                              "launches": len(per_launch), "note": "separate event pair per launch, after the timed region"}
@@ -778,7 +837,7 @@ def rank_main(args, engine_factory=HipEngine):
     if args.config == "c2" and not args.no_c5 and (args.c5_lanes or not (args.lanes or args.frames)):
         # the strong-scaling job beside the weak-scaling headline: 2^20 / N lanes per rank
         sub, e5 = run_config("c5", args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
-                             min(args.warmup, 3), min(args.settle_ms, 100.0), args.c5_lanes, args.c5_frames)
+                             args.warmup, min(args.settle_ms, 100.0), args.c5_lanes, args.c5_frames)
         e5.free()
     subs = {}
     if args.config == "c2" and not (args.lanes or args.frames):
@@ -788,7 +847,7 @@ def rank_main(args, engine_factory=HipEngine):
             if skip or CONFIGS[name]["family"] not in families:
                 continue
             subs[name], e = run_config(name, args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
-                                       min(args.warmup, 3), min(args.settle_ms, 100.0), 0, 0)
+                                       args.warmup, min(args.settle_ms, 100.0), 0, 0)
             e.free()
     lm_subs = {}
     if args.config == "c2" and args.layout == "frame" and not getattr(args, "no_lane_major", False) and not (args.lanes or args.frames):
@@ -800,10 +859,23 @@ def rank_main(args, engine_factory=HipEngine):
             if skip or CONFIGS[name].get("family", "biquad") not in families:
                 continue
             lm_subs[name], e = run_config(name, lm_args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
-                                          min(args.warmup, 3), min(args.settle_ms, 100.0), 0, 0)
+                                          args.warmup, min(args.settle_ms, 100.0), 0, 0)
+            e.free()
+    ip_subs = {}
+    if (args.config == "c2" and args.layout == "frame" and not getattr(args, "no_inplace", False) and getattr(engine_factory, "INPLACE", False)
+            and not (args.lanes or args.frames)):
+        # the reference's own benchmarked mode: SplitInplace::inplace (dsp-process/src/process.rs:135-142; "slice inplace",
+        # tests/embedded/README.md) — C2 and (unless --no-c5) C5 with y == x, same inputs, so the checksums on file hold
+        for name, skip in (("c2", False), ("c5", args.no_c5)):
+            if skip:
+                continue
+            ip_subs[name], e = run_config(name, args, engine_factory, dist, rank, world, local, backend, min(args.steps, 20),
+                                          args.warmup, min(args.settle_ms, 100.0), 0, 0, inplace=True)
             e.free()
     if rank == 0:
-        line["rccl_ranks"] = rccl_ranks
+        # ranks that met in the process group's SUM all-reduce; `rccl_ranks` only when that group IS an RCCL communicator
+        line["group_ranks"] = rccl_ranks
+        line["rccl_ranks"] = rccl_ranks if (backend == "nccl" and dist) else None
         line["backend"] = "nccl (RCCL)" if backend == "nccl" else backend
         line["ranks_share_device"] = shared
         line["launcher"] = os.environ.get("IDSP_BENCH_LAUNCHER", "torchrun (external)" if world > 1 else "single process")
@@ -820,6 +892,9 @@ def rank_main(args, engine_factory=HipEngine):
         if lm_subs:
             keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "integrity")
             line["lane_major"] = {name: {k: sl[k] for k in keep} for name, sl in lm_subs.items()}
+        if ip_subs:
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "integrity")
+            line["inplace"] = {name: {k: sl[k] for k in keep} for name, sl in ip_subs.items()}
         if world == 1 and not args.no_cpu and CONFIGS[args.config].get("family", "biquad") == "biquad":
             cb = cpu_baseline(args.config, CONFIGS[args.config], x_host, args.layout)
             integ = line["integrity"]
@@ -832,6 +907,7 @@ def rank_main(args, engine_factory=HipEngine):
             line["cpu_baseline"] = cb
         else:
             line["cpu_baseline"] = None
+        line["summary"] = summary_of(line, args.config)  # LAST key: the stored tail of a long line still carries every config
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
@@ -852,6 +928,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 strong-scaling sub-object of the default run")
     ap.add_argument("--no-lane-major", action="store_true", help="skip the LaneMajor sub-objects (C2, C3, C4) of the default run")
+    ap.add_argument("--no-inplace", action="store_true", help="skip the in-place (y == x) sub-objects (C2, C5) of the default run")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 (HbfDec /16) sub-object of the default run")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (lock-in) sub-object of the default run")
     ap.add_argument("--c5-lanes", type=int, default=0, help="total lanes of the C5 sub-object (diagnostics; default 2^20)")

@@ -53,13 +53,21 @@ struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
+// set by an atexit handler registered at the first side_stream(): from then on the HIP runtime may already be gone, and a
+// thread that ends during process teardown (a detached worker, a daemon thread joined from atexit) must not call into it
+inline std::atomic<bool> &process_exiting()
+{
+    static std::atomic<bool> flag{false};
+    return flag;
+}
 struct SideStreamTable {
     static constexpr int kMaxDev = 64;
     SideStream e[kMaxDev];
     ~SideStreamTable()
     {
         // The main thread's holder dies at process exit, possibly after the HIP runtime has shut down: leave its streams
-        // to the process teardown.  Worker threads release theirs while the runtime is alive.
+        // to the process teardown.  Worker threads release theirs while the runtime is alive — i.e. before exit() began.
+        if (process_exiting().load(std::memory_order_acquire)) return;
         if (getpid() == pid_t(syscall(SYS_gettid))) return;
         for (SideStream &s : e) {
             if (s.fork) (void)hipEventDestroy(s.fork);
@@ -70,6 +78,8 @@ struct SideStreamTable {
 };
 inline SideStream *side_stream(hipStream_t caller)
 {
+    static const bool hooked = (std::atexit([] { process_exiting().store(true, std::memory_order_release); }), true);
+    (void)hooked;
     static thread_local SideStreamTable table;
     int cur = 0, dev = 0;
     if (hipGetDevice(&cur) != hipSuccess) return nullptr;

@@ -378,7 +378,13 @@ __device__ __forceinline__ void static_for(F &&f)
 // `dwordx4` request starts on a 64-byte boundary (the LDS-DMA destination is fixed by the hardware lane, so the row sits
 // rotated in LDS and the owning thread reads its column through the rotation) ran at 0.56 on EVERY pitch, aligned ones
 // included: the straddling quads were not the cost.
-template <class P, int NB = LdsRingOf<P>::value, int LPT = 1, bool RUN = LdsRunOf<P>::value, bool XCDC = false>
+// ILV (round 5, LPT > 1): the LPT sub-blocks of a workgroup are INTERLEAVED over the row — workgroup w of G owns the 256-lane
+// blocks w, w + G, w + 2G, ... — instead of adjacent.  One round of G workgroups then requests every row as ONE dense piece in
+// the very order the single-round C2 launch does (consecutive 1 KiB segments from consecutive workgroups, i.e. from the 8 XCDs
+// in turn), whatever the lane count: the launch sweeps memory front to back instead of visiting a 256 KiB panel of every row
+// per round (see launch_stream and profiles/NOTES.md, round 5: the strided panel walk is what holds C5 at 0.67-0.70; dense
+// rows run at 0.78 at a 32 GiB footprint as well).
+template <class P, int NB = LdsRingOf<P>::value, int LPT = 1, bool RUN = LdsRunOf<P>::value, bool XCDC = false, bool ILV = false>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes)
@@ -470,13 +476,15 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     const size_t blk = wg_ + rr_ * gridDim.x;
     if (blk >= nblocks) continue;
 #endif
-    const size_t lane0 = blk * kBlockLanes;
+    static_assert(!ILV || (LPT > 1 && !XCDC), "ILV: interleaved sub-blocks of an LPT > 1 workgroup");
+    const size_t lane0 = ILV ? blk * size_t(kFmBlock) : blk * kBlockLanes;
+    const size_t sub = ILV ? nblocks * size_t(kFmBlock) : size_t(kFmBlock);  // lanes between the sub-blocks of this workgroup
     const size_t avail = lanes - lane0;  // lanes of this block that exist (>= 4)
     const bool ragged_block = LPT == 1 && OW == 1 && avail < size_t(kFmBlock);
     const int lid4 = ragged_block && size_t(lid * 4) >= avail ? int(size_t(lid * 4) % avail) : lid * 4;  // first lane of this thread's piece
     const bool lane_ok = !ragged_block || size_t(tid) < avail;
 #pragma unroll
-    for (int s = 0; s < LPT; s++) p[s].load(prm, st, slanes, lane_ok ? lane0 + size_t(s) * kFmBlock + tid : lanes - 1);
+    for (int s = 0; s < LPT; s++) p[s].load(prm, st, slanes, lane_ok ? lane0 + size_t(s) * sub + tid : lanes - 1);
     // The state loads must have landed HERE, in a way the compiler's wait-count pass sees: it cannot see the DMA
     // requests of glds16(), and if it first needs a state register inside the steady-state loop it protects that use
     // with `s_waitcnt vmcnt(0)` on every iteration — which drains the whole prefetch ring each tile (0.52 instead of
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
         for (int j = 0; j < RPW; j++) {
             const int g = wave + 4 * j;
             if ((FULL || g < ns) && IDSP_EXP_LM_LD_ON) {
-                const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * kFmBlock : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * kFmBlock + lid4;
+                const In *src = RUN ? xq + size_t(g / LPT) * xl + (g % LPT) * sub : x + (v * R + g / LPT) * xl + lane0 + (g % LPT) * sub + lid4;
                 if constexpr ((XCDC && !IDSP_XCDC_LOAD_NT) || IDSP_EXP_LDS_PLAIN_LD)
                     glds16_plain(src, lds_base + uint32_t((slot * TS + g) * kFmBlock * 4));
                 else
@@ -527,8 +535,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
                     const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + (g * OW + h) * kFmBlock + lid4);
-                    uint32_t *dst = RUN ? yq + (size_t(g / LPT) * yl + (g % LPT) * kFmBlock) * OW + h * kFmBlock
-                                        : yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * kFmBlock) * OW + h * kFmBlock + lid4;
+                    uint32_t *dst = RUN ? yq + (size_t(g / LPT) * yl + (g % LPT) * sub) * OW + h * kFmBlock
+                                        : yw + ((v * R + g / LPT) * yl + lane0 + (g % LPT) * sub) * OW + h * kFmBlock + lid4;
                     if constexpr ((XCDC && !IDSP_XCDC_STORE_NT) || IDSP_EXP_LDS_PLAIN_ST)
                         *reinterpret_cast<u32x4 *>(dst) = v4;
                     else
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_lds(
     for (; i < ntiles; i++) slow_iter();
 #pragma unroll
     for (int s = 0; s < LPT; s++)
-        if (lane_ok) p[s].store(prm, st, slanes, lane0 + size_t(s) * kFmBlock + tid);
+        if (lane_ok) p[s].store(prm, st, slanes, lane0 + size_t(s) * sub + tid);
     // No barrier needed here: the next block's first lds_barrier() (after each wave's lgkmcnt wait) orders this
     // block's last output-tile reads before the compute() that overwrites the tile, and its first DMA rows only
     // touch input slots whose last readers passed the barrier after the final compute().
@@ -1368,9 +1376,16 @@ template <class T, class = void>
 struct HasCoefPlanes : std::false_type {};
 template <class T>
 struct HasCoefPlanes<T, std::void_t<decltype(std::declval<T>().coef)>> : std::true_type {};
+// (parameters that carry a per-lane side pointer — lockin_generic.hip's XWalk `xw`, computed from the lane index of the WHOLE call —
+// cannot be shifted here: launch_stream's lane splits only take 4-byte-in / 4-byte-out processors, and this assert keeps it so)
+template <class T, class = void>
+struct HasSideWalk : std::false_type {};
+template <class T>
+struct HasSideWalk<T, std::void_t<decltype(std::declval<T>().xw)>> : std::true_type {};
 template <class Params>
 inline Params shift_lanes(Params p, size_t first, size_t elem)
 {
+    static_assert(!HasSideWalk<Params>::value, "lane split of a processor whose parameters hold a side pointer (XWalk): shift it here first");
     if constexpr (HasCoefPlanes<Params>::value) p.coef = static_cast<const char *>(p.coef) + first * elem;
     return p;
 }

@@ -241,6 +241,16 @@ int check_lo_args(const void *cfg, const void *state, const void *x, const void 
     int rc = check_stream_args(cfg, 1, state, x, y, lanes, frames, layout);
     if (rc) return rc;
     if (lanes && frames && !lo) return fail(IDSP_EINVAL, "lo is NULL");
+    // lo and y hold `Complex` pairs and are read / written 8 bytes at a time (i32x2 in lockin_waves.h, cplx_i32 / cplx_f32 in the stream
+    // processors): an address that is only 4-byte aligned is legal by the C signature but would rely on the unaligned-access mode
+    if (reinterpret_cast<uintptr_t>(lo) % 8 || reinterpret_cast<uintptr_t>(y) % 8)
+        return fail(IDSP_EINVAL, "lo and y hold Complex pairs: both must be 8-byte aligned");
+    // three separate buffers (include/idsp_hip.h): x is walked by a side pointer while lo streams through the kernel, no in-place form
+    const uintptr_t n = uintptr_t(lanes) * frames, xb = reinterpret_cast<uintptr_t>(x), lb = reinterpret_cast<uintptr_t>(lo),
+                    yb = reinterpret_cast<uintptr_t>(y);
+    auto meet = [](uintptr_t a, uintptr_t an, uintptr_t b, uintptr_t bn) { return a < b + bn && b < a + an; };
+    if (n && (meet(xb, n * 4, yb, n * 8) || meet(lb, n * 8, yb, n * 8) || meet(xb, n * 4, lb, n * 8)))
+        return fail(IDSP_EINVAL, "x, lo and y must not overlap");
     return IDSP_OK;
 }
 

@@ -743,7 +743,8 @@ int idsp_lockin_i32_norm_sqr(const idsp_lockin_i32 *cfg, void *state, const int3
  * `Biquad<C>`), 1 <= n <= IDSP_LOCKIN_MAX_SECTIONS; the same sections run on I (`state[0]`) and on Q (`state[1]`).
  * External LO: lo[index(f,l)*2 + {0: re, 1: im}] holds `Complex<Q32<32>>` bits (i32) or `Complex<f32>`; the mixer is
  * `x * lo.re`, `x * lo.im` — for i32 `((q as i64 * x as i64) >> 32) as i32` (dsp-fixedpoint/src/lib.rs:449-456), for f32 one
- * rounded multiply — and the output `Complex<X>` = [re, im] adjacent as above.  x, lo and y are three separate buffers.
+ * rounded multiply — and the output `Complex<X>` = [re, im] adjacent as above.  x, lo and y are three separate buffers
+ * (overlap is IDSP_EINVAL), lo and y 8-byte aligned (they hold pairs).
  * The f32 entry with lo = (cos, -sin) is the `mix * lowpass.lanes()` graph of examples/ddc_lockin.rs:35-42.
  * State words per lane: phase form { accu.state, accu.step, I: n x {x0,x1,y0,y1}, Q: n x {x0,x1,y0,y1} };
  * `_lo` forms: the two arms only — biquad arms { I: n x {x0,x1,y0,y1}, Q: ... }, lowpass arms the words of

@@ -1,6 +1,6 @@
 """`bench.py --gpus N` starts N ranks itself.  On CPU: the launcher line is the contract's, and a 2-rank run of
 bench.rank_main (started by bench.spawn exactly as bench.py starts its own ranks; tests/_bench_rank_stub.py injects the
-CPU oracle where bench.py constructs HipEngine) prints ONE line with n_gpus = rccl_ranks = 2, per-rank kernel medians,
+CPU oracle where bench.py constructs HipEngine) prints ONE line with n_gpus = group_ranks = 2 (`rccl_ranks` is null: the group is gloo, not RCCL), per-rank kernel medians,
 the §8e checksum all-reduce, the weak-scaling headline and the strong-scaling C5 sub-object — whose summed checksums
 equal the unsharded oracle run (lanes never meet: dsp-process/src/compose.rs:468-494)."""
 import ctypes as C
@@ -72,7 +72,8 @@ def test_two_ranks_started_by_bench_spawn_print_one_line(tmp_path):
     lines = [ln for ln in open(out).read().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["ranks_share_device"]
+    assert line["n_gpus"] == 2 and line["group_ranks"] == 2 and line["rccl_ranks"] is None and line["backend"] == "gloo" and line["ranks_share_device"]
+    assert list(line)[-1] == "summary" and line["summary"]["c2"][0] == line["ms_per_step"] and "c5" in line["summary"]
     assert line["scaling"] == "weak" and line["config"]["lanes_per_gpu"] == 192 and line["config"]["lanes_total"] == 384
     assert line["steps"] == 3 and len(line["ranks"]["kernel_ms_median"]) == 2 and line["ranks"]["lanes"] == [192, 192]
     assert line["cpu_baseline"] is None
