@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "idsp_hip.h"
 
@@ -170,6 +171,24 @@ inline int ensure_dyn_lds(size_t bytes)
     if (e != hipSuccess) return fail(IDSP_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (dev < 64) done.fetch_or(bit, std::memory_order_release);
     return IDSP_OK;
+}
+
+// The start-up stagger of the line-wise LaneMajor kernels (lockin_waves.h "lanes in phase", dds.hip) spaces the CUs of an XCD by
+// ticks of the 100 MHz wall clock and relies on workgroup b running on XCD b % 8 of a 256-CU part: tuned on MI355X (gfx950) in SPX
+// mode.  On any other part or partition the wait would be pure added latency, so it is armed only there (cached per device).
+inline bool stagger_tuned_device()
+{
+    static std::atomic<int> cache[64];  // 0 unknown, 1 no, 2 yes
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int c = cache[dev].load(std::memory_order_acquire);
+    if (c == 0) {
+        hipDeviceProp_t pr;
+        c = 1;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256 && strncmp(pr.gcnArchName, "gfx950", 6) == 0) c = 2;
+        cache[dev].store(c, std::memory_order_release);
+    }
+    return c == 2;
 }
 
 inline int launch_status()

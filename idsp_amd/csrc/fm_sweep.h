@@ -1,0 +1,461 @@
+// fm_sweep.h — FrameMajor per-lane recurrences as ONE dense sweep over memory, for any lane count (round 5).
+//
+// Replaces the same triple loop as lane_stream.h (dsp-process/src/process.rs:122-141 driven by `Lanes`,
+// dsp-process/src/compose.rs:468-494: any N in `Lanes<C>`).
+//
+// What was measured (profiles/NOTES.md, round 5).  The LDS-DMA kernel of lane_stream.h runs at 0.78 of the HBM peak when
+// its 256 workgroups together cover every row of the tensor as one dense piece (C2: 65536 lanes, 256 KiB rows) — at a
+// 2 GiB and at a 32 GiB footprint alike — and at 0.60-0.70 whenever a round of workgroups covers only a PANEL of every
+// row (more than 65536 lanes on a persistent grid: 256 KiB pieces at a 4 MiB stride for C5), whatever the kernel's inner
+// structure is (role waves with decoupled loads and stores ran the same rates).  The memory system wants the launch as
+// a whole to move front to back through the tensor.  So here the lane count never changes the shape of the walk:
+//
+//   * always ONE round of G <= 256 co-resident workgroups (one per CU); a workgroup owns LPT sub-blocks of `bw` lanes
+//     each, INTERLEAVED over the row: sub-block s of workgroup w = lanes [(s G + w) bw, (s G + w + 1) bw).  Consecutive
+//     blocks of a row belong to consecutive workgroups (the 8 XCDs in turn), every row is requested as one dense piece,
+//     and the launch sweeps x and y front to back exactly as the single-round C2 launch does.  Thread t runs the LPT
+//     independent recurrences of lanes t of its sub-blocks (LPT = 1, 2, 4, 8, 16 — state registers x LPT);
+//   * `bw` <= 256 lanes (a multiple of 16: blocks start on 64-byte boundaries of a 64-byte aligned row) is chosen by the
+//     host so that G LPT bw covers the lanes with less than one workgroup's worth of waste at G close to 256
+//     (sweep_geometry below): 65536 lanes -> 256 x 1 x 256; 100000 -> 241 x 2 x 208; 2^20 -> 256 x 16 x 256.  Pieces
+//     (16 bytes = 4 lanes) beyond a block's `bw` lanes are masked out of the requests and stores (partial EXEC — no
+//     duplicate traffic); a sub-block that lies wholly beyond the last lane (only the last sub-block of the last few
+//     workgroups can) runs as a CLONE of the workgroup's sub-block 0 — same requests, same state, same results stored to
+//     the same addresses — so that every wave issues the same number of memory operations per tile and the hand-counted
+//     `s_waitcnt vmcnt(N)` stays static;
+//   * tiles are always 8 one-KiB segments (ring of NB = 7: 56 KiB of requests in flight per CU, the depth C2 was tuned
+//     to, whatever LPT is): LPT <= 8 -> 8 / LPT frames x LPT sub-blocks, LPT = 16 -> half a frame (the main loop is
+//     unrolled over the tiles of a frame so that the state registers are indexed statically);
+//   * more lanes than 256 x 16 x 256: several such sweeps one after the other inside the launch (`rounds`), each over a
+//     contiguous range of lanes.
+//
+// Everything else (LDS-DMA ring, output staging in LDS, nontemporal 16-byte stores, hand-counted vmcnt, in-place safe
+// because a workgroup's requests run ahead of its own stores) is stream_frame_major_lds's.
+#pragma once
+
+#include "lane_stream.h"
+
+namespace idsp {
+
+constexpr int kSweepNB = 7;    // ring depth in 8 KiB tiles
+constexpr int kSweepT = 8;     // segments per tile
+// schedules of the shipped instantiations (FORM bits, see the kernel; tools/exp_fm_roles.hip measures all of them): full 256-lane blocks are
+// bound by memory and run best on the plain two-barrier schedule (C5 0.75 flat over nine placements of y, against 0.69-0.73 for the others);
+// narrower blocks (lane counts that are no multiple of 65536 / LPT) leave the memory system slack, the serial skeleton shows, and the form that
+// reads the whole tile into registers first is 15-25 % faster there (73728 lanes 0.61 against 0.49 of the HBM peak)
+constexpr int kSweepFormFull = 0, kSweepFormNarrow = 1;
+
+struct SweepGeom {
+    int lpt = 1;             // sub-blocks per workgroup
+    unsigned grid = 0;       // workgroups
+    unsigned bw = 256;       // lanes per sub-block (multiple of 16, <= 256)
+    unsigned rounds = 1;     // sweeps inside the launch
+    size_t round_lanes = 0;  // lanes per sweep (the last one may hold fewer)
+};
+
+// Geometry for `lanes` lanes (a multiple of 4) with at most `max_lpt` sub-blocks per workgroup; false: not coverable
+// (fewer than 16 lanes).  Waste (lanes of capacity beyond the last lane) costs duplicate traffic of at most one
+// workgroup; a grid below 256 leaves CUs idle — scored 4 : 1 (tools/exp_fm_sweep.hip sweeps the alternatives).
+inline bool sweep_geometry(size_t lanes, int max_lpt, SweepGeom &out, unsigned max_grid = 256)
+{
+    if (lanes < 16 || max_lpt < 1) return false;
+    const size_t cap = size_t(max_grid) * size_t(max_lpt) * 256;
+    const size_t rounds = (lanes + cap - 1) / cap;
+    size_t lr = (lanes + rounds - 1) / rounds;
+    lr = (lr + 15) / 16 * 16;
+    int lpt = 1;
+    while (lpt < max_lpt && size_t(max_grid) * size_t(lpt) * 256 < lr) lpt *= 2;
+    double best = 1e30;
+    for (unsigned bw = 256; bw >= 16; bw -= 16) {
+        const size_t per = size_t(lpt) * bw, g = (lr + per - 1) / per;
+        if (g > max_grid) continue;
+        const double waste = double(g * per - lr) / double(lr), idle = double(max_grid - g) / double(max_grid);
+        const double score = waste + 0.25 * idle + (256 - bw) * 1e-5;
+        if (score < best) best = score, out.bw = bw, out.grid = unsigned(g);
+    }
+    if (best >= 1e30) return false;
+    out.lpt = lpt, out.rounds = unsigned(rounds), out.round_lanes = lr;
+    return true;
+}
+
+template <class P>
+constexpr size_t sweep_lds_bytes()
+{
+    return (size_t(kSweepNB) * kSweepT * kFmBlock + 2 * size_t(kSweepT) * kFmBlock * (sizeof(typename P::Out) / 4) + P::LDS_WORDS) * 4;
+}
+
+// FORM bit 0: the tile's samples go to registers before the first step (else read - step - write per sample);
+// FORM bit 1: ONE workgroup barrier per tile (below) instead of two;
+// FORM bit 2 (with bit 1): the wave's second request and second store go out half way through the tile's arithmetic instead of
+// right behind the first ones — the chip's requests then come in two waves per tile period instead of one burst;
+// SLP: `s_sleep SLP` (64 cycles each) before every request (pacing experiment).
+template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0>
+__global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes,
+    const unsigned bw, const unsigned rounds, const size_t round_lanes)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4, "sweep kernel: one 4-byte input per lane and frame");
+    static_assert(LPT >= 1 && (LPT & (LPT - 1)) == 0, "LPT is a power of two");
+    constexpr int OW = sizeof(Out) / 4, B = BatchOf<P>::value, TS = kSweepT;
+    constexpr int SB = LPT < TS ? LPT : TS;  // sub-blocks per tile
+    constexpr int R = TS / SB;               // frames per tile
+    constexpr int PH = LPT / SB;             // tiles per frame group (LPT = 16: 2)
+    constexpr int RPW = TS / 4;              // segments per wave and tile
+    constexpr bool PRE = (FORM & 1) != 0, ONEBAR = (FORM & 2) != 0, SPLIT = (FORM & 4) != 0;
+    static_assert(!SPLIT || (ONEBAR && RPW == 2), "split requests: one-barrier schedule");
+    constexpr int kYoungS = OW + (NB - 2) * (RPW + RPW * OW);  // split schedule: request, stores, request, stores per iteration
+    constexpr int kYoung = RPW * OW + (NB - 1) * (RPW + RPW * OW);
+    constexpr int kYoung1 = RPW * OW + (NB - 2) * (RPW + RPW * OW);  // one-barrier schedule
+    static_assert(kYoung <= 63, "vmcnt range");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *tin = smem;                             // [NB][TS][256]
+    uint32_t *tout = smem + NB * TS * kFmBlock;       // [2][TS][256 * OW]
+    uint32_t *ptab = tout + 2 * TS * kFmBlock * OW;   // [P::LDS_WORDS]
+    const int tid = threadIdx.x, lid = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem;
+    const size_t G = gridDim.x, w = blockIdx.x;
+
+    P p[LPT];
+    if constexpr (P::LDS_WORDS > 0) {
+        P::fill_shared(ptab, tid, kFmBlock);  // published by the first tile barrier
+#pragma unroll
+        for (int s = 0; s < LPT; s++) p[s].set_shared(ptab);
+    }
+
+    // tile position: index, ring slot (index % NB), phase (index % PH), first frame of its frame group and that frame's row offset
+    // — kept as running values (a `% 7` per use is twenty scalar instructions on a wave that has nothing to hide them behind)
+    struct Pos {
+        size_t i;
+        int slot, ph;
+        size_t fr, row;
+    };
+    auto next_pos = [&](Pos &q, size_t pitch) {
+        q.i++;
+        q.slot = q.slot + 1 == NB ? 0 : q.slot + 1;
+        if (PH == 1 || ++q.ph == PH) q.ph = 0, q.fr += R, q.row += size_t(R) * pitch;
+    };
+    const size_t ypitch = yl * OW;  // words between the frames of y
+
+    for (unsigned rd = 0; rd < rounds; rd++) {
+        const size_t rl0 = size_t(rd) * round_lanes;                                    // first lane of this sweep
+        const size_t rlanes = lanes - rl0 < round_lanes ? lanes - rl0 : round_lanes;     // its lanes
+        if (w * bw >= rlanes) break;  // not even sub-block 0 exists (only beyond the data: later sweeps hold no more lanes than this one)
+        // sub-block s: first lane (relative to the sweep) and number of lanes that exist; absent -> clone of sub-block 0
+        auto sub_first = [&](int s) -> size_t {
+            const size_t f = (size_t(s) * G + w) * bw;
+            return f < rlanes ? f : w * bw;
+        };
+        auto sub_count = [&](int s) -> unsigned {
+            size_t f = (size_t(s) * G + w) * bw;
+            if (f >= rlanes) f = w * bw;
+            return rlanes - f < bw ? unsigned(rlanes - f) : bw;
+        };
+        auto sub_present = [&](int s) { return (size_t(s) * G + w) * bw < rlanes; };
+
+#pragma unroll
+        for (int s = 0; s < LPT; s++) {
+            const size_t f = sub_first(s);
+            p[s].load(prm, st, slanes, rl0 + f + (unsigned(tid) < sub_count(s) ? size_t(tid) : 0));
+        }
+        // the state loads must have landed HERE, where the compiler's wait-count pass sees it (see stream_frame_major_lds)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+
+        const size_t ngroups = (frames + R - 1) / R;  // frame groups of R frames
+        const size_t ntiles = ngroups * PH;
+        const size_t nfull = (frames / R) * PH;        // tiles [0, nfull) hold R whole frames
+        const In *xr = x + rl0;
+        uint32_t *yr = reinterpret_cast<uint32_t *>(y) + rl0 * OW;
+
+        // This wave's segments of a tile: g = wave + 4 j; in phase ph that is frame offset g / SB of the group and sub-block
+        // ph SB + g % SB.  Their lane offsets, counts and complete element / word offsets are constants of the sweep.
+        int sfo[RPW];
+        size_t sfst[RPW][PH], sxo[RPW][PH], syo[RPW][PH];
+        unsigned scnt[RPW][PH];
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int g = wave + 4 * j;
+            sfo[j] = g / SB;
+#pragma unroll
+            for (int ph = 0; ph < PH; ph++) {
+                const int s = ph * SB + g % SB;
+                sfst[j][ph] = sub_first(s), scnt[j][ph] = sub_count(s);
+                sxo[j][ph] = size_t(sfo[j]) * xl + sfst[j][ph];
+                syo[j][ph] = (size_t(sfo[j]) * yl + sfst[j][ph]) * OW;
+            }
+        }
+        auto pick = [&](auto &arr, int ph) {  // arr[ph] for a phase known at run time only
+            auto v = arr[0];
+#pragma unroll
+            for (int q = 1; q < PH; q++)
+                if (ph == q) v = arr[q];
+            return v;
+        };
+
+        // requests of the tile at position q (phase static in the steady state: PHS >= 0)
+        auto issue = [&](const Pos &q, auto phs, auto full, int j0 = 0, int j1 = RPW) {
+            constexpr bool FULL = decltype(full)::value;
+            constexpr int PHS = decltype(phs)::value;
+#pragma unroll
+            for (int j = 0; j < RPW; j++) {
+                if (j < j0 || j >= j1) continue;
+                if (SLP) __builtin_amdgcn_s_sleep(SLP);
+                const unsigned cnt = PHS >= 0 ? scnt[j][PHS >= 0 ? PHS : 0] : pick(scnt[j], q.ph);
+                const In *base;
+                if (FULL || q.fr + sfo[j] < frames)
+                    base = xr + q.row + (PHS >= 0 ? sxo[j][PHS >= 0 ? PHS : 0] : pick(sxo[j], q.ph));
+                else  // ragged tile: re-request the last frame (static request count)
+                    base = xr + (frames - 1) * xl + (PHS >= 0 ? sfst[j][PHS >= 0 ? PHS : 0] : pick(sfst[j], q.ph));
+                if (unsigned(lid * 4) < cnt) glds16_s(base, uint32_t(lid) * 16u, lds_base + uint32_t((q.slot * TS + wave + 4 * j) * kFmBlock * 4));
+            }
+        };
+        // stores of the tile at position q (q.row counts words of y)
+        auto store = [&](const Pos &q, auto phs, auto full, int j0 = 0, int j1 = RPW) {
+            constexpr bool FULL = decltype(full)::value;
+            constexpr int PHS = decltype(phs)::value;
+            const uint32_t *o = tout + (q.i & 1) * TS * kFmBlock * OW;
+#pragma unroll
+            for (int j = 0; j < RPW; j++) {
+                if (j < j0 || j >= j1) continue;
+                const int g = wave + 4 * j;
+                const bool row_ok = FULL || q.fr + sfo[j] < frames;
+                const unsigned nv = PHS >= 0 ? scnt[j][PHS >= 0 ? PHS : 0] : pick(scnt[j], q.ph);
+                int gsrc = g;  // segment of the output tile this wave-instruction reads
+                uint32_t *base;
+                if (row_ok) {
+                    base = yr + q.row + (PHS >= 0 ? syo[j][PHS >= 0 ? PHS : 0] : pick(syo[j], q.ph));
+                } else {  // a row beyond the data: the tile's last real row instead
+                    gsrc = int(frames - 1 - q.fr) * SB + g % SB;
+                    base = yr + ((frames - 1) * yl + (PHS >= 0 ? sfst[j][PHS >= 0 ? PHS : 0] : pick(sfst[j], q.ph))) * OW;
+                }
+#pragma unroll
+                for (int h = 0; h < OW; h++) {
+                    // piece (h, lid) holds lanes (h 256 + lid 4) / OW ... of the sub-block
+                    const unsigned first = unsigned(h * kFmBlock + lid * 4) / OW;
+                    bool on = first < nv && row_ok;
+                    int word = h * kFmBlock + lid * 4;
+                    if (!row_ok || unsigned(h * kFmBlock) / OW >= nv) {
+                        // no piece of this wave-instruction exists (a row beyond the data, or OW = 2 and nv <= 128): thread 0 stores the first
+                        // piece of the sub-block's last real row once more (same bytes as its owner stores), so that the instruction is
+                        // issued and the hand-counted vmcnt stays exact
+                        on = lid == 0;
+                        word = 0;
+                    }
+                    if (on) {
+                        const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + gsrc * OW * kFmBlock + word);
+                        __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(base + word));
+                    }
+                }
+            }
+        };
+        auto compute = [&](const Pos &q, auto phase, auto full, auto &&mid) {  // mid(): called half way through the tile's steps
+            constexpr bool FULL = decltype(full)::value;
+            constexpr int ph = decltype(phase)::value;
+            const uint32_t *in = tin + q.slot * TS * kFmBlock;
+            uint32_t *o = tout + (q.i & 1) * TS * kFmBlock * OW;
+            const int nr = FULL || frames - q.fr >= size_t(R) ? R : int(frames - q.fr);  // rows of this tile that exist
+            if constexpr (!PRE) {
+                static_for<TS>([&](auto gg) {
+                    constexpr int g = decltype(gg)::value;
+                    constexpr int s = ph * SB + g % SB;
+                    if (g == TS / 2) mid();
+                    if (FULL || g / SB < nr) to_words<Out>(step1(p[s], prm, __builtin_bit_cast(In, in[g * kFmBlock + tid])), o + (g * kFmBlock + tid) * OW);
+                });
+                return;
+            }
+            // PRE: the tile's samples of this thread go to registers FIRST, all TS of them, and the results leave after the last step: input
+            // ring and output tile are one LDS array to the compiler, so a `read, step, write` loop keeps every read behind the previous
+            // step's write and pays the LDS latency once per step.
+            In v[TS];
+            Out r[TS];
+#pragma unroll
+            for (int g = 0; g < TS; g++) v[g] = __builtin_bit_cast(In, in[g * kFmBlock + tid]);
+            if constexpr (B > 1 && LPT == 1) {  // segments are consecutive frames of one lane
+#pragma unroll
+                for (int r0 = 0; r0 < TS; r0 += B) {
+                    if (!FULL && r0 >= nr) break;
+                    typename P::Pre pre[B];
+#pragma unroll
+                    for (int b = 0; b < B; b++)
+                        if (FULL || r0 + b < nr) pre[b] = p[0].pre(prm);
+#pragma unroll
+                    for (int b = 0; b < B; b++) {
+                        const int k = r0 + b;
+                        if (FULL || k < nr) r[k] = p[0].step(prm, v[k], pre[b]);
+                    }
+                    if (r0 + B == TS / 2 || (B > TS / 2 && r0 == 0)) mid();
+                }
+            } else {
+                static_for<TS>([&](auto gg) {
+                    constexpr int g = decltype(gg)::value;  // static: the LPT states stay in registers
+                    constexpr int s = ph * SB + g % SB;
+                    if (g == TS / 2) mid();
+                    if (FULL || g / SB < nr) r[g] = step1(p[s], prm, v[g]);
+                });
+            }
+#pragma unroll
+            for (int g = 0; g < TS; g++)
+                if (FULL || g / SB < nr) to_words<Out>(r[g], o + (g * kFmBlock + tid) * OW);
+        };
+        auto compute_dyn = [&](const Pos &q, auto full) {  // tile phase known at run time only (start-up and drain)
+            static_for<PH>([&](auto pp) {
+                if (q.ph == decltype(pp)::value) compute(q, pp, full, [] {});
+            });
+        };
+
+        using Full = std::true_type;
+        using Ragged = std::false_type;
+        using Dyn = std::integral_constant<int, -1>;
+        Pos qi{0, 0, 0, 0, 0}, qc{0, 0, 0, 0, 0};  // next tile to request (rows in elements of x), tile to compute (rows in words of y)
+        if constexpr (ONEBAR) {
+            // One barrier per tile.  After barrier i every wave's share of tile i has landed (each waited for its own requests) AND
+            // every wave is done with tile i - 1: its input slot is free for tile i + NB - 1 and its output tile is complete.  So the
+            // request, the stores of tile i - 1 and the LDS reads of tile i all go out together, and the arithmetic follows.
+            Pos qs = qc;  // tile to store: one behind qc
+            for (; qi.i + 1 < size_t(NB) && qi.i < ntiles; next_pos(qi, xl)) issue(qi, Dyn{}, Ragged{});
+            auto slow_iter = [&]() {
+                wait_vmcnt<0>();
+                lds_barrier();
+                if (qi.i < ntiles) issue(qi, Dyn{}, Ragged{}), next_pos(qi, xl);
+                if (qc.i >= 1) store(qs, Dyn{}, Ragged{}), next_pos(qs, ypitch);
+                compute_dyn(qc, Ragged{});
+                next_pos(qc, ypitch);
+            };
+            while (qc.i < ntiles && (qc.i < size_t(NB) || qc.ph != 0)) slow_iter();
+            // steady state: younger than tile ii's requests are the stores of tile ii - NB and the requests and stores of the NB - 2
+            // iterations since
+            while (qc.i + NB - 1 + PH <= nfull) {
+                static_for<PH>([&](auto pp) {
+                    constexpr int ph = decltype(pp)::value;
+                    using PhI = std::integral_constant<int, (ph + NB - 1) % PH>;
+                    using PhS = std::integral_constant<int, (ph + PH - 1) % PH>;
+                    if constexpr (SPLIT) {
+                        wait_vmcnt<kYoungS>();
+                        lds_barrier();
+                        issue(qi, PhI{}, Full{}, 0, 1);
+                        store(qs, PhS{}, Full{}, 0, 1);
+                        compute(qc, pp, Full{}, [&] {
+                            issue(qi, PhI{}, Full{}, 1, 2);
+                            store(qs, PhS{}, Full{}, 1, 2);
+                        });
+                    } else {
+                        wait_vmcnt<kYoung1>();
+                        lds_barrier();
+                        issue(qi, PhI{}, Full{});
+                        store(qs, PhS{}, Full{});
+                        compute(qc, pp, Full{}, [] {});
+                    }
+                    next_pos(qi, xl);
+                    next_pos(qs, ypitch);
+                    next_pos(qc, ypitch);
+                });
+            }
+            while (qc.i < ntiles) slow_iter();
+            lds_barrier();  // the last output tile is complete
+            store(qs, Dyn{}, Ragged{});
+        } else {
+            for (; qi.i < size_t(NB) && qi.i < ntiles; next_pos(qi, xl)) issue(qi, Dyn{}, Ragged{});
+            auto slow_iter = [&]() {  // start-up, drain and ragged tiles: wait for everything
+                wait_vmcnt<0>();
+                lds_barrier();
+                compute_dyn(qc, Ragged{});
+                lds_barrier();
+                if (qi.i < ntiles) issue(qi, Dyn{}, Ragged{}), next_pos(qi, xl);
+                store(qc, Dyn{}, Ragged{});
+                next_pos(qc, ypitch);
+            };
+            while (qc.i < ntiles && (qc.i < size_t(NB) || qc.ph != 0)) slow_iter();
+            // steady state: every tile involved is full and every wave has issued exactly RPW requests and RPW * OW stores per
+            // past tile, so kYoung younger operations may stay in flight
+            while (qc.i + NB + PH <= nfull) {
+                static_for<PH>([&](auto pp) {
+                    constexpr int ph = decltype(pp)::value;
+                    wait_vmcnt<kYoung>();
+                    lds_barrier();  // all four waves' segments of the tile have landed
+                    compute(qc, pp, Full{}, [] {});
+                    lds_barrier();  // output tile complete; the tile's ring slot is free again
+                    issue(qi, std::integral_constant<int, (ph + NB) % PH>{}, Full{});
+                    next_pos(qi, xl);
+                    store(qc, pp, Full{});
+                    next_pos(qc, ypitch);
+                });
+            }
+            while (qc.i < ntiles) slow_iter();
+        }
+#pragma unroll
+        for (int s = 0; s < LPT; s++)
+            if (sub_present(s) && unsigned(tid) < sub_count(s)) p[s].store(prm, st, slanes, rl0 + sub_first(s) + tid);
+        // (no barrier before the next sweep: its first lds_barrier() orders this sweep's last output-tile reads before the compute()
+        // that overwrites the tile, and its first requests only touch input slots whose last readers passed the final barrier)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+// Largest LPT a processor is instantiated with (each doubling doubles its state registers and the unrolled loop body): the
+// cheap single sections take every lane count up to 2^20 in ONE sweep; heavier bodies are bound by the VALU long before that
+// and run larger lane counts as several sweeps over lane ranges.  P::SWEEP_MAX_LPT overrides.
+template <class P, class = void>
+struct SweepMaxLptOf {
+    static constexpr int value = P::COST <= 60 ? 16 : P::COST <= 120 ? 4 : 2;
+};
+template <class P>
+struct SweepMaxLptOf<P, std::void_t<decltype(P::SWEEP_MAX_LPT)>> {
+    static constexpr int value = P::SWEEP_MAX_LPT;
+};
+// smallest lane count the sweep kernel takes (below, the staged single-wave kernel's 36 ns per frame beat its barriers)
+constexpr size_t kSweepMinLanes = 49152;
+
+template <class P, int LPT>
+int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename P::In *x, typename P::Out *y, size_t lanes, size_t frames, size_t xl,
+                     size_t yl, size_t sp, const SweepGeom &g, hipStream_t s)
+{
+    constexpr size_t bytes = sweep_lds_bytes<P>();
+    if (g.bw == unsigned(kFmBlock)) {
+        if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormFull>>(bytes)) return rc;
+        hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormFull>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
+                           g.bw, g.rounds, g.round_lanes);
+    } else {
+        if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>>(bytes)) return rc;
+        hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
+                           g.bw, g.rounds, g.round_lanes);
+    }
+    return launch_status();
+}
+
+// The launch for `lanes` lanes (a multiple of 4; rows on the 64-byte grid: launch_stream checks).  Returns IDSP_OK or an error.
+template <class P>
+int launch_sweep(const typename P::Params &prm, uint32_t *st, const typename P::In *x, typename P::Out *y, size_t lanes, size_t frames, size_t xl, size_t yl,
+                 size_t sp, hipStream_t s)
+{
+    constexpr int kMax = SweepMaxLptOf<P>::value;
+    SweepGeom g;
+    // (IDSP_DIAG=1 IDSP_SWEEP_MAX_GRID=n: at most n workgroups — small tensors then reach every LPT and several sweeps per launch: tests)
+    static const unsigned max_grid = unsigned(diag_size("IDSP_SWEEP_MAX_GRID", 256));
+    if (!sweep_geometry(lanes, kMax, g, max_grid ? max_grid : 256u)) return fail(IDSP_EINVAL, "internal: no sweep geometry for %zu lanes", lanes);
+    static const char *const names[] = {"stream_frame_major_sweep[1 block/workgroup]", "stream_frame_major_sweep[2 blocks/workgroup]",
+                                        "stream_frame_major_sweep[4 blocks/workgroup]", "stream_frame_major_sweep[8 blocks/workgroup]",
+                                        "stream_frame_major_sweep[16 blocks/workgroup]"};
+    int k = 0;
+    while ((1 << k) < g.lpt) k++;
+    note_kernel(names[k], typeid(P).name());
+    if constexpr (kMax >= 16) {
+        if (g.lpt == 16) return launch_sweep_lpt<P, 16>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+    }
+    if constexpr (kMax >= 8) {
+        if (g.lpt == 8) return launch_sweep_lpt<P, 8>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+    }
+    if constexpr (kMax >= 4) {
+        if (g.lpt == 4) return launch_sweep_lpt<P, 4>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+    }
+    if constexpr (kMax >= 2) {
+        if (g.lpt == 2) return launch_sweep_lpt<P, 2>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+    }
+    return launch_sweep_lpt<P, 1>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+}
+
+}  // namespace idsp

@@ -757,6 +757,7 @@ template <int TS, int S>
 int launch_ring(uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm, hipStream_t stream)
 {
     using L = Lay<TS, S>;
+    if (lanes > 0x7fffffffu) return 1;  // one workgroup per lane (LaneMajor) in a 31-bit grid: not covered beyond, as in cic_ring_host.h
     if (lm) {
         // ring of 4 slots (18 waves per CU, three requests each in flight); 8 slots (12 waves, seven each) measured slower at C3:
         // 0.955 against 0.892 ms, the arithmetic alone (no requests) 0.643 against 0.567 — the occupancy matters more than the depth

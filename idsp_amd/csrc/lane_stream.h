@@ -1347,6 +1347,10 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_few(
     if (own) p.store(prm, st, slanes, size_t(t));
 }
 
+}  // namespace idsp
+#include "fm_sweep.h"  // the dense-sweep FrameMajor kernel (round 5): needs everything above, is needed by launch_stream below
+namespace idsp {
+
 // --------------------------------------------------------------------- launch
 // Prefetch depth by occupancy: at <= 2 waves/SIMD nothing else hides HBM
 // latency, so go deep; with many resident waves keep the register budget low.
@@ -1502,15 +1506,37 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
                     IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
                     int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, sp);
+                    // (rows on the 64-byte grid: the whole rounds went to the dense-sweep kernel, fm_sweep.h)
+                    const bool head_swept = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * 4) % 64 == 0 && (yl * 4) % 64 == 0;
                     if (rc == IDSP_OK)
                         rc = launch_stream<P>(shift_lanes(prm, head, sizeof(typename P::In)), st + head, x + head, y + head, tail, frames, layout, ss->stream,
                                               Pitch{xl, yl}, sp);
                     // join even after a failed launch: the caller's stream must not run ahead of whatever the side stream holds
                     IDSP_HIP_TRY(hipEventRecord(ss->join, ss->stream));
                     IDSP_HIP_TRY(hipStreamWaitEvent(s, ss->join, 0));
-                    if (rc == IDSP_OK) note_kernel("stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)", typeid(P).name());
+                    if (rc == IDSP_OK)
+                        note_kernel(head_swept ? "stream_frame_major_sweep + stream_frame_major_staged (remainder, second stream)"
+                                               : "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)",
+                                    typeid(P).name());
                     return rc;
                 }
+            }
+        }
+        if constexpr (P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4) {
+            // Round 5: ONE dense sweep for any lane count (fm_sweep.h).  Every lane count from kSweepMinLanes up on rows that sit on the
+            // 64-byte grid goes here — whole multiples of 65536, ragged counts, 2^20 lanes alike — instead of panel walks of a persistent
+            // grid or a ragged last block.  (Lane counts a little above a multiple of 65536 were split above: their whole rounds come back
+            // here as full 256-lane blocks, the remainder runs beside them — 65552 lanes: 0.77 of the HBM peak against 0.54 as one sweep of
+            // half-empty blocks.)  (IDSP_DIAG=1 IDSP_NO_SWEEP=1: the round-4
+            // dispatch below.)  Rows off the 64-byte grid keep the XCD-contiguous LDS-DMA kernel.
+            static const bool no_sweep = diag_env("IDSP_NO_SWEEP") != nullptr;
+            static const size_t sweep_min = diag_size("IDSP_SWEEP_MIN_LANES", kSweepMinLanes);
+            static const bool cost_forced_ = diag_env("IDSP_LDS_COST") != nullptr, no_lds_ = diag_env("IDSP_NO_LDS_PATH") != nullptr;
+            const bool on_grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * sizeof(typename P::In)) % 64 == 0 &&
+                                   (yl * sizeof(typename P::Out)) % 64 == 0;
+            if constexpr (LdsEligibleOf<P>::value) {
+                if (!no_sweep && !cost_forced_ && !no_lds_ && on_grid64 && lanes % 4 == 0 && lanes >= sweep_min && frames >= 16)
+                    return launch_sweep<P>(prm, st, x, y, lanes, frames, xl, yl, sp, s);
             }
         }
         if constexpr (FmStagedOf<P>::value) {

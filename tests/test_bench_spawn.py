@@ -151,3 +151,28 @@ def test_c3_c4_inputs_are_the_same_on_host_and_device_code_paths_and_their_check
     assert bench.job_shard(bench.CONFIGS["c3"], 3, 8) == (0, 16384) and bench.job_shard(bench.CONFIGS["c4"], 1, 2) == (0, 32768)
     assert bench.algorithmic_bytes(bench.CONFIGS["c3"], 16384, 4096) == 16384 * 4096 * 68 + 2 * 118 * 4 * 16384
     assert bench.algorithmic_bytes(bench.CONFIGS["c4"], 32768, 4096) == 32768 * 4096 * 12 + 2 * 18 * 4 * 32768
+
+
+def test_eight_ranks_rendezvous_and_c5_blocks(tmp_path):
+    """World size 8 (what the driver's 8-GPU run uses) over gloo on this CPU box with scaled-down lanes: the rendezvous, the
+    per-rank C5 shards of lane_shard(lanes, g, 8), the rank-0 JSON assembly and the `summary` tail hold at N = 8."""
+    import bench
+    from idsp_amd.sharding import lane_shard
+
+    out = tmp_path / "line8.txt"
+    argv = ["--gpus", "8", "--steps", "2", "--warmup", "1", "--settle-ms", "0", "--lanes", "64", "--frames", "24",
+            "--c5-lanes", "2056", "--c5-frames", "24"]
+    env = dict(os.environ, IDSP_BENCH_LAUNCHER="self-spawned torch.distributed.run")
+    env.pop("WORLD_SIZE", None)
+    with open(out, "w") as fh:
+        rc = subprocess.call(bench.spawn_command(8, argv, STUB), stdout=fh, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=600)
+    assert rc == 0
+    lines = [ln for ln in open(out).read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["group_ranks"] == 8 and line["rccl_ranks"] is None
+    assert line["config"]["lanes_total"] == 8 * 64 and len(line["ranks"]["lanes"]) == 8
+    shards = [lane_shard(2056, g, 8) for g in range(8)]
+    assert line["c5"]["ranks"]["first_lane"] == [lo for lo, _ in shards]
+    assert line["c5"]["ranks"]["lanes"] == [hi - lo for lo, hi in shards] and sum(line["c5"]["ranks"]["lanes"]) == 2056
+    assert list(line)[-1] == "summary" and set(line["summary"]) >= {"c2", "c5"}

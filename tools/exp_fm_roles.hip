@@ -7,10 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "biquad_sections.h"
 #include "fm_roles.h"
+#include "fm_sweep.h"
 
 namespace idsp {
 char *last_error_buf() { static thread_local char b[512]; return b; }
@@ -110,6 +112,31 @@ static void launch_lpt(const Ctx<P> &c, typename P::Out *y)
                        c.lanes, c.frames, c.lanes, c.lanes, c.lanes);
 }
 
+static SweepGeom g_geom;
+template <class P, int LPT, int NB, int FORM, int SLP = 0>
+static void launch_sweep_lpt(const Ctx<P> &c, typename P::Out *y)
+{
+    constexpr size_t bytes = (size_t(NB) * kSweepT * kFmBlock + 2 * size_t(kSweepT) * kFmBlock) * 4;
+    static bool once = false;
+    if (!once) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_sweep<P, LPT, NB, FORM, SLP>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+        once = true;
+    }
+    hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, NB, FORM, SLP>), dim3(g_geom.grid), dim3(kFmBlock), bytes, 0, c.prm, c.st, c.x, y, c.lanes, c.frames, c.lanes, c.lanes,
+                       c.lanes, g_geom.bw, g_geom.rounds, g_geom.round_lanes);
+}
+template <class P, int NB, int FORM, int SLP = 0>
+static void launch_sweep(const Ctx<P> &c, typename P::Out *y)
+{
+    switch (g_geom.lpt) {
+        case 1: return launch_sweep_lpt<P, 1, NB, FORM, SLP>(c, y);
+        case 2: return launch_sweep_lpt<P, 2, NB, FORM, SLP>(c, y);
+        case 4: return launch_sweep_lpt<P, 4, NB, FORM, SLP>(c, y);
+        case 8: return launch_sweep_lpt<P, 8, NB, FORM, SLP>(c, y);
+        default: return launch_sweep_lpt<P, 16, NB, FORM, SLP>(c, y);
+    }
+}
+
 template <class P, int NB, int NLW, int NSW>
 static void launch_roles(const Ctx<P> &c, typename P::Out *y, unsigned grid, int order)
 {
@@ -170,7 +197,16 @@ static int run(const char *name, size_t lanes, size_t frames)
     const size_t deltas[] = {0, 4096, 65536, 262144, 1 << 20, 2 << 20, (6 << 20) + 8192, 25165824, 33554432 + 65536};
     const char *only = getenv("EXP_ONLY");  // comma-free substring filter on the variant name
     auto sweep = [&](const char *variant, unsigned grid, auto &&launch) {
-        if (only && !strstr(variant, only)) return;
+        if (only) {  // '|'-separated substrings
+            bool hit = false;
+            std::string o(only);
+            for (size_t a = 0; a <= o.size();) {
+                const size_t b = o.find('|', a) == std::string::npos ? o.size() : o.find('|', a);
+                if (b > a && strstr(variant, o.substr(a, b - a).c_str())) hit = true;
+                a = b + 1;
+            }
+            if (!hit) return;
+        }
         const unsigned long long bad = check(launch);
         std::vector<double> fr;
         for (size_t d : deltas) {
@@ -196,6 +232,18 @@ static int run(const char *name, size_t lanes, size_t frames)
     const unsigned g1 = lib_grid(lanes);
     const size_t wgs = (lanes + kFmBlock - 1) / kFmBlock;
     sweep("old lds nb7", g1, [&](T *y) { launch_old<P>(c, y); });
+    {
+        const int max_lpt = getenv("EXP_MAX_LPT") ? atoi(getenv("EXP_MAX_LPT")) : 16;
+        const unsigned max_grid = getenv("EXP_MAX_GRID") ? unsigned(atoi(getenv("EXP_MAX_GRID"))) : 256u;
+        if (sweep_geometry(lanes, max_lpt, g_geom, max_grid)) {
+            if (getenv("EXP_BW")) g_geom.bw = unsigned(atoi(getenv("EXP_BW")));
+            if (getenv("EXP_GRID")) g_geom.grid = unsigned(atoi(getenv("EXP_GRID")));
+            char nm[96];
+#define SW(F, N, S) snprintf(nm, sizeof nm, "sweep f" #F " nb" #N " slp" #S " lpt%d bw%u", g_geom.lpt, g_geom.bw); sweep(nm, g_geom.grid, [&](T *y) { launch_sweep<P, N, F, S>(c, y); });
+            SW(0, 7, 0) SW(1, 7, 0) SW(2, 7, 0) SW(3, 7, 0)
+#undef SW
+        }
+    }
     auto lpt_sweeps = [&](auto lpt_tag) {
         constexpr int L = decltype(lpt_tag)::value;
         if (wgs % L || wgs / L < 128 || wgs / L > 1024) return;
