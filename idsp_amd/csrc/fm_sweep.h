@@ -79,9 +79,9 @@ inline bool sweep_geometry(size_t lanes, int max_lpt, SweepGeom &out, unsigned m
 }
 
 template <class P>
-constexpr size_t sweep_lds_bytes()
+constexpr size_t sweep_lds_bytes(int nb = kSweepNB, int ts = kSweepT)
 {
-    return (size_t(kSweepNB) * kSweepT * kFmBlock + 2 * size_t(kSweepT) * kFmBlock * (sizeof(typename P::Out) / 4) + P::LDS_WORDS) * 4;
+    return (size_t(nb) * ts * kFmBlock + 2 * size_t(ts) * kFmBlock * (sizeof(typename P::Out) / 4) + P::LDS_WORDS) * 4;
 }
 
 // FORM bit 0: the tile's samples go to registers before the first step (else read - step - write per sample);
@@ -89,7 +89,8 @@ constexpr size_t sweep_lds_bytes()
 // FORM bit 2 (with bit 1): the wave's second request and second store go out half way through the tile's arithmetic instead of
 // right behind the first ones — the chip's requests then come in two waves per tile period instead of one burst;
 // SLP: `s_sleep SLP` (64 cycles each) before every request (pacing experiment).
-template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0>
+// TSEG: one-KiB segments per tile (8 or 16: twice the steps per barrier pair, for the shapes where the serial skeleton shows).
+template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0, int TSEG = kSweepT>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes,
@@ -99,13 +100,14 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
     using Out = typename P::Out;
     static_assert(P::HAS_IN && P::IN_DIV == 1 && sizeof(In) == 4, "sweep kernel: one 4-byte input per lane and frame");
     static_assert(LPT >= 1 && (LPT & (LPT - 1)) == 0, "LPT is a power of two");
-    constexpr int OW = sizeof(Out) / 4, B = BatchOf<P>::value, TS = kSweepT;
+    constexpr int OW = sizeof(Out) / 4, B = BatchOf<P>::value, TS = TSEG;
     constexpr int SB = LPT < TS ? LPT : TS;  // sub-blocks per tile
     constexpr int R = TS / SB;               // frames per tile
     constexpr int PH = LPT / SB;             // tiles per frame group (LPT = 16: 2)
     constexpr int RPW = TS / 4;              // segments per wave and tile
     constexpr bool PRE = (FORM & 1) != 0, ONEBAR = (FORM & 2) != 0, SPLIT = (FORM & 4) != 0;
     static_assert(!SPLIT || (ONEBAR && RPW == 2), "split requests: one-barrier schedule");
+    static_assert(TS == 8 || TS == 16, "tile of 8 or 16 segments");
     constexpr int kYoungS = OW + (NB - 2) * (RPW + RPW * OW);  // split schedule: request, stores, request, stores per iteration
     constexpr int kYoung = RPW * OW + (NB - 1) * (RPW + RPW * OW);
     constexpr int kYoung1 = RPW * OW + (NB - 2) * (RPW + RPW * OW);  // one-barrier schedule
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
         };
 
         // requests of the tile at position q (phase static in the steady state: PHS >= 0)
-        auto issue = [&](const Pos &q, auto phs, auto full, int j0 = 0, int j1 = RPW) {
+        auto issue = [&](const Pos &q, auto phs, auto full, int j0 = 0, int j1 = 64) {
             constexpr bool FULL = decltype(full)::value;
             constexpr int PHS = decltype(phs)::value;
 #pragma unroll
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
             }
         };
         // stores of the tile at position q (q.row counts words of y)
-        auto store = [&](const Pos &q, auto phs, auto full, int j0 = 0, int j1 = RPW) {
+        auto store = [&](const Pos &q, auto phs, auto full, int j0 = 0, int j1 = 64) {
             constexpr bool FULL = decltype(full)::value;
             constexpr int PHS = decltype(phs)::value;
             const uint32_t *o = tout + (q.i & 1) * TS * kFmBlock * OW;

@@ -1347,6 +1347,13 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_few(
     if (own) p.store(prm, st, slanes, size_t(t));
 }
 
+// a size from the environment (diagnostic switches: honoured only with IDSP_DIAG=1)
+inline size_t diag_size(const char *name, size_t dflt)
+{
+    const char *e = diag_env(name);
+    return e ? size_t(strtoull(e, nullptr, 10)) : dflt;
+}
+
 }  // namespace idsp
 #include "fm_sweep.h"  // the dense-sweep FrameMajor kernel (round 5): needs everything above, is needed by launch_stream below
 namespace idsp {
@@ -1357,11 +1364,6 @@ namespace idsp {
 // smallest launch (in waves) that takes the 256-thread LDS-DMA kernel (IDSP_DIAG=1 IDSP_LDS_MIN_WAVES overrides):
 // measured equal to the single-wave register kernel at 16384 lanes, 15-20 % ahead at 32768-49152,
 // slightly behind at 8192
-inline size_t diag_size(const char *name, size_t dflt)
-{
-    const char *e = diag_env(name);
-    return e ? size_t(strtoull(e, nullptr, 10)) : dflt;
-}
 inline size_t lds_min_waves()
 {
     static const size_t v = diag_size("IDSP_LDS_MIN_WAVES", 256);

@@ -133,7 +133,7 @@ def test_c5_every_output_of_the_one_launch_against_an_oracle_slab(gpu):
     sd = torch.zeros((2, lanes), dtype=torch.int32, device=DEV)
     assert gpu.stream("biquad_f32_df2t", cfg, 1, sd, xd, yd, lanes, frames, FM) == 0
     torch.cuda.synchronize()
-    assert gpu.fn["last_kernel"]().decode().startswith("stream_frame_major_lds")
+    assert gpu.fn["last_kernel"]().decode().startswith("stream_frame_major_sweep[16 blocks/workgroup]<")  # one dense sweep (fm_sweep.h)
     del xd
     wd = torch.from_numpy(np.ascontiguousarray(want.T)).to(DEV).view(torch.int32)  # [frames][slab]
     yv = yd.view(torch.int32).view(frames, reps, slab)

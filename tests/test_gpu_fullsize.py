@@ -358,7 +358,7 @@ def test_c2_shape_variants_on_default_dispatch(eng, op, words, dtype, clamp):
     st = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)
     assert eng.stream(op, cfg, 1, st, x, y, lanes, frames, FM) == 0
     torch.cuda.synchronize()
-    assert eng.fn["last_kernel"]().decode().startswith("stream_frame_major_lds<"), eng.fn["last_kernel"]()
+    assert eng.fn["last_kernel"]().decode().startswith("stream_frame_major_sweep[1 block/workgroup]<"), eng.fn["last_kernel"]()
     idx = _subset(lanes, 509)
     tidx = torch.from_numpy(idx).to(DEV)
     xs = np.ascontiguousarray(x[:, tidx].cpu().numpy())
@@ -376,10 +376,11 @@ def test_c2_shape_variants_on_default_dispatch(eng, op, words, dtype, clamp):
     assert torch.equal(x.view(torch.int32), y.view(torch.int32)) and torch.equal(st, st2)
 
 
-@pytest.mark.parametrize("lanes,want", [(131072, "stream_frame_major_lds<"), (262144, "stream_frame_major_lds<"), (327680, "stream_frame_major_lds<")])
+@pytest.mark.parametrize("lanes,want", [(131072, "stream_frame_major_sweep[2 blocks/workgroup]<"), (262144, "stream_frame_major_sweep[4 blocks/workgroup]<"),
+                                        (327680, "stream_frame_major_sweep[8 blocks/workgroup]<")])
 def test_large_lane_counts_on_default_dispatch(eng, lanes, want):
-    """Beyond 98304 lanes the LDS-DMA kernel runs on a persistent grid of <= 256 workgroups that walks the 256-lane blocks
-    in column panels (C5 shards at 8 / 4 GPUs: 2 / 4 rounds; 327680 lanes = 1280 blocks -> 5 rounds): i32 DF1 and f32
+    """Beyond 65536 lanes the dense-sweep kernel (fm_sweep.h, round 5) gives every workgroup 2 / 4 / 8 interleaved lane blocks
+    (C5 shards at 8 / 4 GPUs; 327680 lanes = 256 workgroups x 8 blocks of 160 lanes): i32 DF1 and f32
     DF2T against the oracle on a lane subset, ragged frame count, chunked == whole."""
     frames = 1003
     o = H.oracle()

@@ -97,7 +97,7 @@ sys.path.insert(0, %r)
 from tests import _harness as H
 from tests._backends import GpuBackend
 gb = GpuBackend()
-lanes, frames = 65536, 16  # from 49152 lanes up FrameMajor takes the LDS-DMA kernel (below: the staged single-wave kernel)
+lanes, frames = 65536, 16  # from 49152 lanes up FrameMajor takes the dense-sweep LDS-DMA kernel (below: the staged single-wave kernel)
 x = np.zeros(lanes * frames, np.int32); st = np.zeros((4, lanes), np.uint32)
 rc, _ = gb.stream("biquad_i32_df1", H.biquad_i32([([1 << 28, 0, 0, 0, 0], 30)]), 1, st, x, lanes, frames, H.FM)
 assert rc == 0
@@ -106,7 +106,7 @@ print(H.engine().fn["last_kernel"]().decode())
     env = {k: v for k, v in os.environ.items() if k != "IDSP_DIAG"}
     env.update(IDSP_NO_LDS_PATH="1", IDSP_LDS_COST="0")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("stream_frame_major_lds<"), r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("stream_frame_major_sweep[1 block/workgroup]<"), r.stdout + r.stderr
     env["IDSP_DIAG"] = "1"
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("stream_frame_major<"), r.stdout + r.stderr

@@ -145,7 +145,7 @@ def test_frame_major_lane_block_in_place_on_the_lds_kernel(gpu):
     ptr = C.c_void_p(xd.data_ptr() + off * 4)
     assert gpu.fn["biquad_i32_df1_pitch"](C.cast(cfg, C.c_void_p), 1, p(sg), ptr, L, ptr, L, lanes, frames, FM, None) == 0
     torch.cuda.synchronize()
-    assert gpu.fn["last_kernel"]().decode().startswith("stream_frame_major_lds<")
+    assert gpu.fn["last_kernel"]().decode().startswith("stream_frame_major_sweep[1 block/workgroup]<")
     got = xd.cpu().numpy()
     assert np.array_equal(got[:, off:off + lanes], want) and np.array_equal(sg.cpu().numpy().view(np.uint32), so)
     assert np.array_equal(got[:, :off], xh[:, :off]) and np.array_equal(got[:, off + lanes:], xh[:, off + lanes:])

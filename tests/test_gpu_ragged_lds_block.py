@@ -46,7 +46,9 @@ def test_default_dispatch_takes_the_lds_kernel_on_ragged_lane_counts(gpu):
             k = kernel_of(gpu)
             # rows off the 64-byte grid (dense 65000 / 100000 lanes, a base 16 bytes into a row) take the XCD-contiguous block order
             aligned = (pitch * 4) % 64 == 0 and (off * 4) % 64 == 0
-            assert k.startswith("stream_frame_major_lds<" if aligned else "stream_frame_major_lds[XCD-contiguous blocks]<"), (op, lanes, pitch, off, k)
+            # (round 5: rows ON the 64-byte grid take the dense-sweep kernel from 16 frames up — tests/test_gpu_sweep.py)
+            want = ("stream_frame_major_sweep[" if frames >= 16 else "stream_frame_major_lds<") if aligned else "stream_frame_major_lds[XCD-contiguous blocks]<"
+            assert k.startswith(want), (op, lanes, pitch, off, k)
 
 
 def test_lane_counts_that_are_not_multiples_of_four_run_their_last_lanes_beside(gpu):

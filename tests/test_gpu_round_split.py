@@ -18,7 +18,11 @@ from tests._backends import GpuBackend, OracleBackend
 from tests.test_gpu_pitch import cases
 
 pytestmark = pytest.mark.gpu
-SPLIT = "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)"
+SPLIT = " + stream_frame_major_staged (remainder, second stream)<"  # after stream_frame_major_lds (rows off the 64-byte grid) or _sweep (on it)
+
+
+def is_split(k):
+    return k.startswith(("stream_frame_major_lds" + SPLIT, "stream_frame_major_sweep" + SPLIT))
 
 
 def kernel_of(eng):
@@ -35,11 +39,11 @@ def test_remainder_beside_the_whole_rounds(gpu):
             if (i + j) % 3:
                 continue
             FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, bool((i + j) & 1), off=off)
-            assert kernel_of(gpu).startswith(SPLIT), (op, lanes, kernel_of(gpu))
+            assert is_split(kernel_of(gpu)), (op, lanes, kernel_of(gpu))
     # a remainder above the limit, and a whole number of rounds, stay one launch
     op, cfg, n, words, dt = cs[0]
     FMS.run_case(gpu, op, cfg, n, words, dt, rng, 65536 + 24576, 16, 65536 + 24576, False)
-    assert kernel_of(gpu).startswith("stream_frame_major_lds<"), kernel_of(gpu)
+    assert kernel_of(gpu).startswith("stream_frame_major_sweep[2 blocks/workgroup]<"), kernel_of(gpu)
 
 
 def test_bylane_bank_moves_its_coefficient_planes_with_the_remainder(gpu):
@@ -53,7 +57,7 @@ def test_bylane_bank_moves_its_coefficient_planes_with_the_remainder(gpu):
         rc, yo = ob.bylane(op, coef, frac, 1, so, x, lanes, frames, H.FM)
         assert rc == 0
         rc, yg = gb.bylane(op, coef, frac, 1, sg, x, lanes, frames, H.FM)
-        assert rc == 0 and kernel_of(gpu).startswith(SPLIT), kernel_of(gpu)
+        assert rc == 0 and is_split(kernel_of(gpu)), kernel_of(gpu)
         assert np.array_equal(yo.view(np.uint32), yg.view(np.uint32)) and np.array_equal(so, sg), op
 
 
@@ -78,5 +82,5 @@ def test_call_stays_ordered_on_the_callers_stream(gpu):
             assert gpu.stream(op, cfg, 1, sd, xd, yd, lanes, frames, H.FM, C.c_void_p(s.cuda_stream)) == 0
         host.copy_(yd, non_blocking=True)
     s.synchronize()
-    assert kernel_of(gpu).startswith(SPLIT)
+    assert is_split(kernel_of(gpu))
     assert np.array_equal(host.numpy(), want) and np.array_equal(sd.cpu().numpy().view(np.uint32), so)

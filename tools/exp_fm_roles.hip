@@ -113,27 +113,27 @@ static void launch_lpt(const Ctx<P> &c, typename P::Out *y)
 }
 
 static SweepGeom g_geom;
-template <class P, int LPT, int NB, int FORM, int SLP = 0>
+template <class P, int LPT, int NB, int FORM, int SLP = 0, int TSEG = 8>
 static void launch_sweep_lpt(const Ctx<P> &c, typename P::Out *y)
 {
-    constexpr size_t bytes = (size_t(NB) * kSweepT * kFmBlock + 2 * size_t(kSweepT) * kFmBlock) * 4;
+    constexpr size_t bytes = (size_t(NB) * TSEG * kFmBlock + 2 * size_t(TSEG) * kFmBlock) * 4;
     static bool once = false;
     if (!once) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_sweep<P, LPT, NB, FORM, SLP>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_sweep<P, LPT, NB, FORM, SLP, TSEG>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
         once = true;
     }
-    hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, NB, FORM, SLP>), dim3(g_geom.grid), dim3(kFmBlock), bytes, 0, c.prm, c.st, c.x, y, c.lanes, c.frames, c.lanes, c.lanes,
+    hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, NB, FORM, SLP, TSEG>), dim3(g_geom.grid), dim3(kFmBlock), bytes, 0, c.prm, c.st, c.x, y, c.lanes, c.frames, c.lanes, c.lanes,
                        c.lanes, g_geom.bw, g_geom.rounds, g_geom.round_lanes);
 }
-template <class P, int NB, int FORM, int SLP = 0>
+template <class P, int NB, int FORM, int SLP = 0, int TSEG = 8>
 static void launch_sweep(const Ctx<P> &c, typename P::Out *y)
 {
     switch (g_geom.lpt) {
-        case 1: return launch_sweep_lpt<P, 1, NB, FORM, SLP>(c, y);
-        case 2: return launch_sweep_lpt<P, 2, NB, FORM, SLP>(c, y);
-        case 4: return launch_sweep_lpt<P, 4, NB, FORM, SLP>(c, y);
-        case 8: return launch_sweep_lpt<P, 8, NB, FORM, SLP>(c, y);
-        default: return launch_sweep_lpt<P, 16, NB, FORM, SLP>(c, y);
+        case 1: return launch_sweep_lpt<P, 1, NB, FORM, SLP, TSEG>(c, y);
+        case 2: return launch_sweep_lpt<P, 2, NB, FORM, SLP, TSEG>(c, y);
+        case 4: return launch_sweep_lpt<P, 4, NB, FORM, SLP, TSEG>(c, y);
+        case 8: return launch_sweep_lpt<P, 8, NB, FORM, SLP, TSEG>(c, y);
+        default: return launch_sweep_lpt<P, 16, NB, FORM, SLP, TSEG>(c, y);
     }
 }
 
@@ -154,6 +154,7 @@ template <class P>
 static int run(const char *name, size_t lanes, size_t frames)
 {
     using T = typename P::In;
+    using T_ = T;
     const size_t n = lanes * frames, pad = size_t(96) << 20;
     char *buf;
     CK(hipMalloc(&buf, 3 * n * 4 + 2 * pad));
@@ -239,8 +240,13 @@ static int run(const char *name, size_t lanes, size_t frames)
             if (getenv("EXP_BW")) g_geom.bw = unsigned(atoi(getenv("EXP_BW")));
             if (getenv("EXP_GRID")) g_geom.grid = unsigned(atoi(getenv("EXP_GRID")));
             char nm[96];
-#define SW(F, N, S) snprintf(nm, sizeof nm, "sweep f" #F " nb" #N " slp" #S " lpt%d bw%u", g_geom.lpt, g_geom.bw); sweep(nm, g_geom.grid, [&](T *y) { launch_sweep<P, N, F, S>(c, y); });
-            SW(0, 7, 0) SW(1, 7, 0) SW(2, 7, 0) SW(3, 7, 0)
+#define SW(F, N, S, T) snprintf(nm, sizeof nm, "sweep f" #F " nb" #N " slp" #S " ts" #T " lpt%d bw%u", g_geom.lpt, g_geom.bw); sweep(nm, g_geom.grid, [&](T_ *y) { launch_sweep<P, N, F, S, T>(c, y); });
+            if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "inplace")) {
+                SW(0, 5, 0, 8) SW(0, 6, 0, 8) SW(0, 7, 0, 8) SW(0, 8, 0, 8) SW(0, 9, 0, 8) SW(0, 7, 2, 8) SW(0, 7, 4, 8) SW(0, 6, 2, 8) SW(0, 8, 2, 8)
+                SW(3, 6, 0, 8) SW(3, 7, 0, 8) SW(3, 7, 2, 8) SW(3, 7, 4, 8) SW(3, 6, 4, 8) SW(3, 8, 4, 8) SW(2, 7, 2, 8) SW(2, 6, 2, 8) SW(2, 8, 2, 8)
+            } else {
+                SW(0, 7, 0, 8) SW(1, 7, 0, 8) SW(0, 4, 0, 16) SW(1, 4, 0, 16) SW(1, 3, 0, 16) SW(3, 4, 0, 16) SW(1, 5, 0, 16)
+            }
 #undef SW
         }
     }
