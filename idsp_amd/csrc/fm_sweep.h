@@ -39,11 +39,23 @@ namespace idsp {
 
 constexpr int kSweepNB = 7;    // ring depth in 8 KiB tiles
 constexpr int kSweepT = 8;     // segments per tile
-// schedules of the shipped instantiations (FORM bits, see the kernel; tools/exp_fm_roles.hip measures all of them): full 256-lane blocks are
-// bound by memory and run best on the plain two-barrier schedule (C5 0.75 flat over nine placements of y, against 0.69-0.73 for the others);
-// narrower blocks (lane counts that are no multiple of 65536 / LPT) leave the memory system slack, the serial skeleton shows, and the form that
-// reads the whole tile into registers first is 15-25 % faster there (73728 lanes 0.61 against 0.49 of the HBM peak)
-constexpr int kSweepFormFull = 0, kSweepFormNarrow = 1;
+// Schedules of the shipped instantiations (FORM bits and SLP: see the kernel; tools/exp_fm_roles.hip measures all of them,
+// profiles/r05_exp_fm_sweep_*.jsonl).  FULL 256-lane blocks are bound by memory, and at that ceiling what matters is how a wave's two requests
+// and two stores per tile are spread over the tile period: all 1024 waves of the launch are in step, and without pacing they all
+// issue right behind the barrier, then nothing for a thousand cycles.  A short `s_sleep` before each request (the cheap processors
+// have the slack) makes the rate the same for every placement of y and for y == x (65536 lanes: 0.78 flat, against 0.69-0.77 by
+// placement and 0.72 in place without it); which schedule carries it best differs with the sub-blocks per workgroup — measured per
+// LPT on i32 DF1 and f32 DF2T.  Heavier processors (COST > 60) and LPT >= 8 run the plain two-barrier schedule unpaced (C5: 0.75
+// flat).  NARROW blocks (lane counts that are no multiple of 65536 LPT) leave the memory system slack, the serial skeleton shows, and
+// the form that reads the whole tile into registers first, with one barrier per tile, is 15-40 % faster there (100000 lanes 0.70-0.72
+// against 0.66, 147456 0.67 against 0.48, 49152 0.73 against 0.67; the two-barrier form with registers first wins only at half-empty
+// blocks right above a multiple of 65536 lanes, which launch_stream splits off instead).
+template <int LPT, bool CHEAP>
+struct SweepFullForm {
+    static constexpr int form = !CHEAP ? 0 : LPT == 1 ? 3 : LPT == 2 ? 2 : LPT == 4 ? 3 : 0;
+    static constexpr int slp = !CHEAP ? 0 : LPT == 1 ? 4 : LPT == 2 ? 2 : LPT == 4 ? 4 : 0;
+};
+constexpr int kSweepFormNarrow = 3;
 
 struct SweepGeom {
     int lpt = 1;             // sub-blocks per workgroup
@@ -94,7 +106,7 @@ template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0, int TS
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes,
-    const unsigned bw, const unsigned rounds, const size_t round_lanes)
+    const unsigned bw, const unsigned rounds, const size_t round_lanes, const unsigned xcdc)
 {
     using In = typename P::In;
     using Out = typename P::Out;
@@ -121,7 +133,17 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
     const int tid = threadIdx.x, lid = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem;
-    const size_t G = gridDim.x, w = blockIdx.x;
+    // xcdc (rows off the 64-byte grid — dense rows of a lane count that is no multiple of 16, odd pitches, a base pointer off the
+    // grid): neighbouring blocks then share the 64-byte pieces at their boundaries, and with consecutive blocks dealt to the 8 XCDs
+    // in turn both halves of every shared piece go through two different L2s (round 3: 0.58-0.64 against 0.77).  Workgroup
+    // blockIdx runs on XCD blockIdx % 8: give XCD j the j-th contiguous eighth of the block positions, so that neighbours meet in
+    // one L2.  (The rows are still swept densely: the eight eighths advance together.)
+    const size_t G = gridDim.x;
+    size_t w = blockIdx.x;
+    if (xcdc) {
+        const size_t q = G / 8, r = G % 8, j = blockIdx.x % 8;
+        w = j * q + (j < r ? j : r) + blockIdx.x / 8;
+    }
 
     P p[LPT];
     if constexpr (P::LDS_WORDS > 0) {
@@ -414,26 +436,32 @@ constexpr size_t kSweepMinLanes = 49152;
 
 template <class P, int LPT>
 int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename P::In *x, typename P::Out *y, size_t lanes, size_t frames, size_t xl,
-                     size_t yl, size_t sp, const SweepGeom &g, hipStream_t s)
+                     size_t yl, size_t sp, const SweepGeom &g, hipStream_t s, unsigned xcdc)
 {
     constexpr size_t bytes = sweep_lds_bytes<P>();
+    using FF = SweepFullForm<LPT, (P::COST <= 60)>;
     if (g.bw == unsigned(kFmBlock)) {
-        if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormFull>>(bytes)) return rc;
-        hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormFull>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
-                           g.bw, g.rounds, g.round_lanes);
+        if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, FF::form, FF::slp>>(bytes)) return rc;
+        hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, FF::form, FF::slp>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
+                           g.bw, g.rounds, g.round_lanes, xcdc);
     } else {
         if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>>(bytes)) return rc;
         hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
-                           g.bw, g.rounds, g.round_lanes);
+                           g.bw, g.rounds, g.round_lanes, xcdc);
     }
     return launch_status();
 }
 
-// The launch for `lanes` lanes (a multiple of 4; rows on the 64-byte grid: launch_stream checks).  Returns IDSP_OK or an error.
+// The launch for `lanes` lanes (a multiple of 4: whole 16-byte pieces; rows need dword alignment only — `global_load_lds_dwordx4` and the
+// 16-byte stores take it, round 3 — and off the 64-byte grid the blocks go to the XCDs in contiguous eighths).  Returns IDSP_OK or an error.
 template <class P>
 int launch_sweep(const typename P::Params &prm, uint32_t *st, const typename P::In *x, typename P::Out *y, size_t lanes, size_t frames, size_t xl, size_t yl,
                  size_t sp, hipStream_t s)
 {
+    const bool on_grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * sizeof(typename P::In)) % 64 == 0 &&
+                           (yl * sizeof(typename P::Out)) % 64 == 0;
+    static const bool no_xcdc = diag_env("IDSP_SWEEP_NO_XCDC") != nullptr;
+    const unsigned xcdc = !on_grid64 && !no_xcdc ? 1u : 0u;
     constexpr int kMax = SweepMaxLptOf<P>::value;
     SweepGeom g;
     // (IDSP_DIAG=1 IDSP_SWEEP_MAX_GRID=n: at most n workgroups — small tensors then reach every LPT and several sweeps per launch: tests)
@@ -444,20 +472,23 @@ int launch_sweep(const typename P::Params &prm, uint32_t *st, const typename P::
                                         "stream_frame_major_sweep[16 blocks/workgroup]"};
     int k = 0;
     while ((1 << k) < g.lpt) k++;
-    note_kernel(names[k], typeid(P).name());
+    static const char *const names_x[] = {"stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]", "stream_frame_major_sweep[2 blocks/workgroup, XCD-contiguous]",
+                                          "stream_frame_major_sweep[4 blocks/workgroup, XCD-contiguous]", "stream_frame_major_sweep[8 blocks/workgroup, XCD-contiguous]",
+                                          "stream_frame_major_sweep[16 blocks/workgroup, XCD-contiguous]"};
+    note_kernel(xcdc && g.grid >= 8 ? names_x[k] : names[k], typeid(P).name());
     if constexpr (kMax >= 16) {
-        if (g.lpt == 16) return launch_sweep_lpt<P, 16>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+        if (g.lpt == 16) return launch_sweep_lpt<P, 16>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s, xcdc && g.grid >= 8);
     }
     if constexpr (kMax >= 8) {
-        if (g.lpt == 8) return launch_sweep_lpt<P, 8>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+        if (g.lpt == 8) return launch_sweep_lpt<P, 8>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s, xcdc && g.grid >= 8);
     }
     if constexpr (kMax >= 4) {
-        if (g.lpt == 4) return launch_sweep_lpt<P, 4>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+        if (g.lpt == 4) return launch_sweep_lpt<P, 4>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s, xcdc && g.grid >= 8);
     }
     if constexpr (kMax >= 2) {
-        if (g.lpt == 2) return launch_sweep_lpt<P, 2>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+        if (g.lpt == 2) return launch_sweep_lpt<P, 2>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s, xcdc && g.grid >= 8);
     }
-    return launch_sweep_lpt<P, 1>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s);
+    return launch_sweep_lpt<P, 1>(prm, st, x, y, lanes, frames, xl, yl, sp, g, s, xcdc && g.grid >= 8);
 }
 
 }  // namespace idsp

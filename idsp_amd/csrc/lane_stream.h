@@ -1502,14 +1502,17 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
         }
         if constexpr (FmStagedOf<P>::value && P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4 && P::COST <= 120) {
             const size_t head = lanes / (size_t(256) * kFmBlock) * (size_t(256) * kFmBlock), tail = lanes - head;
-            if (head && tail && tail <= kSplitTailMax && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() && rows_ok &&
+            // (round 5: only when the whole rounds are 1, 2, 4, 8 or 16 times 65536 lanes — FULL 256-lane blocks on the sweep kernel; three
+            // or five rounds would be narrow blocks themselves, and the call is one sweep over all its lanes instead)
+            const size_t head_rounds = head / (size_t(256) * kFmBlock);
+            if (head && tail && tail <= kSplitTailMax && (head_rounds & (head_rounds - 1)) == 0 && head_rounds <= 16 && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() && rows_ok &&
                 xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
                 if (SideStream *ss = side_stream(s)) {
                     IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
                     IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
                     int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, sp);
                     // (rows on the 64-byte grid: the whole rounds went to the dense-sweep kernel, fm_sweep.h)
-                    const bool head_swept = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * 4) % 64 == 0 && (yl * 4) % 64 == 0;
+                    const bool head_swept = true;
                     if (rc == IDSP_OK)
                         rc = launch_stream<P>(shift_lanes(prm, head, sizeof(typename P::In)), st + head, x + head, y + head, tail, frames, layout, ss->stream,
                                               Pitch{xl, yl}, sp);
@@ -1530,14 +1533,16 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             // grid or a ragged last block.  (Lane counts a little above a multiple of 65536 were split above: their whole rounds come back
             // here as full 256-lane blocks, the remainder runs beside them — 65552 lanes: 0.77 of the HBM peak against 0.54 as one sweep of
             // half-empty blocks.)  (IDSP_DIAG=1 IDSP_NO_SWEEP=1: the round-4
-            // dispatch below.)  Rows off the 64-byte grid keep the XCD-contiguous LDS-DMA kernel.
+            // dispatch below.)  Rows off the 64-byte grid (dword alignment is all the requests and stores need): the same sweep with the
+            // blocks dealt to the XCDs in contiguous eighths.
             static const bool no_sweep = diag_env("IDSP_NO_SWEEP") != nullptr;
             static const size_t sweep_min = diag_size("IDSP_SWEEP_MIN_LANES", kSweepMinLanes);
             static const bool cost_forced_ = diag_env("IDSP_LDS_COST") != nullptr, no_lds_ = diag_env("IDSP_NO_LDS_PATH") != nullptr;
+            static const bool grid64_only = diag_env("IDSP_SWEEP_GRID64_ONLY") != nullptr;  // IDSP_DIAG=1: rows off the 64-byte grid stay on round 3's kernel
             const bool on_grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * sizeof(typename P::In)) % 64 == 0 &&
                                    (yl * sizeof(typename P::Out)) % 64 == 0;
             if constexpr (LdsEligibleOf<P>::value) {
-                if (!no_sweep && !cost_forced_ && !no_lds_ && on_grid64 && lanes % 4 == 0 && lanes >= sweep_min && frames >= 16)
+                if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || (!grid64_only && rows_ok)) && lanes % 4 == 0 && lanes >= sweep_min && frames >= 16)
                     return launch_sweep<P>(prm, st, x, y, lanes, frames, xl, yl, sp, s);
             }
         }

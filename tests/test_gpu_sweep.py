@@ -41,14 +41,15 @@ def test_default_dispatch_full_size_lane_counts(gpu):
     shapes = [(65536, 19, 65536, 0, 1), (49152, 21, 49152, 0, 1), (100000, 33, 100000 + 16, 0, 2), (131072, 17, 131072, 0, 2), (200000, 18, 200000, 0, 4),
               (262144, 9, 262144 + 64, 32, 4), (300016, 20, 300016, 0, 8), (1048576, 10, 1048576, 0, 16), (1000000, 17, 1000000, 0, 16),
               (90000, 41, 131072, 16, 2)]
+    big = {"biquad_i32_df1", "biquad_f32_df2t_clamp", "biquad_i32_df1_clamp"}  # the big shapes: a cheap i32, a cheap f32 and the 2-section chain
     for i, (lanes, frames, pitch, off, blocks) in enumerate(shapes):
         for j, (op, cfg, n, words, dt) in enumerate(cs):
-            if (i + j) % 4 and lanes > 70000:
-                continue  # the big shapes on a quarter of the entries
+            if lanes > 70000 and (op not in big or (lanes > 300000 and (i + j) % 2)):
+                continue
             FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, bool((i + j) & 1), off=off)
             k = kernel_of(gpu)
             assert k.startswith("stream_frame_major_sweep["), (op, lanes, k)
-            if n == 1 and op in ("biquad_i32_df1", "biquad_f32_df2t", "biquad_f32_df1"):
+            if n == 1 and op in ("biquad_i32_df1", "biquad_f32_df2t_clamp", "biquad_f32_df1"):
                 assert k.startswith(f"stream_frame_major_sweep[{blocks} block"), (op, lanes, k)
 
 
@@ -59,7 +60,7 @@ def test_lane_counts_a_little_above_whole_rounds_split(gpu):
         pytest.skip("forced small-shape run")
     rng = np.random.default_rng(502)
     op, cfg, n, words, dt = sweep_cases(rng)[0]
-    for lanes in (65552, 131072 + 4096):
+    for lanes in (65552, 131072 + 4096):  # (3 x 65536 + 3392 = 200000 lanes above: no split, the three rounds would be narrow blocks)
         FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, 37, lanes, False)
         assert kernel_of(gpu).startswith("stream_frame_major_sweep + stream_frame_major_staged (remainder, second stream)"), kernel_of(gpu)
 

@@ -123,7 +123,7 @@ static void launch_sweep_lpt(const Ctx<P> &c, typename P::Out *y)
         once = true;
     }
     hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, NB, FORM, SLP, TSEG>), dim3(g_geom.grid), dim3(kFmBlock), bytes, 0, c.prm, c.st, c.x, y, c.lanes, c.frames, c.lanes, c.lanes,
-                       c.lanes, g_geom.bw, g_geom.rounds, g_geom.round_lanes);
+                       c.lanes, g_geom.bw, g_geom.rounds, g_geom.round_lanes, getenv("EXP_XCDC") ? 1u : 0u);
 }
 template <class P, int NB, int FORM, int SLP = 0, int TSEG = 8>
 static void launch_sweep(const Ctx<P> &c, typename P::Out *y)
@@ -241,6 +241,9 @@ static int run(const char *name, size_t lanes, size_t frames)
             if (getenv("EXP_GRID")) g_geom.grid = unsigned(atoi(getenv("EXP_GRID")));
             char nm[96];
 #define SW(F, N, S, T) snprintf(nm, sizeof nm, "sweep f" #F " nb" #N " slp" #S " ts" #T " lpt%d bw%u", g_geom.lpt, g_geom.bw); sweep(nm, g_geom.grid, [&](T_ *y) { launch_sweep<P, N, F, S, T>(c, y); });
+            if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "ship")) {
+                SW(0, 7, 0, 8) SW(1, 7, 0, 8) SW(3, 7, 4, 8) SW(2, 7, 2, 8)
+            } else
             if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "inplace")) {
                 SW(0, 5, 0, 8) SW(0, 6, 0, 8) SW(0, 7, 0, 8) SW(0, 8, 0, 8) SW(0, 9, 0, 8) SW(0, 7, 2, 8) SW(0, 7, 4, 8) SW(0, 6, 2, 8) SW(0, 8, 2, 8)
                 SW(3, 6, 0, 8) SW(3, 7, 0, 8) SW(3, 7, 2, 8) SW(3, 7, 4, 8) SW(3, 6, 4, 8) SW(3, 8, 4, 8) SW(2, 7, 2, 8) SW(2, 6, 2, 8) SW(2, 8, 2, 8)
