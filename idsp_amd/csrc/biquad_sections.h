@@ -93,6 +93,52 @@ struct Df1I32 {
         s[2] = uint32_t(y0);
         return y0;
     }
+    // A whole tile of samples at once (round 5): SB independent lanes (states st[0 .. SB)), R consecutive samples of each, x and y in the
+    // order g = r SB + lane.  step() is ONE chain of five dependent v_mad_i64_i32 per sample, and an in-order wave that has nothing else
+    // to issue pays the ~10-cycle latency of each (86 cycles per sample measured where the arithmetic is 25).  The wrapping i64 sum of
+    // biquad.rs:366-383 is associative and commutative mod 2^64, so the same bits come out of any order: here the three feed-forward
+    // products of ALL samples go first, term by term across the tile (independent chains, back to back), and only a1 y1 — with a2 y2
+    // issued beside it — and the shift stay on the per-sample chain.
+    static constexpr bool HAS_TILE = true;
+    template <int SB, int R, class StateOf>
+    static __device__ __forceinline__ void tile(const SecI32 &c, StateOf &&state_of, const int32_t (&x)[SB * R], int32_t (&y)[SB * R])
+    {
+        int64_t acc[SB * R];
+#pragma unroll
+        for (int g = 0; g < SB * R; g++) acc[g] = mulw(c.ba[0], x[g]);
+#pragma unroll
+        for (int g = 0; g < SB * R; g++) acc[g] = wadd(acc[g], mulw(c.ba[1], g >= SB ? x[g - SB] : int32_t(state_of(g % SB)[0])));
+#pragma unroll
+        for (int g = 0; g < SB * R; g++)
+            acc[g] = wadd(acc[g], mulw(c.ba[2], g >= 2 * SB ? x[g - 2 * SB] : int32_t(state_of(g % SB)[g >= SB ? 0 : 1])));
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int l = 0; l < SB; l++) {
+                const int g = r * SB + l;
+                acc[g] = wadd(acc[g], mulw(c.ba[4], r >= 2 ? y[g - 2 * SB] : int32_t(state_of(l)[r == 1 ? 2 : 3])));
+            }
+#pragma unroll
+            for (int l = 0; l < SB; l++) {
+                const int g = r * SB + l;
+                acc[g] = wadd(acc[g], mulw(c.ba[3], r >= 1 ? y[g - SB] : int32_t(state_of(l)[2])));
+            }
+#pragma unroll
+            for (int l = 0; l < SB; l++) {
+                const int g = r * SB + l;
+                int32_t y0 = shr_lo(acc[g], c.frac);
+                if (CLAMP) y0 = clampi(int32_t(uint32_t(y0) + uint32_t(c.u)), c.mn, c.mx);
+                y[g] = y0;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < SB; l++) {
+            uint32_t(&s)[W] = state_of(l);
+            const uint32_t nx1 = R >= 2 ? uint32_t(x[(R - 2) * SB + l]) : s[0], ny1 = R >= 2 ? uint32_t(y[(R - 2) * SB + l]) : s[2];
+            s[1] = nx1, s[0] = uint32_t(x[(R - 1) * SB + l]);
+            s[3] = ny1, s[2] = uint32_t(y[(R - 1) * SB + l]);
+        }
+    }
 };
 
 // src/iir/biquad.rs:511-538 (first-order error feedback)
@@ -377,6 +423,11 @@ struct SecLdsMaxN<Sec, std::void_t<decltype(Sec::LDS_MAX_N)>> {
 };
 
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
+template <class Sec, class = void>
+struct SecHasTile : std::false_type {};
+template <class Sec>
+struct SecHasTile<Sec, std::void_t<decltype(Sec::HAS_TILE)>> : std::integral_constant<bool, Sec::HAS_TILE> {};
+
 template <class Sec, int N>
 struct Chain {
     using In = typename Sec::T;
@@ -410,6 +461,18 @@ struct Chain {
 #pragma unroll
         for (int k = 0; k < N; k++) x = Sec::step(p.sec[k], s[k], x);
         return x;
+    }
+    // tile form of a single section that has one (Sec::tile; lane_stream.h: HasTileOf): `p` points at SB chains of independent lanes
+    static constexpr bool HAS_TILE = N == 1 && SecHasTile<Sec>::value;
+    template <int SB, int R>
+    static __device__ __forceinline__ void tile(const Params &prm, Chain *p, const In (&x)[SB * R], Out (&y)[SB * R])
+    {
+        if constexpr (HAS_TILE) {
+            Sec::template tile<SB, R>(prm.sec[0], [&](int l) -> uint32_t(&)[Sec::W] { return p[l].s[0]; }, x, y);
+        } else {
+#pragma unroll
+            for (int g = 0; g < SB * R; g++) y[g] = p[g % SB].step(prm, x[g]);
+        }
     }
 };
 

@@ -314,6 +314,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
                     }
                     if (r0 + B == TS / 2 || (B > TS / 2 && r0 == 0)) mid();
                 }
+            } else if constexpr (FULL && B == 1 && HasTileOf<P>::value && !SPLIT) {
+                tile_of<P, SB, R>(prm, &p[ph * SB], v, r);  // the tile's feed-forward terms ahead of the per-sample chains
             } else {
                 static_for<TS>([&](auto gg) {
                     constexpr int g = decltype(gg)::value;  // static: the LPT states stay in registers
@@ -440,11 +442,11 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
 {
     constexpr size_t bytes = sweep_lds_bytes<P>();
     using FF = SweepFullForm<LPT, (P::COST <= 60)>;
-    if (g.bw == unsigned(kFmBlock)) {
+    if (g.bw == unsigned(kFmBlock) && !xcdc) {
         if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, FF::form, FF::slp>>(bytes)) return rc;
         hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, FF::form, FF::slp>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
                            g.bw, g.rounds, g.round_lanes, xcdc);
-    } else {
+    } else {  // narrow blocks, and rows off the 64-byte grid (pacing costs 20 % there: tools/exp_fm_roles.hip with EXP_XCDC=1)
         if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>>(bytes)) return rc;
         hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
                            g.bw, g.rounds, g.round_lanes, xcdc);

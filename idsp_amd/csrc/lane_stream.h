@@ -77,6 +77,13 @@ struct HasPreBatch : std::false_type {};
 template <class P>
 struct HasPreBatch<P, std::void_t<decltype(&P::pre_batch)>> : std::true_type {};
 
+// Processors with a tile form — P::tile<SB, R>(prm, P *lanes, x, y): SB independent lanes x R consecutive samples in one call, the
+// state-independent part of all samples issued ahead of the per-sample chains (biquad_sections.h, Df1I32::tile) — declare HAS_TILE.
+template <class P, class = void>
+struct HasTileOf : std::false_type {};
+template <class P>
+struct HasTileOf<P, std::void_t<decltype(P::HAS_TILE)>> : std::integral_constant<bool, P::HAS_TILE> {};
+
 template <class P, int B>
 __device__ __forceinline__ void pre_all(P &p, const typename P::Params &prm, typename P::Pre (&pre)[B])
 {
@@ -96,6 +103,18 @@ __device__ __forceinline__ typename P::Out step1(P &p, const typename P::Params 
         return p.step(prm, v, p.pre(prm));
     else
         return p.step(prm, v);
+}
+
+// (a function of its own: inside the kernels' generic lambdas a discarded `if constexpr` branch is still checked against P)
+template <class P, int SB, int R>
+__device__ __forceinline__ void tile_of(const typename P::Params &prm, P *lanes, const typename P::In (&x)[SB * R], typename P::Out (&y)[SB * R])
+{
+    if constexpr (HasTileOf<P>::value) {
+        P::template tile<SB, R>(prm, lanes, x, y);
+    } else {
+#pragma unroll
+        for (int g = 0; g < SB * R; g++) y[g] = step1(lanes[g % SB], prm, x[g]);
+    }
 }
 
 // words <-> sample helpers (1- or 2-word element types)
@@ -931,8 +950,20 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
                     for (int c = 0; c < CI; c++) nxt[c] = in_piece((g + 1) * CI + c);
                 }
                 u32x4 out[CO];
+                if constexpr (HasTileOf<P>::value && IW == 1 && OW == 1 && B == 1) {
+                    In xin[NS];
+                    Out yo[NS];
 #pragma unroll
-                for (int q = 0; q < NS / 4; q++) quad(cur + q * IW, out + q * OW);
+                    for (int q = 0; q < NS; q++) xin[q] = __builtin_bit_cast(In, uint32_t(cur[q / 4][q % 4]));
+                    tile_of<P, 1, NS>(prm, &p, xin, yo);
+#pragma unroll
+                    for (int q = 0; q < NS / 4; q++)
+                        out[q] = u32x4{__builtin_bit_cast(uint32_t, yo[4 * q]), __builtin_bit_cast(uint32_t, yo[4 * q + 1]), __builtin_bit_cast(uint32_t, yo[4 * q + 2]),
+                                       __builtin_bit_cast(uint32_t, yo[4 * q + 3])};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NS / 4; q++) quad(cur + q * IW, out + q * OW);
+                }
 #pragma unroll
                 for (int c = 0; c < CO; c++) out_piece(g * CO + c, out[c]);
                 asm volatile("" ::: "memory");
@@ -1127,8 +1158,18 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
 #pragma unroll
                     for (int c = 0; c < NS; c++) nxt[c] = col[((g + 1) * NS + c) * LW];
                 }
+                if constexpr (HasTileOf<P>::value && W == 1) {
+                    In xin[NS];
+                    Out yo[NS];
 #pragma unroll
-                for (int c = 0; c < NS; c++) col[(g * NS + c) * LW] = one(cur[c]);
+                    for (int c = 0; c < NS; c++) xin[c] = __builtin_bit_cast(In, cur[c]);
+                    tile_of<P, 1, NS>(prm, &p, xin, yo);
+#pragma unroll
+                    for (int c = 0; c < NS; c++) col[(g * NS + c) * LW] = __builtin_bit_cast(Word, yo[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NS; c++) col[(g * NS + c) * LW] = one(cur[c]);
+                }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int c = 0; c < NS; c++) cur[c] = nxt[c];
@@ -1512,7 +1553,8 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
                     int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, sp);
                     // (rows on the 64-byte grid: the whole rounds went to the dense-sweep kernel, fm_sweep.h)
-                    const bool head_swept = true;
+                    const bool head_swept = (reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * 4) % 64 == 0 && (yl * 4) % 64 == 0) ||
+                                            head > kLdsGridCap * size_t(kFmBlock);
                     if (rc == IDSP_OK)
                         rc = launch_stream<P>(shift_lanes(prm, head, sizeof(typename P::In)), st + head, x + head, y + head, tail, frames, layout, ss->stream,
                                               Pitch{xl, yl}, sp);
@@ -1542,7 +1584,10 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             const bool on_grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * sizeof(typename P::In)) % 64 == 0 &&
                                    (yl * sizeof(typename P::Out)) % 64 == 0;
             if constexpr (LdsEligibleOf<P>::value) {
-                if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || (!grid64_only && rows_ok)) && lanes % 4 == 0 && lanes >= sweep_min && frames >= 16)
+                // rows off the grid: from the lane count up where round 3's XCD-contiguous kernel would walk panels on a persistent grid (131076 dense
+                // lanes 0.56 -> 0.61, 100004 0.58 -> 0.65); below it that kernel is a single round itself and stays (65000 dense lanes 0.745)
+                const bool off_grid_ok = !grid64_only && rows_ok && lanes > kLdsGridCap * size_t(kFmBlock);
+                if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || off_grid_ok) && lanes % 4 == 0 && lanes >= sweep_min && frames >= 16)
                     return launch_sweep<P>(prm, st, x, y, lanes, frames, xl, yl, sp, s);
             }
         }

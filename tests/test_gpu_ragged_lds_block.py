@@ -46,9 +46,9 @@ def test_default_dispatch_takes_the_lds_kernel_on_ragged_lane_counts(gpu):
             k = kernel_of(gpu)
             # rows off the 64-byte grid (dense 65000 / 100000 lanes, a base 16 bytes into a row) take the XCD-contiguous block order
             aligned = (pitch * 4) % 64 == 0 and (off * 4) % 64 == 0
-            # (round 5: from 16 frames up the dense-sweep kernel takes these shapes — tests/test_gpu_sweep.py — with the same XCD-contiguous
-            # block order on rows off the grid; shorter calls stay on the LDS-DMA kernel)
-            want = "stream_frame_major_sweep[" if frames >= 16 else "stream_frame_major_lds<" if aligned else "stream_frame_major_lds[XCD-contiguous blocks]<"
+            # (round 5: rows ON the grid take the dense-sweep kernel from 16 frames up — tests/test_gpu_sweep.py; off it, these lane counts
+            # (<= 98304: one round of workgroups) keep this kernel, larger ones go to the sweep kernel with the same XCD-contiguous order)
+            want = "stream_frame_major_lds[XCD-contiguous blocks]<" if not aligned else "stream_frame_major_sweep[" if frames >= 16 else "stream_frame_major_lds<"
             assert k.startswith(want), (op, lanes, pitch, off, k)
             assert ("XCD-contiguous" in k.split("<")[0]) == (not aligned), (op, lanes, pitch, off, k)
 
@@ -62,7 +62,7 @@ def test_lane_counts_that_are_not_multiples_of_four_run_their_last_lanes_beside(
     for lanes in (65537, 65001):
         FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, 21, lanes, False)
         k = kernel_of(gpu)
-        assert k.startswith("stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<") and k.endswith("(lanes % 4, second stream)"), k
+        assert k.startswith("stream_frame_major_lds[XCD-contiguous blocks]<") and k.endswith("(lanes % 4, second stream)"), k
 
 
 def test_small_ragged_shapes_inner(gpu):

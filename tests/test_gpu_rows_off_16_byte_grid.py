@@ -20,14 +20,14 @@ def test_lane_counts_that_are_not_multiples_of_four(gpu):
     rng = np.random.default_rng(311)
     cs = lds_cases(rng)
     # (lanes, frames, pitch, lane offset, kernel of the lanes - lanes % 4 body)
-    # (round 5: from 49152 lanes and 16 frames up the body runs on the dense-sweep kernel, its blocks dealt to the XCDs in contiguous eighths
-    # on rows off the 64-byte grid — fm_sweep.h)
-    shapes = [(65537, 40, 65537, 0, "stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<"),
-              (65539, 17, 65543, 3, "stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<"),
-              (65001, 21, 65001, 0, "stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<"),
+    # (round 5: beyond 98304 lanes — where this kernel would walk panels on a persistent grid — the body runs on the dense-sweep kernel, its
+    # blocks dealt to the XCDs in contiguous eighths on rows off the 64-byte grid: fm_sweep.h)
+    shapes = [(65537, 40, 65537, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65539, 17, 65543, 3, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65001, 21, 65001, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (8195, 50, 8195, 0, "stream_frame_major_staged[32 lanes/wave]<"),
               (32770, 64, 32771, 1, "stream_frame_major_staged[64 lanes/wave]<"),
-              (73731, 24, 73731, 0, "stream_frame_major_sweep + stream_frame_major_staged (remainder, second stream)<"),
+              (73731, 24, 73731, 0, "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)<"),
               (131073, 16, 131073, 0, "stream_frame_major_sweep[2 blocks/workgroup, XCD-contiguous]<")]
     for i, (lanes, frames, pitch, off, body) in enumerate(shapes):
         for j, (op, cfg, n, words, dt) in enumerate(cs):
@@ -42,13 +42,13 @@ def test_whole_pieces_on_rows_off_the_grid(gpu):
     """lane counts that are multiples of four with odd pitches / odd base offsets: no second stream, 16-byte kernels"""
     rng = np.random.default_rng(312)
     cs = lds_cases(rng)
-    shapes = [(65536, 33, 65537, 0, "stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<"),
-              (65536, 20, 65544, 1, "stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<"),
-              (65000, 19, 65003, 2, "stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<"),
+    shapes = [(65536, 33, 65537, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65536, 20, 65544, 1, "stream_frame_major_lds[XCD-contiguous blocks]<"),
+              (65000, 19, 65003, 2, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (16384, 130, 16387, 0, "stream_frame_major_staged[32 lanes/wave]<"),  # round 4: plain accesses on such rows, 64 from 25600 lanes
               (28672, 40, 28675, 1, "stream_frame_major_staged[64 lanes/wave]<"),
               (4096, 257, 4099, 3, "stream_frame_major_staged[16 lanes/wave]<"),
-              (69632, 18, 69633, 0, "stream_frame_major_sweep + stream_frame_major_staged (remainder, second stream)<")]
+              (69632, 18, 69633, 0, "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)<")]
     for i, (lanes, frames, pitch, off, want) in enumerate(shapes):
         for j, (op, cfg, n, words, dt) in enumerate(cs):
             if (i + j) % 3:

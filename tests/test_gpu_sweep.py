@@ -39,7 +39,7 @@ def test_default_dispatch_full_size_lane_counts(gpu):
     cs = sweep_cases(rng)
     # (lanes, frames, pitch, lane offset, blocks per workgroup expected for the cheap single sections)
     shapes = [(65536, 19, 65536, 0, 1), (49152, 21, 49152, 0, 1), (100000, 33, 100000 + 16, 0, 2), (131072, 17, 131072, 0, 2), (200000, 18, 200000, 0, 4),
-              (262144, 9, 262144 + 64, 32, 4), (300016, 20, 300016, 0, 8), (1048576, 10, 1048576, 0, 16), (1000000, 17, 1000000, 0, 16),
+              (262144, 19, 262144 + 64, 32, 4), (300016, 20, 300016, 0, 8), (1048576, 18, 1048576, 0, 16), (1000000, 17, 1000000, 0, 16),
               (90000, 41, 131072, 16, 2)]
     big = {"biquad_i32_df1", "biquad_f32_df2t_clamp", "biquad_i32_df1_clamp"}  # the big shapes: a cheap i32, a cheap f32 and the 2-section chain
     for i, (lanes, frames, pitch, off, blocks) in enumerate(shapes):
