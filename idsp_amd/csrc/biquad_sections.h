@@ -316,6 +316,7 @@ struct Df2tF64 {
 // `Normal<C>` x `DirectForm1<T>` (src/iir/normal.rs:37-58); ba = [b0, b1, b2, p.re, p.im], state words
 // {x0, x1, y0, y1}: y1' = (b0 x0 + b1 x1 + b2 x2 + re y1 + (-im) y0).as_(), y0' = (im y1 + re y0).as_().
 struct NormalI32 {
+    static constexpr int SWEEP_LPT = 4;
     using T = int32_t;
     static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = true;
@@ -342,6 +343,7 @@ struct NormalI32 {
     }
 };
 struct NormalF32 {
+    static constexpr int SWEEP_LPT = 4;
     using T = float;
     static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = true;
@@ -423,6 +425,16 @@ struct SecLdsMaxN<Sec, std::void_t<decltype(Sec::LDS_MAX_N)>> {
 };
 
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
+// largest number of sub-blocks per workgroup a single section is instantiated with on the sweep kernel: 16 (2^20 lanes in one sweep) for the
+// biquad sections proper, Sec::SWEEP_LPT for the others (Normal: 4)
+template <class Sec, class = void>
+struct SecSweepLpt {
+    static constexpr int value = 16;
+};
+template <class Sec>
+struct SecSweepLpt<Sec, std::void_t<decltype(Sec::SWEEP_LPT)>> {
+    static constexpr int value = Sec::SWEEP_LPT;
+};
 template <class Sec, class = void>
 struct SecHasTile : std::false_type {};
 template <class Sec>
@@ -439,6 +451,7 @@ struct Chain {
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 4;  // N >= 2: tools/tune_lds.hip (worst placement 0.75-0.77 against 0.68 at 8 tiles for N = 2)
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     static constexpr bool LDS_ELIGIBLE = N <= SecLdsMaxN<Sec>::value;
+    static constexpr int SWEEP_MAX_LPT = N == 1 ? SecSweepLpt<Sec>::value : N == 2 ? 4 : 2;  // sub-blocks per workgroup on the sweep kernel (fm_sweep.h)
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
 
@@ -492,6 +505,7 @@ struct CascadeDf1 {
     // LDS-DMA kernel against register window at the C2 shape: i32 x3 0.78 vs 0.59, x4 0.69 vs 0.65, x8 0.42 vs 0.50;
     // f32 x2 0.76 vs 0.70, x4 0.59 vs 0.62
     static constexpr bool LDS_ELIGIBLE = std::is_same<T, int32_t>::value ? N <= 4 : (std::is_same<T, float>::value && N <= 2);
+    static constexpr int SWEEP_MAX_LPT = N == 1 ? 4 : 2;
     using SecT = typename std::conditional<std::is_same<T, float>::value, SecF32,
                                            typename std::conditional<kFloat, SecF64, SecI32>::type>::type;
     using Params = ChainParams<SecT, N>;
@@ -592,6 +606,8 @@ struct ChainByLane {
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     static constexpr bool LDS_ELIGIBLE = N <= SecLdsMaxN<Sec>::value;
     static constexpr int CV = Sec::kClamp ? 8 : 5;
+    // sub-blocks per workgroup on the sweep kernel (fm_sweep.h): every lane carries its own coefficients in registers beside its state
+    static constexpr int SWEEP_MAX_LPT = N == 1 ? 4 : 2;
     using Params = ByLaneParams;
     uint32_t s[N][Sec::W];
     typename Sec::Sec c[N];

@@ -700,7 +700,7 @@ int idsp_fm_disc_i32(const idsp_fm_disc *cfg, void *state, const int32_t *x, int
         static const size_t sk_forced = diag_size("IDSP_FMD_SKEW", ~size_t(0));
         static const unsigned sk_shift = unsigned(diag_size("IDSP_FMD_SKEW_SHIFT", 4)) & 31u, sk_mod = unsigned(diag_size("IDSP_FMD_SKEW_MOD", 4));  // shift 0..31
         const unsigned grid = unsigned((lanes + kWave - 1) / kWave);
-        const unsigned sk_ticks = sk_forced != ~size_t(0) ? unsigned(sk_forced) : grid >= 512 && frames >= 2048 && frames <= 8192 && stagger_tuned_device() ? 1200u : 0u;
+        const unsigned sk_ticks = sk_forced != ~size_t(0) ? unsigned(sk_forced) : grid >= thr::kStaggerMinWorkgroups && frames >= thr::kStaggerMinFrames && frames <= thr::kStaggerMaxFrames && stagger_tuned_device() ? thr::kFmDiscStaggerTicks : 0u;
         hipLaunchKernelGGL(fm_disc_waves_lm_kernel, dim3(grid), dim3(kWave * 5), 0, as_stream(stream), p,
                            static_cast<uint32_t *>(state), reinterpret_cast<const cplx_bits *>(x), y, lanes, body, frames, sk_ticks, sk_shift, sk_mod ? sk_mod : 1u);
         if (int rc = launch_status()) return rc;

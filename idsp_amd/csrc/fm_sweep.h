@@ -43,25 +43,25 @@ constexpr int kSweepT = 8;     // segments per tile
 // profiles/r05_exp_fm_sweep_*.jsonl).  FULL 256-lane blocks are bound by memory, and at that ceiling what matters is how a wave's two requests
 // and two stores per tile are spread over the tile period: all 1024 waves of the launch are in step, and without pacing they all
 // issue right behind the barrier, then nothing for a thousand cycles.  A short `s_sleep` before each request (the cheap processors
-// have the slack) makes the rate the same for every placement of y and for y == x (65536 lanes: 0.78 flat, against 0.69-0.77 by
-// placement and 0.72 in place without it); which schedule carries it best differs with the sub-blocks per workgroup — measured per
-// LPT on i32 DF1 and f32 DF2T.  Heavier processors (COST > 60) and LPT >= 8 run the plain two-barrier schedule unpaced (C5: 0.75
-// flat).  NARROW blocks (lane counts that are no multiple of 65536 LPT) leave the memory system slack, the serial skeleton shows, and
-// the form that reads the whole tile into registers first, with one barrier per tile, is 15-40 % faster there (100000 lanes 0.70-0.72
-// against 0.66, 147456 0.67 against 0.48, 49152 0.73 against 0.67; the two-barrier form with registers first wins only at half-empty
-// blocks right above a multiple of 65536 lanes, which launch_stream splits off instead).
-template <int LPT, bool CHEAP>
-struct SweepFullForm {
-    static constexpr int form = !CHEAP ? 0 : LPT == 1 ? 3 : LPT == 2 ? 2 : LPT == 4 ? 3 : 0;
-    static constexpr int slp = !CHEAP ? 0 : LPT == 1 ? 4 : LPT == 2 ? 2 : LPT == 4 ? 4 : 0;
-};
-constexpr int kSweepFormNarrow = 3;
+// have the slack) makes the rate the same for every placement of y and for y == x.  NARROW blocks (lane counts that are no multiple of
+// 65536 LPT) leave the memory system slack, the serial skeleton shows, and the form that reads the whole tile into registers first, with
+// one barrier per tile, is 15-40 % faster there than the read-step-write forms (100000 lanes 0.70-0.72 against 0.66, 147456 0.67 against
+// 0.48, 49152 0.73 against 0.67).
+// One schedule for everything — registers first, one barrier per tile (FORM 3) — and for the cheap processors' full blocks `s_sleep 4` before each
+// request (SLP 4, a compile-time constant: the same sleep behind a run-time switch measured 0.754 where this runs 0.800 — these kernels sit on a
+// timing edge).  Over five boxes: 65536 lanes 0.78-0.80, flat over the placement of y and in place, where the unpaced forms range 0.71-0.79 by box
+// and 0.60-0.79 by placement; 2^20 lanes 0.735-0.74 flat (two-barrier unpaced: 0.72-0.75).  CHEAP = COST <= 50: i32 DF1 (with its tile form) and the
+// f32 sections; the dither / wide / multi-section bodies have no slack to sleep in.
+constexpr int kSweepForm = 3, kSweepPace = 4;
+template <class P>
+constexpr bool sweep_cheap() { return P::COST <= 50; }
 
 struct SweepGeom {
     int lpt = 1;             // sub-blocks per workgroup
     unsigned grid = 0;       // workgroups
     unsigned bw = 256;       // lanes per sub-block (multiple of 16, <= 256)
     unsigned rounds = 1;     // sweeps inside the launch
+    unsigned fps = 1;        // frames per one-KiB segment (LPT = 1 and bw <= 128: launch_sweep sets it for 4-byte outputs)
     size_t round_lanes = 0;  // lanes per sweep (the last one may hold fewer)
 };
 
@@ -102,11 +102,13 @@ constexpr size_t sweep_lds_bytes(int nb = kSweepNB, int ts = kSweepT)
 // right behind the first ones — the chip's requests then come in two waves per tile period instead of one burst;
 // SLP: `s_sleep SLP` (64 cycles each) before every request (pacing experiment).
 // TSEG: one-KiB segments per tile (8 or 16: twice the steps per barrier pair, for the shapes where the serial skeleton shows).
-template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0, int TSEG = kSweepT>
+// FPSM: several frames per segment (`fps_` of them; LPT = 1 and 4-byte outputs only).  A template flag, not just the run-time count: with the slot
+// loop in it the one-frame-per-segment kernel lost 5-30 % at 65536 lanes (0.34 -> 0.36-0.49 ms by schedule).
+template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0, int TSEG = kSweepT, bool FPSM = false>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes,
-    const unsigned bw, const unsigned rounds, const size_t round_lanes, const unsigned xcdc)
+    const unsigned bw, const unsigned rounds, const size_t round_lanes, const unsigned xcdc, const unsigned fps_)
 {
     using In = typename P::In;
     using Out = typename P::Out;
@@ -159,10 +161,23 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
         int slot, ph;
         size_t fr, row;
     };
+    // fps (LPT = 1, 4-byte outputs, few lanes): SEVERAL frames share a one-KiB segment — slot k of a segment holds the block's `bw` lanes of
+    // frame (first frame of the tile) + k TS + (segment index), fps = 256 / bw slots — so that a tile is 8 KiB of real samples however few
+    // lanes a workgroup owns (16384 lanes: 64 per workgroup, 32 frames per tile) instead of 8 KiB of which three quarters are masked.
+    // Each thread's piece of a segment then lies in slot (4 lid) / bw at lane (4 lid) % bw: a per-thread address offset, constant for
+    // the launch; threads 0 .. bw - 1 run the tile's 8 fps steps of their lane, slot after slot.
+    static_assert(!FPSM || (LPT == 1 && OW == 1), "several frames per segment: one block per workgroup, 4-byte outputs");
+    const unsigned fps = FPSM && fps_ > 1 ? fps_ : 1u;
+    const unsigned fpt = unsigned(R) * fps;  // frames per tile (frame group)
+    const unsigned tslot = fps > 1 ? unsigned(lid * 4) / bw : 0u, tlane = fps > 1 ? unsigned(lid * 4) % bw : unsigned(lid * 4);
+    const bool tgeo = tslot < fps;
+    const uint32_t xvoff = uint32_t((size_t(tslot) * TS * xl + tlane) * sizeof(In));  // launcher: fits 32 bits
+    const size_t yword = fps > 1 ? size_t(tslot) * TS * yl + tlane : size_t(lid * 4);  // words (OW = 1 when fps > 1)
+    const bool comp_on = fps == 1 || unsigned(tid) < bw;
     auto next_pos = [&](Pos &q, size_t pitch) {
         q.i++;
         q.slot = q.slot + 1 == NB ? 0 : q.slot + 1;
-        if (PH == 1 || ++q.ph == PH) q.ph = 0, q.fr += R, q.row += size_t(R) * pitch;
+        if (PH == 1 || ++q.ph == PH) q.ph = 0, q.fr += fpt, q.row += size_t(fpt) * pitch;
     };
     const size_t ypitch = yl * OW;  // words between the frames of y
 
@@ -190,9 +205,9 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
         // the state loads must have landed HERE, where the compiler's wait-count pass sees it (see stream_frame_major_lds)
         __builtin_amdgcn_s_waitcnt(0x0F70);
 
-        const size_t ngroups = (frames + R - 1) / R;  // frame groups of R frames
+        const size_t ngroups = (frames + fpt - 1) / fpt;  // frame groups of R fps frames
         const size_t ntiles = ngroups * PH;
-        const size_t nfull = (frames / R) * PH;        // tiles [0, nfull) hold R whole frames
+        const size_t nfull = (frames / fpt) * PH;        // tiles [0, nfull) hold whole frame groups
         const In *xr = x + rl0;
         uint32_t *yr = reinterpret_cast<uint32_t *>(y) + rl0 * OW;
 
@@ -235,7 +250,15 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
                     base = xr + q.row + (PHS >= 0 ? sxo[j][PHS >= 0 ? PHS : 0] : pick(sxo[j], q.ph));
                 else  // ragged tile: re-request the last frame (static request count)
                     base = xr + (frames - 1) * xl + (PHS >= 0 ? sfst[j][PHS >= 0 ? PHS : 0] : pick(sfst[j], q.ph));
-                if (unsigned(lid * 4) < cnt) glds16_s(base, uint32_t(lid) * 16u, lds_base + uint32_t((q.slot * TS + wave + 4 * j) * kFmBlock * 4));
+                bool on = tgeo && tlane < cnt;
+                uint32_t voff = xvoff;
+                if constexpr (!FULL) {
+                    if (q.fr + sfo[j] >= frames)
+                        on = on && tslot == 0, voff = tlane * uint32_t(sizeof(In));  // the re-requested last frame: slot 0 only
+                    else
+                        on = on && q.fr + size_t(tslot) * TS + sfo[j] < frames;       // this thread's slot lies beyond the last frame
+                }
+                if (on) glds16_s(base, voff, lds_base + uint32_t((q.slot * TS + wave + 4 * j) * kFmBlock * 4));
             }
         };
         // stores of the tile at position q (q.row counts words of y)
@@ -249,30 +272,33 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
                 const int g = wave + 4 * j;
                 const bool row_ok = FULL || q.fr + sfo[j] < frames;
                 const unsigned nv = PHS >= 0 ? scnt[j][PHS >= 0 ? PHS : 0] : pick(scnt[j], q.ph);
-                int gsrc = g;  // segment of the output tile this wave-instruction reads
+                int gsrc = g, lds0 = 0;  // segment (and first word inside it) of the output tile this wave-instruction reads
                 uint32_t *base;
                 if (row_ok) {
                     base = yr + q.row + (PHS >= 0 ? syo[j][PHS >= 0 ? PHS : 0] : pick(syo[j], q.ph));
-                } else {  // a row beyond the data: the tile's last real row instead
-                    gsrc = int(frames - 1 - q.fr) * SB + g % SB;
+                } else {  // a row beyond the data: the tile's last real row instead (fps > 1: frame k of the tile sits in slot k / TS of segment k % TS)
+                    const size_t lastf = frames - 1 - q.fr;
+                    gsrc = fps > 1 ? int(lastf % TS) : int(lastf) * SB + g % SB;
+                    lds0 = fps > 1 ? int(lastf / TS) * int(bw) : 0;
                     base = yr + ((frames - 1) * yl + (PHS >= 0 ? sfst[j][PHS >= 0 ? PHS : 0] : pick(sfst[j], q.ph))) * OW;
                 }
 #pragma unroll
                 for (int h = 0; h < OW; h++) {
                     // piece (h, lid) holds lanes (h 256 + lid 4) / OW ... of the sub-block
-                    const unsigned first = unsigned(h * kFmBlock + lid * 4) / OW;
-                    bool on = first < nv && row_ok;
-                    int word = h * kFmBlock + lid * 4;
+                    const unsigned first = fps > 1 ? tlane : unsigned(h * kFmBlock + lid * 4) / OW;
+                    bool on = tgeo && first < nv && row_ok && (FULL || q.fr + size_t(tslot) * TS + sfo[j] < frames);
+                    int word = h * kFmBlock + lid * 4;   // in the LDS tile
+                    size_t gword = fps > 1 ? yword : size_t(word);  // in memory, from `base`
                     if (!row_ok || unsigned(h * kFmBlock) / OW >= nv) {
                         // no piece of this wave-instruction exists (a row beyond the data, or OW = 2 and nv <= 128): thread 0 stores the first
                         // piece of the sub-block's last real row once more (same bytes as its owner stores), so that the instruction is
                         // issued and the hand-counted vmcnt stays exact
                         on = lid == 0;
-                        word = 0;
+                        word = 0, gword = 0;
                     }
                     if (on) {
-                        const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + gsrc * OW * kFmBlock + word);
-                        __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(base + word));
+                        const u32x4 v4 = *reinterpret_cast<const u32x4 *>(o + gsrc * OW * kFmBlock + (row_ok ? 0 : lds0) + word);
+                        __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(base + gword));
                     }
                 }
             }
@@ -282,15 +308,22 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
             constexpr int ph = decltype(phase)::value;
             const uint32_t *in = tin + q.slot * TS * kFmBlock;
             uint32_t *o = tout + (q.i & 1) * TS * kFmBlock * OW;
-            const int nr = FULL || frames - q.fr >= size_t(R) ? R : int(frames - q.fr);  // rows of this tile that exist
+            if (!comp_on) return;  // (several frames per segment) threads beyond the block's lanes own no column
+            const size_t left = frames - q.fr;  // frames from this tile's first one on
+            // (requesting the NEXT slot's samples before this slot's arithmetic was measured slower: 32768 lanes 0.195 -> 0.23 ms)
+            for (unsigned jj = 0; jj < (FPSM ? fps : 1u); jj++) {
+            const unsigned joff = jj * bw * (fps > 1);  // this slot's lanes inside a segment
+            const size_t f0 = size_t(jj) * R;
+            const int nr = FULL || left >= f0 + size_t(R) ? R : left > f0 ? int(left - f0) : 0;  // rows of this slot that exist
             if constexpr (!PRE) {
                 static_for<TS>([&](auto gg) {
                     constexpr int g = decltype(gg)::value;
                     constexpr int s = ph * SB + g % SB;
-                    if (g == TS / 2) mid();
-                    if (FULL || g / SB < nr) to_words<Out>(step1(p[s], prm, __builtin_bit_cast(In, in[g * kFmBlock + tid])), o + (g * kFmBlock + tid) * OW);
+                    if (g == TS / 2 && jj == 0) mid();
+                    if (FULL || g / SB < nr)
+                        to_words<Out>(step1(p[s], prm, __builtin_bit_cast(In, in[g * kFmBlock + joff + tid])), o + (g * kFmBlock + joff + tid) * OW);
                 });
-                return;
+                continue;
             }
             // PRE: the tile's samples of this thread go to registers FIRST, all TS of them, and the results leave after the last step: input
             // ring and output tile are one LDS array to the compiler, so a `read, step, write` loop keeps every read behind the previous
@@ -298,7 +331,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
             In v[TS];
             Out r[TS];
 #pragma unroll
-            for (int g = 0; g < TS; g++) v[g] = __builtin_bit_cast(In, in[g * kFmBlock + tid]);
+            for (int g = 0; g < TS; g++) v[g] = __builtin_bit_cast(In, in[g * kFmBlock + joff + tid]);
             if constexpr (B > 1 && LPT == 1) {  // segments are consecutive frames of one lane
 #pragma unroll
                 for (int r0 = 0; r0 < TS; r0 += B) {
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
                         const int k = r0 + b;
                         if (FULL || k < nr) r[k] = p[0].step(prm, v[k], pre[b]);
                     }
-                    if (r0 + B == TS / 2 || (B > TS / 2 && r0 == 0)) mid();
+                    if ((r0 + B == TS / 2 || (B > TS / 2 && r0 == 0)) && jj == 0) mid();
                 }
             } else if constexpr (FULL && B == 1 && HasTileOf<P>::value && !SPLIT) {
                 tile_of<P, SB, R>(prm, &p[ph * SB], v, r);  // the tile's feed-forward terms ahead of the per-sample chains
@@ -320,13 +353,14 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
                 static_for<TS>([&](auto gg) {
                     constexpr int g = decltype(gg)::value;  // static: the LPT states stay in registers
                     constexpr int s = ph * SB + g % SB;
-                    if (g == TS / 2) mid();
+                    if (g == TS / 2 && jj == 0) mid();
                     if (FULL || g / SB < nr) r[g] = step1(p[s], prm, v[g]);
                 });
             }
 #pragma unroll
             for (int g = 0; g < TS; g++)
-                if (FULL || g / SB < nr) to_words<Out>(r[g], o + (g * kFmBlock + tid) * OW);
+                if (FULL || g / SB < nr) to_words<Out>(r[g], o + (g * kFmBlock + joff + tid) * OW);
+            }
         };
         auto compute_dyn = [&](const Pos &q, auto full) {  // tile phase known at run time only (start-up and drain)
             static_for<PH>([&](auto pp) {
@@ -422,35 +456,49 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
 }
 
 // ------------------------------------------------------------------------------------------------------------ host
-// Largest LPT a processor is instantiated with (each doubling doubles its state registers and the unrolled loop body): the
-// cheap single sections take every lane count up to 2^20 in ONE sweep; heavier bodies are bound by the VALU long before that
-// and run larger lane counts as several sweeps over lane ranges.  P::SWEEP_MAX_LPT overrides.
+// Largest LPT a processor is instantiated with (each doubling doubles its state registers, the unrolled loop body and the build time): the
+// single biquad sections (P::SWEEP_MAX_LPT = 16) take every lane count up to 2^20 in ONE sweep; everything else runs more than 262144 lanes
+// (heavy bodies: 131072) as several sweeps over lane ranges — quarter rows of a 2^20-lane tensor, still dense pieces of 1 MiB.
 template <class P, class = void>
 struct SweepMaxLptOf {
-    static constexpr int value = P::COST <= 60 ? 16 : P::COST <= 120 ? 4 : 2;
+    static constexpr int value = P::COST <= 120 ? 4 : 2;  // (single biquad sections declare 16: biquad_sections.h)
 };
 template <class P>
 struct SweepMaxLptOf<P, std::void_t<decltype(P::SWEEP_MAX_LPT)>> {
     static constexpr int value = P::SWEEP_MAX_LPT;
 };
-// smallest lane count the sweep kernel takes (below, the staged single-wave kernel's 36 ns per frame beat its barriers)
-constexpr size_t kSweepMinLanes = 49152;
+// smallest lane count the sweep kernel takes: 49152, or 24576 for 4-byte outputs, where several frames share a segment (`fps`: 32768 lanes 0.69 of
+// the HBM peak against 0.56 on the staged single-wave kernel, 24576 0.52 against 0.50; at 16384 lanes the staged kernel's 36 ns per frame win, 0.46
+// against 0.42 — one computing wave per CU issues a `v_mad_i64_i32` every 10 cycles whatever the schedule)
+constexpr size_t kSweepMinLanes = thr::kSweepMinLanes, kSweepMinLanesFps = thr::kSweepMinLanesFps;
 
 template <class P, int LPT>
 int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename P::In *x, typename P::Out *y, size_t lanes, size_t frames, size_t xl,
                      size_t yl, size_t sp, const SweepGeom &g, hipStream_t s, unsigned xcdc)
 {
     constexpr size_t bytes = sweep_lds_bytes<P>();
-    using FF = SweepFullForm<LPT, (P::COST <= 60)>;
-    if (g.bw == unsigned(kFmBlock) && !xcdc) {
-        if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, FF::form, FF::slp>>(bytes)) return rc;
-        hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, FF::form, FF::slp>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
-                           g.bw, g.rounds, g.round_lanes, xcdc);
-    } else {  // narrow blocks, and rows off the 64-byte grid (pacing costs 20 % there: tools/exp_fm_roles.hip with EXP_XCDC=1)
-        if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>>(bytes)) return rc;
-        hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepFormNarrow>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
-                           g.bw, g.rounds, g.round_lanes, xcdc);
+    const bool full = g.bw == unsigned(kFmBlock) && !xcdc && g.fps <= 1;  // full blocks on the 64-byte grid: bound by memory
+    if constexpr (sweep_cheap<P>()) {
+        if (full) {
+            if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm, kSweepPace>>(bytes)) return rc;
+            hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm, kSweepPace>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl,
+                               yl, sp, g.bw, g.rounds, g.round_lanes, xcdc, g.fps);
+            return launch_status();
+        }
     }
+    if (g.fps > 1) {
+        if constexpr (LPT == 1 && sizeof(typename P::Out) == 4) {
+            if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, 1, kSweepNB, kSweepForm, 0, kSweepT, true>>(bytes)) return rc;
+            hipLaunchKernelGGL((stream_frame_major_sweep<P, 1, kSweepNB, kSweepForm, 0, kSweepT, true>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames,
+                               xl, yl, sp, g.bw, g.rounds, g.round_lanes, xcdc, g.fps);
+            return launch_status();
+        } else {
+            return fail(IDSP_EINVAL, "internal: several frames per segment with %d blocks per workgroup", LPT);
+        }
+    }
+    if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm>>(bytes)) return rc;
+    hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp, g.bw,
+                       g.rounds, g.round_lanes, xcdc, g.fps);
     return launch_status();
 }
 
@@ -469,6 +517,14 @@ int launch_sweep(const typename P::Params &prm, uint32_t *st, const typename P::
     // (IDSP_DIAG=1 IDSP_SWEEP_MAX_GRID=n: at most n workgroups — small tensors then reach every LPT and several sweeps per launch: tests)
     static const unsigned max_grid = unsigned(diag_size("IDSP_SWEEP_MAX_GRID", 256));
     if (!sweep_geometry(lanes, kMax, g, max_grid ? max_grid : 256u)) return fail(IDSP_EINVAL, "internal: no sweep geometry for %zu lanes", lanes);
+    // few lanes per workgroup (below 32768 + lanes in all): several frames per one-KiB segment, so that a tile stays 8 KiB of real samples
+    // (IDSP_DIAG=1 IDSP_SWEEP_NO_FPS=1: one frame per segment)
+    static const bool no_fps = diag_env("IDSP_SWEEP_NO_FPS") != nullptr;
+    if (g.lpt == 1 && sizeof(typename P::Out) == 4 && g.bw <= 128 && !no_fps) {
+        unsigned f = 256u / g.bw;
+        while (f > 1 && (size_t(f - 1) * kSweepT * (xl > yl ? xl : yl) + 256) * 4 >= (size_t(1) << 32)) f--;  // per-thread byte offsets are 32-bit
+        g.fps = f;
+    }
     static const char *const names[] = {"stream_frame_major_sweep[1 block/workgroup]", "stream_frame_major_sweep[2 blocks/workgroup]",
                                         "stream_frame_major_sweep[4 blocks/workgroup]", "stream_frame_major_sweep[8 blocks/workgroup]",
                                         "stream_frame_major_sweep[16 blocks/workgroup]"};

@@ -46,6 +46,7 @@
 #include <typeinfo>
 
 #include "common.h"
+#include "dispatch_thresholds.h"
 #include "lds_dma.h"
 
 namespace idsp {
@@ -305,7 +306,7 @@ constexpr int kLdsT = 8;    // frames per tile
 // placement, 7 or fewer a flat 0.41-0.46 ms), so only DF1 i32, dither and f32 DF2T without clamp take 7.
 constexpr int kLdsNB = 8;
 // Largest non-persistent grid of the LDS-DMA kernel; launches with more workgroups walk their lane blocks persistently.
-constexpr size_t kLdsGridCap = 384;
+constexpr size_t kLdsGridCap = thr::kLdsGridCap;
 // LDS-DMA path or register-window kernel (launch_stream): P::LDS_ELIGIBLE if the processor declares it, else COST <= 120.
 template <class P, class = void>
 struct LdsEligibleOf {
@@ -1407,7 +1408,7 @@ namespace idsp {
 // slightly behind at 8192
 inline size_t lds_min_waves()
 {
-    static const size_t v = diag_size("IDSP_LDS_MIN_WAVES", 256);
+    static const size_t v = diag_size("IDSP_LDS_MIN_WAVES", thr::kLdsMinWaves);
     return v;
 }
 
@@ -1439,7 +1440,7 @@ inline Params shift_lanes(Params p, size_t first, size_t elem)
 
 // Largest remainder (in lanes) that launch_stream runs beside the whole rounds on a second stream (tools/exp_split_streams.py:
 // 73728 lanes 0.58 -> 0.69 of the HBM peak with an 8192-lane remainder, 81920 0.59 -> 0.63 with 16384, no gain from 24576 up)
-constexpr size_t kSplitTailMax = 20480;
+constexpr size_t kSplitTailMax = thr::kSplitTailMax;
 
 template <class P>
 int launch_stream(const typename P::Params &prm, void *state, const typename P::In *x,
@@ -1469,7 +1470,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 // 8-section cascade (VALU-bound: half-empty waves cost arithmetic) 0.57 / 0.45 / 0.52 at 16384 and
                 // 0.61 / 0.91 / 1.56 at 65536
                 constexpr bool heavy = P::COST > 120;
-                const size_t lw = forced_lw ? forced_lw : lanes >= 49152 ? 64 : (lanes >= 24576 || heavy) ? 32 : 16;
+                const size_t lw = forced_lw ? forced_lw : lanes >= thr::kLmStaged64Lanes ? 64 : (lanes >= thr::kLmStaged32Lanes || heavy) ? 32 : 16;
                 auto go = [&](auto lw_tag) {
                     constexpr int LW = decltype(lw_tag)::value;
                     // the 32- and 16-lane forms move 1 KiB per lane and tile (the same 32 / 16 KiB slot and staging registers
@@ -1578,7 +1579,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             // dispatch below.)  Rows off the 64-byte grid (dword alignment is all the requests and stores need): the same sweep with the
             // blocks dealt to the XCDs in contiguous eighths.
             static const bool no_sweep = diag_env("IDSP_NO_SWEEP") != nullptr;
-            static const size_t sweep_min = diag_size("IDSP_SWEEP_MIN_LANES", kSweepMinLanes);
+            static const size_t sweep_min = diag_size("IDSP_SWEEP_MIN_LANES", sizeof(typename P::Out) == 4 ? kSweepMinLanesFps : kSweepMinLanes);
             static const bool cost_forced_ = diag_env("IDSP_LDS_COST") != nullptr, no_lds_ = diag_env("IDSP_NO_LDS_PATH") != nullptr;
             static const bool grid64_only = diag_env("IDSP_SWEEP_GRID64_ONLY") != nullptr;  // IDSP_DIAG=1: rows off the 64-byte grid stay on round 3's kernel
             const bool on_grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * sizeof(typename P::In)) % 64 == 0 &&
@@ -1587,7 +1588,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 // rows off the grid: from the lane count up where round 3's XCD-contiguous kernel would walk panels on a persistent grid (131076 dense
                 // lanes 0.56 -> 0.61, 100004 0.58 -> 0.65); below it that kernel is a single round itself and stays (65000 dense lanes 0.745)
                 const bool off_grid_ok = !grid64_only && rows_ok && lanes > kLdsGridCap * size_t(kFmBlock);
-                if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || off_grid_ok) && lanes % 4 == 0 && lanes >= sweep_min && frames >= 16)
+                if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || off_grid_ok) && lanes % 4 == 0 && lanes >= sweep_min && frames >= thr::kSweepMinFrames)
                     return launch_sweep<P>(prm, st, x, y, lanes, frames, xl, yl, sp, s);
             }
         }
@@ -1603,7 +1604,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             static const size_t forced_flw = diag_size("IDSP_FM_LANES_PER_WAVE", 0);
             constexpr size_t sz = sizeof(typename P::In);
             constexpr bool heavy = P::COST > 120;
-            const bool in_range = heavy ? (lanes >= 12288 && lanes < 40960) : lanes < 49152;
+            const bool in_range = heavy ? (lanes >= thr::kStagedHeavyMinLanes && lanes < thr::kStagedHeavyMaxLanes) : lanes < thr::kStagedMaxLanes;
             if (!no_fm_staged && (forced_flw || in_range) && frames >= 16 && (lanes * sz) % 16 == 0 && rows_ok &&
                 xl * sz < (size_t(1) << 28) && yl * sz < (size_t(1) << 28)) {  // 32-bit offsets: up to 15 row pitches + 1 KiB inside a tile (16 lanes/wave)
                 // rows off the 64-byte grid: a 32-lane wave's 128-byte row pieces each straddle two lines; whole 256-byte pieces from 12288
@@ -1612,7 +1613,7 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 const bool off64 = (xl * sz) % 64 != 0 || (yl * sz) % 64 != 0 || reinterpret_cast<uintptr_t>(x) % 64 != 0 || reinterpret_cast<uintptr_t>(y) % 64 != 0;
                 // (round 4, with plain accesses on such rows the 32-lane form wins again up to ~25000 lanes: 16385 lanes 0.217 -> 0.182 ms,
                 // 12292 0.202 -> 0.163, 20484 0.240 -> 0.200, 24580 0.249 -> 0.223; 26628 0.255 with 64 against 0.268 with 32)
-                const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= (off64 ? 25600 : 24576) ? 64 : lanes >= 8192 ? 32 : 16;
+                const size_t lw = forced_flw ? forced_flw : heavy ? 32 : lanes >= (off64 ? thr::kStaged64LanesOffGrid : thr::kStaged64Lanes) ? 64 : lanes >= thr::kStaged32Lanes ? 32 : 16;
                 auto go = [&](auto lw_tag) {
                     constexpr int LW = decltype(lw_tag)::value;
                     constexpr size_t bytes = size_t(kFmStagedTile) + size_t(P::LDS_WORDS) * 4;
@@ -1769,8 +1770,8 @@ int launch_duo(const typename PA::Params &pa, const typename PB::Params &pb, uin
 inline bool duo_wanted(size_t m, size_t lanes, int layout)
 {
     static const bool off = diag_env("IDSP_NO_DUO") != nullptr;
-    if (off || layout != IDSP_FRAME_MAJOR || lanes < 40960) return false;
-    return m >= 5 || (m == 4 && lanes <= 98304);
+    if (off || layout != IDSP_FRAME_MAJOR || lanes < thr::kDuoMinLanes) return false;
+    return m >= 5 || (m == 4 && lanes <= thr::kDuo4MaxLanes);
 }
 
 }  // namespace idsp

@@ -50,7 +50,7 @@ constexpr int kLwPieceGroup = 1;                 // the 16-byte-piece form
 // `skew` ticks (10 ns each; workgroup b runs on XCD b % 8) — buys more than it costs: 0.357 -> 0.328-0.335 ms at C4 for steps of
 // 5-13 us and moduli 3-8, including the 15-40 us the last group waits (shifts 0-2 and 6-8, i.e. phases per XCD or per
 // workgroup pair, gain nothing).  Which launches: launch_lockin_waves_in.
-constexpr unsigned kLwSkewTicks = 600;
+constexpr unsigned kLwSkewTicks = thr::kLockinStaggerTicks;
 #ifndef IDSP_LW_LM_LINES
 #define IDSP_LW_LM_LINES 1  // LaneMajor, 8-byte elements: whole 128-byte lines per store instruction
 #endif
@@ -850,7 +850,7 @@ int launch_lockin_waves_in(const typename Bank::Params &p, uint32_t *st, const i
     static const bool no_skew = diag_env("IDSP_LOCKIN_NO_SKEW") != nullptr;
     // (one workgroup per CU: 16384 x 4096 0.217 -> 0.225 ms with it; 32768 lanes x 2048 frames 0.187 -> 0.179, x 4096 0.350 -> 0.323,
     // x 16384 1.335 -> 1.358: long calls drift apart by themselves; 65536 x 4096 0.696 -> 0.640)
-    const unsigned skew = (IN == IN_LM_REG || IN == IN_LM_DMA) && !no_skew && grid.x >= 512 && frames >= 2048 && frames <= 8192 && stagger_tuned_device() ? kLwSkewTicks : 0u;
+    const unsigned skew = (IN == IN_LM_REG || IN == IN_LM_DMA) && !no_skew && grid.x >= thr::kStaggerMinWorkgroups && frames >= thr::kStaggerMinFrames && frames <= thr::kStaggerMaxFrames && stagger_tuned_device() ? kLwSkewTicks : 0u;
     note_kernel(waves == 6 ? "lockin_waves_kernel[6 waves per 64 lanes]" : "lockin_waves_kernel[4 waves per 64 lanes]", Bank::name());
     if constexpr (Bank::kSixWaves) {
         if (waves == 6) {

@@ -116,6 +116,19 @@ static SweepGeom g_geom;
 template <class P, int LPT, int NB, int FORM, int SLP = 0, int TSEG = 8>
 static void launch_sweep_lpt(const Ctx<P> &c, typename P::Out *y)
 {
+    if constexpr (LPT == 1) {
+        if (g_geom.fps > 1) {
+            constexpr size_t bytes = (size_t(NB) * TSEG * kFmBlock + 2 * size_t(TSEG) * kFmBlock) * 4;
+            static bool once1 = false;
+            if (!once1) {
+                CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_frame_major_sweep<P, 1, NB, FORM, SLP, TSEG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+                once1 = true;
+            }
+            hipLaunchKernelGGL((stream_frame_major_sweep<P, 1, NB, FORM, SLP, TSEG, true>), dim3(g_geom.grid), dim3(kFmBlock), bytes, 0, c.prm, c.st, c.x, y, c.lanes, c.frames,
+                               c.lanes, c.lanes, c.lanes, g_geom.bw, g_geom.rounds, g_geom.round_lanes, getenv("EXP_XCDC") ? 1u : 0u, g_geom.fps);
+            return;
+        }
+    }
     constexpr size_t bytes = (size_t(NB) * TSEG * kFmBlock + 2 * size_t(TSEG) * kFmBlock) * 4;
     static bool once = false;
     if (!once) {
@@ -123,7 +136,7 @@ static void launch_sweep_lpt(const Ctx<P> &c, typename P::Out *y)
         once = true;
     }
     hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, NB, FORM, SLP, TSEG>), dim3(g_geom.grid), dim3(kFmBlock), bytes, 0, c.prm, c.st, c.x, y, c.lanes, c.frames, c.lanes, c.lanes,
-                       c.lanes, g_geom.bw, g_geom.rounds, g_geom.round_lanes, getenv("EXP_XCDC") ? 1u : 0u);
+                       c.lanes, g_geom.bw, g_geom.rounds, g_geom.round_lanes, getenv("EXP_XCDC") ? 1u : 0u, g_geom.fps);
 }
 template <class P, int NB, int FORM, int SLP = 0, int TSEG = 8>
 static void launch_sweep(const Ctx<P> &c, typename P::Out *y)
@@ -239,10 +252,14 @@ static int run(const char *name, size_t lanes, size_t frames)
         if (sweep_geometry(lanes, max_lpt, g_geom, max_grid)) {
             if (getenv("EXP_BW")) g_geom.bw = unsigned(atoi(getenv("EXP_BW")));
             if (getenv("EXP_GRID")) g_geom.grid = unsigned(atoi(getenv("EXP_GRID")));
+            if (g_geom.lpt == 1 && g_geom.bw <= 128 && !getenv("EXP_NO_FPS")) g_geom.fps = 256u / g_geom.bw;
             char nm[96];
-#define SW(F, N, S, T) snprintf(nm, sizeof nm, "sweep f" #F " nb" #N " slp" #S " ts" #T " lpt%d bw%u", g_geom.lpt, g_geom.bw); sweep(nm, g_geom.grid, [&](T_ *y) { launch_sweep<P, N, F, S, T>(c, y); });
+#define SW(F, N, S, T) snprintf(nm, sizeof nm, "sweep f" #F " nb" #N " slp" #S " ts" #T " lpt%d bw%u fps%u", g_geom.lpt, g_geom.bw, g_geom.fps); sweep(nm, g_geom.grid, [&](T_ *y) { launch_sweep<P, N, F, S, T>(c, y); });
+            if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "small")) {
+                SW(0, 7, 0, 8) SW(1, 7, 0, 8) SW(3, 7, 0, 8) SW(2, 7, 0, 8)
+            } else
             if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "ship")) {
-                SW(0, 7, 0, 8) SW(1, 7, 0, 8) SW(3, 7, 4, 8) SW(2, 7, 2, 8)
+                SW(0, 7, 0, 8) SW(3, 7, 0, 8) SW(3, 7, 4, 8)
             } else
             if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "inplace")) {
                 SW(0, 5, 0, 8) SW(0, 6, 0, 8) SW(0, 7, 0, 8) SW(0, 8, 0, 8) SW(0, 9, 0, 8) SW(0, 7, 2, 8) SW(0, 7, 4, 8) SW(0, 6, 2, 8) SW(0, 8, 2, 8)
