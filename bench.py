@@ -641,8 +641,8 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
     alg_bytes = algorithmic_bytes(cfg, lanes_rank, frames)
     med = statistics.median(kern_ms) if kern_ms else 0.0
     achieved = alg_bytes / (med * 1e-3) / 1e9 if med > 0 else 0.0
-    traffic, traffic_src = (committed_traffic(cfg_name if args.layout == "frame" else cfg_name + "_lane", kernel)
-                            if not args.lanes and not inplace else (None, None))
+    traffic, traffic_src = (committed_traffic(cfg_name + ("_inplace" if inplace else "" if args.layout == "frame" else "_lane"), kernel)
+                            if not args.lanes else (None, None))
     return {
         "metric": cfg["metric"],
         "value": round(samples_all * args.steps / elapsed / 1e6, 1),
@@ -830,7 +830,7 @@ def rank_main(args, engine_factory=HipEngine):
         assert rccl_ranks == dist.get_world_size() == world
 
     line, engine = run_config(args.config, args, engine_factory, dist, rank, world, local, backend, args.steps, args.warmup,
-                              args.settle_ms, args.lanes, args.frames)
+                              args.settle_ms, args.lanes, args.frames, inplace=bool(getattr(args, "inplace", False)))
     x_host = getattr(engine, "x_host", None)
     engine.free()
     sub = None
@@ -928,6 +928,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 strong-scaling sub-object of the default run")
     ap.add_argument("--no-lane-major", action="store_true", help="skip the LaneMajor sub-objects (C2, C3, C4) of the default run")
+    ap.add_argument("--inplace", action="store_true", help="run the configuration itself in place (y == x; profiling runs of the in-place mode)")
     ap.add_argument("--no-inplace", action="store_true", help="skip the in-place (y == x) sub-objects (C2, C5) of the default run")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 (HbfDec /16) sub-object of the default run")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (lock-in) sub-object of the default run")

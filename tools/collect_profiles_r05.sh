@@ -30,12 +30,14 @@ run() {  # name, command...
   rm -rf $O/$n  # the sqlite databases are large; the summaries are what gets committed
 }
 WHAT=${2:-all}
-# usage: collect_profiles_r05.sh [tag] [all | comma list of c2,c2df,c2lm,c5,c5s8,c3,c3lm,c4,c4lm,cic]
+# usage: collect_profiles_r05.sh [tag] [all | comma list of c2,c2df,c2ip,c2lm,c5,c5ip,c5s8,c3,c3lm,c4,c4lm,cic]
 want() { [ "$WHAT" = all ] || echo ",$WHAT," | grep -q ",$1,"; }
 want c2 && run c2 python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --no-lane-major --no-inplace --steps 100 --warmup 5
 want c2df && run c2_driverflags python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --no-lane-major --no-inplace --steps 20 --warmup 5
 want c2lm && run c2_lanemajor python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --no-lane-major --no-inplace --layout lane --steps 100 --warmup 5
+want c2ip && run c2_inplace python bench.py --no-cpu --no-c5 --no-c3 --no-c4 --no-lane-major --no-inplace --inplace --steps 20 --warmup 5
 want c5 && run c5 python bench.py --config c5 --no-cpu --steps 20 --warmup 5
+want c5ip && run c5_inplace python bench.py --config c5 --inplace --no-cpu --steps 20 --warmup 5
 want c5s8 && run c5_shard8 python bench.py --config c5 --lanes 131072 --no-cpu --steps 50 --warmup 5
 # C3 / C4 from bench.py alone: one kernel name = one shape (FRAME_MAJOR, the layout of the driver's line), then LANE_MAJOR
 want c3 && run c3 python bench.py --config c3 --no-cpu --steps 20 --warmup 5
@@ -46,4 +48,4 @@ want c4lm && run c4_lanemajor python bench.py --config c4 --layout lane --no-cpu
 want cic && run cic python tools/perf_configs.py --only cic --iters 20
 # the LaneMajor fm_disc role kernel at 65536 lanes x 4096 frames
 want fmlm && run fm_disc_lanemajor python tools/perf_configs.py --only fmlm --iters 20
-for n in c2 c2_driverflags c2_lanemajor c5 c5_shard8 c3 c3_lanemajor c4 c4_lanemajor cic fm_disc_lanemajor; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done
+for n in c2 c2_driverflags c2_inplace c2_lanemajor c5 c5_inplace c5_shard8 c3 c3_lanemajor c4 c4_lanemajor cic fm_disc_lanemajor; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done
