@@ -307,11 +307,27 @@ static int run(const char *name, size_t lanes, size_t frames)
     return 0;
 }
 
+// a section that does nothing (y = x): the kernels' skeleton without arithmetic
+struct CopySec {
+    using T = int32_t;
+    using Sec = idsp::bq::SecI32;
+    static constexpr int W = 1;
+    static constexpr int COST = 1;
+    static constexpr bool kClamp = false;
+    static constexpr int LDS_MAX_N = 1;
+    static __device__ __forceinline__ int32_t step(const idsp::bq::SecI32 &, uint32_t (&s)[W], int32_t x0)
+    {
+        s[0] = uint32_t(x0);
+        return x0;
+    }
+};
+
 int main(int argc, char **argv)
 {
     const char *proc = argc > 1 ? argv[1] : "i32";
     const size_t lanes = argc > 2 ? atoll(argv[2]) : 65536, frames = argc > 3 ? atoll(argv[3]) : 4096;
     if (argc > 4) g_iters = atoi(argv[4]);
     if (!strcmp(proc, "f32")) return run<bq::Chain<bq::Df2tF32<false>, 1>>("f32_df2t", lanes, frames);
+    if (!strcmp(proc, "copy")) return run<bq::Chain<CopySec, 1>>("copy", lanes, frames);
     return run<bq::Chain<bq::Df1I32<false>, 1>>("i32_df1", lanes, frames);
 }
