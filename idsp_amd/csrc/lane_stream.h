@@ -820,8 +820,16 @@ struct LmSide {
 template <class P, int LW = kWave, int LB = kLmRun>
 __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const unsigned skew = 0, const unsigned skew_shift = 8)
 {
+    // Start-up skew (round 5 experiment; IDSP_DIAG=1 IDSP_LM_SKEW=ticks of 10 ns, IDSP_LM_SKEW_SHIFT): every wave of a launch issues its tile's 32
+    // loads in one burst and its 32 stores in another, and all waves do so at the same time — a CU's memory pipe then serves a load burst
+    // and a store burst one after the other (round 4: the kernel runs as the SUM of its directions).  Workgroups with an odd
+    // (blockIdx >> shift) start `skew` ticks late, so that half the waves of a CU store while the other half load.
+    if (skew && ((blockIdx.x >> skew_shift) & 1u)) {
+        const long long d = skew, t0 = wall_clock64();
+        for (long long spins = d / 8 + 16; spins > 0 && wall_clock64() - t0 < d; spins--) __builtin_amdgcn_s_sleep(8);
+    }
     using In = typename P::In;
     using Out = typename P::Out;
     static_assert(LmStagedOf<P>::value, "one lane per thread, 4- or 8-byte samples, pre-stage batch 1 or 4");
@@ -1481,8 +1489,9 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P, LW, LB>>(bytes)) return rc;
                     note_kernel(LW == 64 ? "stream_lane_major_staged" : LW == 32 ? "stream_lane_major_staged[32 lanes/wave]" : "stream_lane_major_staged[16 lanes/wave]",
                                 typeid(P).name());
+                    static const unsigned lm_skew = unsigned(diag_size("IDSP_LM_SKEW", 0)), lm_skew_shift = unsigned(diag_size("IDSP_LM_SKEW_SHIFT", 8)) & 31u;
                     hipLaunchKernelGGL((stream_lane_major_staged<P, LW, LB>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
-                                       lanes, frames, xl, yl);
+                                       lanes, frames, xl, yl, lm_skew, lm_skew_shift);
                     return launch_status();
                 };
                 // forms instantiated per processor: all three for the cheap ones, 64 / 32 for the heavy ones (never 16 above),

@@ -1,6 +1,6 @@
-// exp_fm_roles.hip — round 5: the role-wave FrameMajor kernel (idsp_amd/csrc/fm_roles.h) against the shipped LDS-DMA kernel
+// exp_fm_roles.hip — round 5: the role-wave FrameMajor kernel (tools/fm_roles.h) against the shipped LDS-DMA kernel
 // (stream_frame_major_lds), bit for bit first, then timed over several placements of the output buffer.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fwrapv -fno-slp-vectorize -Iinclude -Iidsp_amd/csrc \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fwrapv -fno-slp-vectorize -Iinclude -Iidsp_amd/csrc -Itools \
 //         tools/exp_fm_roles.hip -o build/exp_fm_roles
 //   build/exp_fm_roles <i32|f32> <lanes> <frames> [iters]
 #include <algorithm>
@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "biquad_sections.h"
-#include "fm_roles.h"
+#include "fm_roles.h"  // tools/fm_roles.h: the role-wave experiment kernel (not part of the library)
 #include "fm_sweep.h"
 
 namespace idsp {

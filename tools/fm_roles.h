@@ -1,4 +1,4 @@
-// fm_roles.h — FrameMajor per-lane recurrences on ROLE waves (round 5).
+// fm_roles.h — FrameMajor per-lane recurrences on ROLE waves (round 5 EXPERIMENT: measured equal to the shipped kernel and not used by the library; tools/exp_fm_roles.hip).
 //
 // Replaces the same triple loop as lane_stream.h (dsp-process/src/process.rs:122-141 driven by `Lanes`,
 // dsp-process/src/compose.rs:468-494).  stream_frame_major_lds (lane_stream.h) lets every wave of a 256-lane workgroup do

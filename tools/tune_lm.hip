@@ -269,7 +269,7 @@ void one_staged(const char *name, const typename P::Params &prm, const Bufs &b, 
     char *yy = b.y;
     auto launch = [&]() {
         hipLaunchKernelGGL((stream_lane_major_staged<P, LW, LB>), dim3(grid), dim3(kWave), bytes, 0, prm, b.st, reinterpret_cast<const In *>(inplace ? yy : b.x),
-                           reinterpret_cast<Out *>(yy), sh.lanes, sh.frames, sh.pitch, sh.pitch);
+                           reinterpret_cast<Out *>(yy), sh.lanes, sh.frames, sh.pitch, sh.pitch, 0u, 8u);
     };
     CK(hipMemset(b.st, 0, sh.lanes * 256));
     if (inplace)
