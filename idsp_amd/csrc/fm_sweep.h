@@ -480,9 +480,13 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
     const bool full = g.bw == unsigned(kFmBlock) && !xcdc && g.fps <= 1;  // full blocks on the 64-byte grid: bound by memory
     if constexpr (sweep_cheap<P>()) {
         if (full) {
-            if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm, kSweepPace>>(bytes)) return rc;
-            hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm, kSweepPace>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl,
-                               yl, sp, g.bw, g.rounds, g.round_lanes, xcdc, g.fps);
+            // up to 4 blocks per workgroup: the paced one-barrier schedule; 8 and 16 (a frame is one or two whole tiles, sixteen chains per thread): the
+            // plain two-barrier schedule, unpaced — there the sleep no longer fits the skeleton (2^20 lanes, profiles/r05_exp_fm_sweep_17.jsonl: f32 DF2T
+            // 0.74-0.75 flat either way, i32 DF1 0.71 unpaced against 0.69 paced)
+            constexpr int kForm = LPT <= 4 ? kSweepForm : 0, kPace = LPT <= 4 ? kSweepPace : 0;
+            if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kForm, kPace>>(bytes)) return rc;
+            hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kForm, kPace>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
+                               g.bw, g.rounds, g.round_lanes, xcdc, g.fps);
             return launch_status();
         }
     }

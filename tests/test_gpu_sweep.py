@@ -97,3 +97,19 @@ def test_every_geometry_class_on_a_capped_grid(gpu, grid, forms):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "small_shapes_inner"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("grid", ["3", "256"])
+def test_other_processor_families_on_the_sweep_kernel(gpu, grid):
+    """The parity suites of the whole biquad family, the per-lane coefficient banks, `Normal` and `Lowpass` (every LDS-eligible processor:
+    chains, cascades with shared delay lines, clamp / dither / wide sections, f32) re-run with the sweep kernel taking every FrameMajor
+    shape from 16 lanes and 16 frames up, on a grid of at most 3 workgroups (several blocks per workgroup, several sweeps per launch)
+    and on the default one."""
+    if FORCED:
+        pytest.skip("already inside a forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_SWEEP_MIN_LANES="16", IDSP_SWEEP_MAX_GRID=grid)
+    suites = ["tests/test_gpu_parity.py", "tests/test_gpu_bylane.py", "tests/test_gpu_normal_wdf.py", "tests/test_gpu_pitch.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", *suites, "-m", "gpu", "-x", "-q", "-k", "not last_kernel and not on_the_lds_kernel"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

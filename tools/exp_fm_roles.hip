@@ -255,6 +255,10 @@ static int run(const char *name, size_t lanes, size_t frames)
             if (g_geom.lpt == 1 && g_geom.bw <= 128 && !getenv("EXP_NO_FPS")) g_geom.fps = 256u / g_geom.bw;
             char nm[96];
 #define SW(F, N, S, T) snprintf(nm, sizeof nm, "sweep f" #F " nb" #N " slp" #S " ts" #T " lpt%d bw%u fps%u", g_geom.lpt, g_geom.bw, g_geom.fps); sweep(nm, g_geom.grid, [&](T_ *y) { launch_sweep<P, N, F, S, T>(c, y); });
+            if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "c5")) {
+                SW(0, 7, 0, 8) SW(0, 8, 0, 8) SW(0, 6, 0, 8) SW(3, 7, 4, 8) SW(3, 7, 3, 8) SW(3, 7, 2, 8) SW(3, 8, 4, 8) SW(3, 6, 4, 8) SW(3, 7, 6, 8) SW(2, 7, 2, 8) SW(2, 7, 4, 8) SW(1, 7, 0, 8)
+                SW(0, 7, 2, 8) SW(0, 7, 1, 8) SW(1, 7, 2, 8)
+            } else
             if (getenv("EXP_SET") && !strcmp(getenv("EXP_SET"), "small")) {
                 SW(0, 7, 0, 8) SW(1, 7, 0, 8) SW(3, 7, 0, 8) SW(2, 7, 0, 8)
             } else
