@@ -72,6 +72,7 @@ __device__ __forceinline__ int64_t sum5(const SecI32 &c, int32_t x0, int32_t x1,
 template <bool CLAMP>
 struct Df1I32 {
     static constexpr bool kClamp = CLAMP;
+    static constexpr bool SWEEP_BIG_TWO_BARRIER = !CLAMP;
 #ifdef IDSP_EXP_DF1_RING  // experiment: ring depth of the plain i32 DF1 (co-residency of two workgroups per CU against the ring's LDS)
     static constexpr int LDS_RING = CLAMP ? 4 : IDSP_EXP_DF1_RING;
 #else
@@ -238,6 +239,7 @@ struct Df1F32 {
 template <bool CLAMP>
 struct Df2tF32 {
     static constexpr bool kClamp = CLAMP;
+    static constexpr bool SWEEP_BIG_TWO_BARRIER = !CLAMP;
     static constexpr int LDS_RING = CLAMP ? 4 : 7;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = false;
     static constexpr int LDS_MAX_N = 2;     // serial sections up to which the LDS-DMA kernel beats the register window
@@ -316,7 +318,7 @@ struct Df2tF64 {
 // `Normal<C>` x `DirectForm1<T>` (src/iir/normal.rs:37-58); ba = [b0, b1, b2, p.re, p.im], state words
 // {x0, x1, y0, y1}: y1' = (b0 x0 + b1 x1 + b2 x2 + re y1 + (-im) y0).as_(), y0' = (im y1 + re y0).as_().
 struct NormalI32 {
-    static constexpr int SWEEP_LPT = 4;
+    static constexpr int SWEEP_LPT = 8;
     using T = int32_t;
     static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = true;
@@ -343,7 +345,8 @@ struct NormalI32 {
     }
 };
 struct NormalF32 {
-    static constexpr int SWEEP_LPT = 4;
+    static constexpr int SWEEP_LPT = 8;
+    static constexpr bool SWEEP_BIG_TWO_BARRIER = true;
     using T = float;
     static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = true;
@@ -426,7 +429,7 @@ struct SecLdsMaxN<Sec, std::void_t<decltype(Sec::LDS_MAX_N)>> {
 
 // N independent sections in series (`[C] x [S]`, compose.rs:43-77).
 // largest number of sub-blocks per workgroup a single section is instantiated with on the sweep kernel: 16 (2^20 lanes in one sweep) for the
-// biquad sections proper, Sec::SWEEP_LPT for the others (Normal: 4)
+// biquad sections proper, Sec::SWEEP_LPT for the others (Normal: 8)
 template <class Sec, class = void>
 struct SecSweepLpt {
     static constexpr int value = 16;
@@ -435,6 +438,11 @@ template <class Sec>
 struct SecSweepLpt<Sec, std::void_t<decltype(Sec::SWEEP_LPT)>> {
     static constexpr int value = Sec::SWEEP_LPT;
 };
+// sections whose single-section processors run 8 / 16 blocks per workgroup of the sweep kernel on its two-barrier schedule (fm_sweep.h)
+template <class Sec, class = void>
+struct SecBigTwoBarrier : std::false_type {};
+template <class Sec>
+struct SecBigTwoBarrier<Sec, std::void_t<decltype(Sec::SWEEP_BIG_TWO_BARRIER)>> : std::integral_constant<bool, Sec::SWEEP_BIG_TWO_BARRIER> {};
 template <class Sec, class = void>
 struct SecHasTile : std::false_type {};
 template <class Sec>
@@ -451,7 +459,8 @@ struct Chain {
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 4;  // N >= 2: tools/tune_lds.hip (worst placement 0.75-0.77 against 0.68 at 8 tiles for N = 2)
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     static constexpr bool LDS_ELIGIBLE = N <= SecLdsMaxN<Sec>::value;
-    static constexpr int SWEEP_MAX_LPT = N == 1 ? SecSweepLpt<Sec>::value : N == 2 ? 4 : 2;  // sub-blocks per workgroup on the sweep kernel (fm_sweep.h)
+    static constexpr int SWEEP_MAX_LPT = N == 1 ? SecSweepLpt<Sec>::value : N == 2 ? 8 : 2;
+    static constexpr bool SWEEP_BIG_TWO_BARRIER = N == 1 && SecBigTwoBarrier<Sec>::value;  // sub-blocks per workgroup on the sweep kernel (fm_sweep.h)
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
 
@@ -607,7 +616,8 @@ struct ChainByLane {
     static constexpr bool LDS_ELIGIBLE = N <= SecLdsMaxN<Sec>::value;
     static constexpr int CV = Sec::kClamp ? 8 : 5;
     // sub-blocks per workgroup on the sweep kernel (fm_sweep.h): every lane carries its own coefficients in registers beside its state
-    static constexpr int SWEEP_MAX_LPT = N == 1 ? 4 : 2;
+    static constexpr int SWEEP_MAX_LPT = N == 1 ? 8 : 2;
+    static constexpr bool SWEEP_BIG_TWO_BARRIER = N == 1 && SecBigTwoBarrier<Sec>::value && std::is_same<typename Sec::T, float>::value;  // (i32 DF1 by lane: one barrier)
     using Params = ByLaneParams;
     uint32_t s[N][Sec::W];
     typename Sec::Sec c[N];

@@ -14,6 +14,9 @@ namespace thr {
 constexpr size_t kSweepMinLanes = 49152, kSweepMinLanesFps = 24576;
 // ... and from this many frames up (shorter calls: the round-3 LDS-DMA kernel or the staged kernel)
 constexpr size_t kSweepMinFrames = 16;
+// ... and only when the launch is one sweep, or its sweeps are at least this many blocks per workgroup wide (fm_sweep.h `sweep_takes`; a processor's
+// largest count is its SWEEP_MAX_LPT: 16 single biquad sections, 8 `Normal` / per-lane banks / two-section chains, 4 and 2 cascades and longer chains)
+constexpr int kSweepMinLptSeveralSweeps = 8;
 // rows off the 64-byte grid take the sweep kernel only above the largest single-round grid of the round-3 LDS-DMA kernel
 constexpr size_t kLdsGridCap = 384;  // workgroups of 256 lanes: 98304 lanes
 // "whole rounds + remainder on a second stream": remainders up to this many lanes, whole rounds of 1, 2, 4, 8 or 16 x 65536 lanes

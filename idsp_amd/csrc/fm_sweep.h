@@ -55,6 +55,11 @@ constexpr int kSweepT = 8;     // segments per tile
 constexpr int kSweepForm = 3, kSweepPace = 4;
 template <class P>
 constexpr bool sweep_cheap() { return P::COST <= 50; }
+// processors whose full blocks run 8 / 16 blocks per workgroup on the two-barrier schedule (launch_sweep_lpt below)
+template <class P, class = void>
+struct SweepBigTwoBarrierOf : std::false_type {};
+template <class P>
+struct SweepBigTwoBarrierOf<P, std::void_t<decltype(P::SWEEP_BIG_TWO_BARRIER)>> : std::integral_constant<bool, P::SWEEP_BIG_TWO_BARRIER> {};
 
 struct SweepGeom {
     int lpt = 1;             // sub-blocks per workgroup
@@ -457,8 +462,8 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
 
 // ------------------------------------------------------------------------------------------------------------ host
 // Largest LPT a processor is instantiated with (each doubling doubles its state registers, the unrolled loop body and the build time): the
-// single biquad sections (P::SWEEP_MAX_LPT = 16) take every lane count up to 2^20 in ONE sweep; everything else runs more than 262144 lanes
-// (heavy bodies: 131072) as several sweeps over lane ranges — quarter rows of a 2^20-lane tensor, still dense pieces of 1 MiB.
+// single biquad sections (P::SWEEP_MAX_LPT = 16) take every lane count up to 2^20 in ONE sweep; `Normal`, the per-lane banks and two-section chains
+// (8) up to 524288, and 2^20 as two sweeps over half rows; everything else (4, heavy bodies 2) one sweep only — `sweep_takes` below.
 template <class P, class = void>
 struct SweepMaxLptOf {
     static constexpr int value = P::COST <= 120 ? 4 : 2;  // (single biquad sections declare 16: biquad_sections.h)
@@ -478,15 +483,25 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
 {
     constexpr size_t bytes = sweep_lds_bytes<P>();
     const bool full = g.bw == unsigned(kFmBlock) && !xcdc && g.fps <= 1;  // full blocks on the 64-byte grid: bound by memory
-    if constexpr (sweep_cheap<P>()) {
+    // Full blocks of the cheap processors up to 4 blocks per workgroup: the paced one-barrier schedule.  8 and 16 blocks per workgroup (a frame is one
+    // or two whole tiles, up to sixteen chains per thread): unpaced — the sleep no longer fits the skeleton — and on the plain two-barrier schedule for
+    // the processors that declare SWEEP_BIG_TWO_BARRIER (the unclamped i32 DF1, f32 DF2T and `Normal` sections: 2^20 lanes 0.72 / 0.75 / 0.66 against
+    // 0.68 / 0.69 / 0.64 on one barrier), on the one-barrier schedule for everything else (clamped sections 0.69-0.71 against 0.54-0.60, two-section
+    // chains 0.68-0.72 against 0.65-0.69: profiles/r05_perf_big_lanes.txt).
+    if constexpr (LPT <= 4) {
+        if constexpr (sweep_cheap<P>()) {
+            if (full) {
+                if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm, kSweepPace>>(bytes)) return rc;
+                hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm, kSweepPace>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames,
+                                   xl, yl, sp, g.bw, g.rounds, g.round_lanes, xcdc, g.fps);
+                return launch_status();
+            }
+        }
+    } else if constexpr (SweepBigTwoBarrierOf<P>::value) {
         if (full) {
-            // up to 4 blocks per workgroup: the paced one-barrier schedule; 8 and 16 (a frame is one or two whole tiles, sixteen chains per thread): the
-            // plain two-barrier schedule, unpaced — there the sleep no longer fits the skeleton (2^20 lanes, profiles/r05_exp_fm_sweep_17.jsonl: f32 DF2T
-            // 0.74-0.75 flat either way, i32 DF1 0.71 unpaced against 0.69 paced)
-            constexpr int kForm = LPT <= 4 ? kSweepForm : 0, kPace = LPT <= 4 ? kSweepPace : 0;
-            if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, kForm, kPace>>(bytes)) return rc;
-            hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kForm, kPace>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp,
-                               g.bw, g.rounds, g.round_lanes, xcdc, g.fps);
+            if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0>>(bytes)) return rc;
+            hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp, g.bw,
+                               g.rounds, g.round_lanes, xcdc, g.fps);
             return launch_status();
         }
     }
@@ -504,6 +519,19 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
     hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, kSweepForm>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp, g.bw,
                        g.rounds, g.round_lanes, xcdc, g.fps);
     return launch_status();
+}
+
+// Whether the sweep kernel is the one to take for `lanes` lanes of P: when the launch is ONE sweep, or when its sweeps are at least 8 blocks per
+// workgroup wide (2 MiB of every row).  Several narrower sweeps per launch are the panel walk again (rows at a stride, 1 MiB or less of each): 2^20 lanes
+// in four sweeps of 4 blocks per workgroup 0.54-0.57 of the HBM peak for every family against 0.60-0.62 on round 4's dispatch, which those launches keep
+// (profiles/r05_perf_big_lanes.txt).
+template <class P>
+bool sweep_takes(size_t lanes)
+{
+    SweepGeom g;
+    static const unsigned max_grid = unsigned(diag_size("IDSP_SWEEP_MAX_GRID", 256));
+    if (!sweep_geometry(lanes, SweepMaxLptOf<P>::value, g, max_grid ? max_grid : 256u)) return false;
+    return g.rounds == 1 || g.lpt >= thr::kSweepMinLptSeveralSweeps || max_grid != 256;  // (a capped grid is the tests' way to reach several sweeps per launch at small sizes)
 }
 
 // The launch for `lanes` lanes (a multiple of 4: whole 16-byte pieces; rows need dword alignment only — `global_load_lds_dwordx4` and the

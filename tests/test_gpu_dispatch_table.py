@@ -21,23 +21,23 @@ def last(eng):
     return eng.fn["last_kernel"]().decode()
 
 
-def biquad_kernel(gpu, op, lanes, frames, layout, dtype, words, pitch=None):
+def biquad_kernel(gpu, op, lanes, frames, layout, dtype, words, pitch=None, n=1):
     o = H.oracle()
     sos = (C.c_double * 6)(*o.lowpass_sos(0.01))
     if dtype == torch.int32:
         q = _abi.BiquadI32()
         assert o.fn["biquad_i32_from_sos"](sos, 30, C.byref(q)) == 0
-        cfg = (_abi.BiquadI32 * 1)(q)
+        cfg = (_abi.BiquadI32 * n)(*([q] * n))
     else:
         q = _abi.BiquadF32()
         assert o.fn["biquad_f32_from_sos_f64"](sos, C.byref(q)) == 0
-        cfg = (_abi.BiquadF32 * 1)(q)
+        cfg = (_abi.BiquadF32 * n)(*([q] * n))
     pitch = pitch or (lanes if layout == FM else frames)
     rows = frames if layout == FM else lanes
     x = torch.zeros(rows * pitch, dtype=dtype, device=DEV)
     y = torch.full_like(x, 7)
-    st = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)
-    rc = gpu.fn[op + "_pitch"](C.cast(cfg, C.c_void_p), 1, C.c_void_p(st.data_ptr()), C.c_void_p(x.data_ptr()), pitch, C.c_void_p(y.data_ptr()), pitch,
+    st = torch.zeros((words * n, lanes), dtype=torch.int32, device=DEV)
+    rc = gpu.fn[op + "_pitch"](C.cast(cfg, C.c_void_p), n, C.c_void_p(st.data_ptr()), C.c_void_p(x.data_ptr()), pitch, C.c_void_p(y.data_ptr()), pitch,
                                lanes, frames, layout, None)
     torch.cuda.synchronize()
     assert rc == 0, gpu.err()
@@ -81,6 +81,15 @@ def test_c5_and_lane_major_biquads(gpu):
     assert biquad_kernel(gpu, "biquad_i32_df1", 65536, 4096, LM, torch.int32, 4).startswith("stream_lane_major_staged<")
     assert biquad_kernel(gpu, "biquad_i32_df1", 32768, 4096, LM, torch.int32, 4).startswith("stream_lane_major_staged[32 lanes/wave]<")
     assert biquad_kernel(gpu, "biquad_i32_df1", 16384, 4096, LM, torch.int32, 4).startswith("stream_lane_major_staged[16 lanes/wave]<")
+
+
+def test_several_sweeps_per_launch_only_when_eight_blocks_wide(gpu):
+    """fm_sweep.h `sweep_takes`: a family whose largest blocks-per-workgroup count does not cover the lanes in ONE sweep keeps round 4's dispatch,
+    unless its sweeps are 8 blocks per workgroup wide (two-section chains: 8, three: 2)."""
+    assert biquad_kernel(gpu, "biquad_i32_df1", 1 << 19, 32, FM, torch.int32, 4, n=2).startswith(SWEEP + "8 blocks/workgroup]<")
+    assert biquad_kernel(gpu, "biquad_i32_df1", 1 << 20, 32, FM, torch.int32, 4, n=2).startswith(SWEEP + "8 blocks/workgroup]<")  # two sweeps
+    assert biquad_kernel(gpu, "biquad_i32_df1", 1 << 17, 32, FM, torch.int32, 4, n=3).startswith(SWEEP + "2 blocks/workgroup]<")
+    assert not biquad_kernel(gpu, "biquad_i32_df1", 1 << 18, 32, FM, torch.int32, 4, n=3).startswith(SWEEP)                      # would be two narrow sweeps
 
 
 def test_c3_and_c4(gpu):
