@@ -18,7 +18,9 @@ ORCFLAGS   := -O3 -std=c11 -fPIC -ffp-contract=off -fno-fast-math \
 
 CSRC       := idsp_amd/csrc
 # the translation units that compile longest go first, so that `make -j` does not end on one of them
-HIP_SLOW   := $(addprefix $(CSRC)/,dds.hip lockin_stream_iq.hip lockin_stream_arg.hip lockin_stream_norm_sqr.hip normal_wdf.hip cascade.hip biquad_f64.hip cic_int_i64_hi.hip cic_int_i32_hi.hip)
+HIP_SLOW   := $(addprefix $(CSRC)/,biquad_f32_df1.hip biquad_f32_df2t.hip normal.hip normal_wdf.hip biquad_i32_dither.hip cic_int_i32_hi.hip biquad_i32_wide.hip lowpass.hip \
+              biquad_f64.hip biquad_f64_df2t.hip cascade.hip cascade_f32.hip biquad_bylane_f.hip biquad_bylane_f64.hip biquad_bylane_i32.hip biquad_bylane_i32_wide.hip \
+              biquad_i32_df1.hip cic_int_i64_hi.hip lockin_generic.hip lockin_stream_arg.hip cic_dec_i32_hi.hip)
 HIP_SRCS   := $(HIP_SLOW) $(filter-out $(HIP_SLOW),$(wildcard $(CSRC)/*.hip))
 HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 HIP_HDRS   := $(wildcard $(CSRC)/*.h) include/idsp_hip.h

@@ -1,4 +1,4 @@
-// biquad_bylane_f.hip — C-ABI entry points (include/idsp_hip.h) of the per-lane-coefficient f32 biquads (f64: biquad_bylane_f64.hip)
+// biquad_bylane_f64.hip — C-ABI entry points (include/idsp_hip.h) of the per-lane-coefficient f64 biquads
 // (`ByLane<[Biquad<f32>; N]>`, dsp-process/src/compose.rs:363-390); device code in biquad_sections.h.
 #include "biquad_sections.h"
 
@@ -18,8 +18,8 @@ using namespace idsp::bq;
     }
 
 extern "C" {
-IDSP_BYLANE_F(float, f32, df1, Df1F32<false>)
-IDSP_BYLANE_F(float, f32, df1_clamp, Df1F32<true>)
-IDSP_BYLANE_F(float, f32, df2t, Df2tF32<false>)
-IDSP_BYLANE_F(float, f32, df2t_clamp, Df2tF32<true>)
+IDSP_BYLANE_F(double, f64, df1, Df1F64<false>)
+IDSP_BYLANE_F(double, f64, df1_clamp, Df1F64<true>)
+IDSP_BYLANE_F(double, f64, df2t, Df2tF64<false>)
+IDSP_BYLANE_F(double, f64, df2t_clamp, Df2tF64<true>)
 }  // extern "C"

@@ -1,4 +1,4 @@
-// biquad_bylane_i32.hip — C-ABI entry points (include/idsp_hip.h) of the per-lane-coefficient i32 biquads
+// biquad_bylane_i32_wide.hip — (second half of biquad_bylane_i32.hip: the clamped dither and the wide sections) C-ABI entry points (include/idsp_hip.h) of the per-lane-coefficient i32 biquads
 // (`ByLane<[Biquad<Q32<F>>; N]>`, dsp-process/src/compose.rs:363-390); device code in biquad_sections.h.
 #include "biquad_sections.h"
 
@@ -18,7 +18,7 @@ using namespace idsp::bq;
     }
 
 extern "C" {
-IDSP_BYLANE_I32(df1, Df1I32<false>)
-IDSP_BYLANE_I32(df1_clamp, Df1I32<true>)
-IDSP_BYLANE_I32(dither, DitherI32<false>)
+IDSP_BYLANE_I32(dither_clamp, DitherI32<true>)
+IDSP_BYLANE_I32(wide, WideI32<false>)
+IDSP_BYLANE_I32(wide_clamp, WideI32<true>)
 }  // extern "C"

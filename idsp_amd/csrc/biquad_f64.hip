@@ -1,4 +1,5 @@
-// biquad_f64.hip — C-ABI entry points (include/idsp_hip.h) of the f64 biquad family; device code in biquad_sections.h.
+// biquad_f64.hip — C-ABI entry points (include/idsp_hip.h) of the f64 DF1 biquads and the f64 cascade; device code in
+// biquad_sections.h.  (DF2T: biquad_f64_df2t.hip — translation units sized for the parallel build.)
 #include "biquad_sections.h"
 
 using namespace idsp;
@@ -18,18 +19,6 @@ int idsp_biquad_f64_df1_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *
     return entry_f64<Df1F64<true>, idsp_biquad_clamp_f64, FillClampF64>(cfg, n, state, x, y, lanes, frames, layout, stream);
 }
 
-int idsp_biquad_f64_df2t(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, double *y,
-                         size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_f64<Df2tF64<false>, idsp_biquad_f64, FillF64>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
-int idsp_biquad_f64_df2t_clamp(const idsp_biquad_clamp_f64 *cfg, size_t n, void *state, const double *x, double *y,
-                               size_t lanes, size_t frames, int layout, void *stream)
-{
-    return entry_f64<Df2tF64<true>, idsp_biquad_clamp_f64, FillClampF64>(cfg, n, state, x, y, lanes, frames, layout, stream);
-}
-
 int idsp_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, double *y,
                          size_t lanes, size_t frames, int layout, void *stream)
 {
@@ -41,8 +30,6 @@ int idsp_cascade_f64_df1(const idsp_biquad_f64 *cfg, size_t n, void *state, cons
 // explicit row pitches (include/idsp_hip.h, "_pitch" entries)
 IDSP_PITCH_TWIN(idsp_biquad_f64_df1, idsp_biquad_f64, double, entry_f64, Df1F64<false>, idsp_biquad_f64, FillF64)
 IDSP_PITCH_TWIN(idsp_biquad_f64_df1_clamp, idsp_biquad_clamp_f64, double, entry_f64, Df1F64<true>, idsp_biquad_clamp_f64, FillClampF64)
-IDSP_PITCH_TWIN(idsp_biquad_f64_df2t, idsp_biquad_f64, double, entry_f64, Df2tF64<false>, idsp_biquad_f64, FillF64)
-IDSP_PITCH_TWIN(idsp_biquad_f64_df2t_clamp, idsp_biquad_clamp_f64, double, entry_f64, Df2tF64<true>, idsp_biquad_clamp_f64, FillClampF64)
 
 int idsp_cascade_f64_df1_pitch(const idsp_biquad_f64 *cfg, size_t n, void *state, const double *x, size_t x_pitch, double *y,
                                size_t y_pitch, size_t lanes, size_t frames, int layout, void *stream)
