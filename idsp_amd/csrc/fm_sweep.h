@@ -482,7 +482,9 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
                      size_t yl, size_t sp, const SweepGeom &g, hipStream_t s, unsigned xcdc)
 {
     constexpr size_t bytes = sweep_lds_bytes<P>();
-    const bool full = g.bw == unsigned(kFmBlock) && !xcdc && g.fps <= 1;  // full blocks on the 64-byte grid: bound by memory
+    // (IDSP_DIAG=1 IDSP_SWEEP_PACE=1: narrow blocks take the full blocks' schedule too; =2: rows off the grid as well)
+    static const size_t pace_more = diag_size("IDSP_SWEEP_PACE", 0);
+    const bool full = (g.bw == unsigned(kFmBlock) || pace_more >= 1) && (!xcdc || pace_more >= 2) && g.fps <= 1;  // full blocks on the 64-byte grid: bound by memory
     // Full blocks of the cheap processors up to 4 blocks per workgroup: the paced one-barrier schedule.  8 and 16 blocks per workgroup (a frame is one
     // or two whole tiles, up to sixteen chains per thread): unpaced — the sleep no longer fits the skeleton — and on the plain two-barrier schedule for
     // the processors that declare SWEEP_BIG_TWO_BARRIER (the unclamped i32 DF1, f32 DF2T and `Normal` sections: 2^20 lanes 0.72 / 0.75 / 0.66 against
@@ -498,7 +500,8 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
             }
         }
     } else if constexpr (SweepBigTwoBarrierOf<P>::value) {
-        if (full) {
+        static const bool xcdc_two = diag_env("IDSP_SWEEP_XCDC_TWO_BARRIER") != nullptr;  // IDSP_DIAG=1: rows off the grid on the two-barrier schedule too
+        if (full || (xcdc_two && g.bw == unsigned(kFmBlock) && g.fps <= 1)) {
             if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0>>(bytes)) return rc;
             hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp, g.bw,
                                g.rounds, g.round_lanes, xcdc, g.fps);
@@ -543,7 +546,8 @@ int launch_sweep(const typename P::Params &prm, uint32_t *st, const typename P::
     const bool on_grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * sizeof(typename P::In)) % 64 == 0 &&
                            (yl * sizeof(typename P::Out)) % 64 == 0;
     static const bool no_xcdc = diag_env("IDSP_SWEEP_NO_XCDC") != nullptr;
-    const unsigned xcdc = !on_grid64 && !no_xcdc ? 1u : 0u;
+    static const bool force_xcdc = diag_env("IDSP_SWEEP_FORCE_XCDC") != nullptr;  // IDSP_DIAG=1: the XCD-contiguous block order on every launch
+    const unsigned xcdc = (!on_grid64 && !no_xcdc) || force_xcdc ? 1u : 0u;
     constexpr int kMax = SweepMaxLptOf<P>::value;
     SweepGeom g;
     // (IDSP_DIAG=1 IDSP_SWEEP_MAX_GRID=n: at most n workgroups — small tensors then reach every LPT and several sweeps per launch: tests)

@@ -13,7 +13,8 @@ q = _abi.BiquadI32()
 call("biquad_i32_from_sos", (C.c_double * 6)(*P.lowpass_sos(0.01)), 30, C.byref(q))
 cfg = (_abi.BiquadI32 * 1)(q)
 frames = 4096
-for lanes, pitch in ((65536, 65536), (65536, 65536 + 32), (65536, 65536 + 8), (65536, 65536 + 4), (65536, 65536 + 16), (65000, 65000), (65000, 65024), (65000, 65536), (65532, 65532), (65532, 65536)):
+shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]]  # lanes:pitch pairs; default: the round-3 list
+for lanes, pitch in shapes or ((65536, 65536), (65536, 65536 + 32), (65536, 65536 + 8), (65536, 65536 + 4), (65536, 65536 + 16), (65000, 65000), (65000, 65024), (65000, 65536), (65532, 65532), (65532, 65536)):
     x = torch.randint(-(1 << 24), 1 << 24, (frames * pitch,), dtype=torch.int32, device="cuda")
     y = torch.empty_like(x)
     st = torch.zeros((4, lanes), dtype=torch.int32, device="cuda")
