@@ -109,7 +109,11 @@ constexpr size_t sweep_lds_bytes(int nb = kSweepNB, int ts = kSweepT)
 // TSEG: one-KiB segments per tile (8 or 16: twice the steps per barrier pair, for the shapes where the serial skeleton shows).
 // FPSM: several frames per segment (`fps_` of them; LPT = 1 and 4-byte outputs only).  A template flag, not just the run-time count: with the slot
 // loop in it the one-frame-per-segment kernel lost 5-30 % at 65536 lanes (0.34 -> 0.36-0.49 ms by schedule).
-template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0, int TSEG = kSweepT, bool FPSM = false>
+// XC (full 256-lane blocks on rows off the 64-byte grid): every request goes out as TWO instructions, lanes 0-59 and lanes 60-63.  Same lines, same
+// bytes — but a 1 KiB request that starts off the grid ran 0.59-0.65 of the peak in the copy skeleton where 60 + 4 lanes run 0.68-0.72 and 960-byte
+// segments 0.74-0.76 (tools/ubench_fm_rows_off_grid.hip, NOTES round 5).  The second instruction always has its four lanes on (a lane beyond a partial
+// block's pieces re-requests the block's first piece into its own, unused, part of the segment): the request count stays static.
+template <class P, int LPT, int NB = kSweepNB, int FORM = 3, int SLP = 0, int TSEG = kSweepT, bool FPSM = false, bool XC = false>
 __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes,
@@ -127,9 +131,11 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
     constexpr bool PRE = (FORM & 1) != 0, ONEBAR = (FORM & 2) != 0, SPLIT = (FORM & 4) != 0;
     static_assert(!SPLIT || (ONEBAR && RPW == 2), "split requests: one-barrier schedule");
     static_assert(TS == 8 || TS == 16, "tile of 8 or 16 segments");
+    constexpr int RQ = XC ? 2 : 1;           // request instructions per segment
+    static_assert(!XC || (!FPSM && !SPLIT), "split requests: one frame per segment, unsplit schedule");
     constexpr int kYoungS = OW + (NB - 2) * (RPW + RPW * OW);  // split schedule: request, stores, request, stores per iteration
-    constexpr int kYoung = RPW * OW + (NB - 1) * (RPW + RPW * OW);
-    constexpr int kYoung1 = RPW * OW + (NB - 2) * (RPW + RPW * OW);  // one-barrier schedule
+    constexpr int kYoung = RPW * OW + (NB - 1) * (RPW * RQ + RPW * OW);
+    constexpr int kYoung1 = RPW * OW + (NB - 2) * (RPW * RQ + RPW * OW);  // one-barrier schedule
     static_assert(kYoung <= 63, "vmcnt range");
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -263,7 +269,12 @@ __global__ __launch_bounds__(kFmBlock) void stream_frame_major_sweep(
                     else
                         on = on && q.fr + size_t(tslot) * TS + sfo[j] < frames;       // this thread's slot lies beyond the last frame
                 }
-                if (on) glds16_s(base, voff, lds_base + uint32_t((q.slot * TS + wave + 4 * j) * kFmBlock * 4));
+                if constexpr (XC) {
+                    const uint32_t dst = lds_base + uint32_t((q.slot * TS + wave + 4 * j) * kFmBlock * 4);
+                    if (on && lid < 60) glds16_s(base, voff, dst);
+                    if (lid >= 60) glds16_s(base, on ? voff : 0u, dst);
+                } else if (on)
+                    glds16_s(base, voff, lds_base + uint32_t((q.slot * TS + wave + 4 * j) * kFmBlock * 4));
             }
         };
         // stores of the tile at position q (q.row counts words of y)
@@ -507,6 +518,18 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
                                g.rounds, g.round_lanes, xcdc, g.fps);
             return launch_status();
         }
+    }
+    // Full blocks on rows off the 64-byte grid (the whole rounds of a dense tensor of 65536 k + 1 ... 3 lanes, odd pitches): the two-barrier schedule with
+    // every request as two instructions (XC above) — 131072 lanes at pitch + 4: 0.62 of the peak against 0.59, 524288: 0.63 against 0.60, 65536: 0.65-0.72
+    // against 0.61-0.65 (profiles/r05_exp_sweep_off_grid_full_blocks.txt).  Cheap processors only (one more instantiation per blocks-per-workgroup count).
+    static const bool no_xc = diag_env("IDSP_SWEEP_NO_SPLIT_REQUESTS") != nullptr;  // IDSP_DIAG=1: one instruction per request on rows off the grid too
+    if constexpr (sweep_cheap<P>()) {
+      if (xcdc && g.bw == unsigned(kFmBlock) && g.fps <= 1 && !no_xc) {
+        if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0, kSweepT, false, true>>(bytes)) return rc;
+        hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0, kSweepT, false, true>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames,
+                           xl, yl, sp, g.bw, g.rounds, g.round_lanes, xcdc, g.fps);
+        return launch_status();
+      }
     }
     if (g.fps > 1) {
         if constexpr (LPT == 1 && sizeof(typename P::Out) == 4) {

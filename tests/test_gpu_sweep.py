@@ -99,6 +99,39 @@ def test_every_geometry_class_on_a_capped_grid(gpu, grid, forms):
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_rows_off_the_grid_inner(gpu):
+    """(inside the forced run below) full 256-lane blocks on rows off the 64-byte grid: the split-request instantiation (fm_sweep.h XC) at every
+    blocks-per-workgroup count, whole and partial last blocks, dense odd pitches"""
+    if not (FORCED and os.environ.get("IDSP_SWEEP_OFFGRID_MIN_LANES")):
+        pytest.skip("runs inside test_full_blocks_on_rows_off_the_grid")
+    rng = np.random.default_rng(504)
+    cs = sweep_cases(rng)
+    seen = set()
+    for k, lpt in enumerate((1, 2, 4, 8, 16)):
+        for j, (op, cfg, n, words, dt) in enumerate(cs):
+            if (j + k) % 2:
+                continue
+            lanes = 8 * 256 * lpt - (0 if (j + k) % 4 else 100)  # whole blocks / a partial last one
+            frames = int(rng.choice([16, 23, 57, 64, 130]))
+            pitch = lanes + int(rng.choice([1, 4, 8, 17]))
+            FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, bool((j + k) & 1))
+            assert kernel_of(gpu).startswith("stream_frame_major_sweep["), (op, lanes, kernel_of(gpu))
+            seen.add(kernel_of(gpu).split("<")[0])
+    assert sum("XCD-contiguous" in k for k in seen) >= 4, seen
+
+
+def test_full_blocks_on_rows_off_the_grid(gpu):
+    """IDSP_DIAG=1 IDSP_SWEEP_MIN_LANES=16 IDSP_SWEEP_OFFGRID_MIN_LANES=1 IDSP_SWEEP_MAX_GRID=8: small tensors with odd row pitches on the sweep kernel's
+    XCD-contiguous order with 8 workgroups."""
+    if FORCED:
+        pytest.skip("already inside a forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_SWEEP_MIN_LANES="16", IDSP_SWEEP_MAX_GRID="8", IDSP_SWEEP_OFFGRID_MIN_LANES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "rows_off_the_grid_inner"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("grid", ["3", "256"])
 def test_other_processor_families_on_the_sweep_kernel(gpu, grid):
     """The parity suites of the whole biquad family, the per-lane coefficient banks, `Normal` and `Lowpass` (every LDS-eligible processor:

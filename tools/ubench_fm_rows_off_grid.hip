@@ -59,8 +59,13 @@ __global__ __launch_bounds__(256) void k_rows(const uint32_t *x, uint32_t *y, co
             if constexpr (SPLIT_RQ) {
                 if (lid < 60) glds16_s(x + A, uint32_t(lid * 16), lds_base + uint32_t(((slot * TS + g) * SEG) * 4));
                 if (lid >= 60) glds16_s(x + A, uint32_t(lid * 16), lds_base + uint32_t(((slot * TS + g) * SEG) * 4));
-            } else if ((MODE != 0 && MODE < 3) || lid < BW / 4)
+            } else if ((MODE != 0 && MODE < 3) || lid < BW / 4) {
+#ifdef UB_VADDR  // the request's address as a 64-bit VGPR pair per lane (round 3's kernel) instead of SGPR base + 32-bit lane offset (fm_sweep.h)
+                glds16(x + A + lid * 4, lds_base + uint32_t(((slot * TS + g) * SEG) * 4));
+#else
                 glds16_s(x + A, uint32_t(lid * 16), lds_base + uint32_t(((slot * TS + g) * SEG) * 4));
+#endif
+            }
         }
     };
     for (size_t t = 0; t + 1 < NB; t++) issue(t);
