@@ -19,6 +19,8 @@ constexpr size_t kSweepMinFrames = 16;
 constexpr int kSweepMinLptSeveralSweeps = 8;
 // rows off the 64-byte grid take the sweep kernel only above the largest single-round grid of the round-3 LDS-DMA kernel
 constexpr size_t kLdsGridCap = 384;  // workgroups of 256 lanes: 98304 lanes
+// ... and up to this many lanes (below: several frames per segment against the staged single-wave kernel; in between round 3's XCD-contiguous LDS-DMA kernel)
+constexpr size_t kSweepOffGridSmallMax = 53248;
 // "whole rounds + remainder on a second stream": remainders up to this many lanes, whole rounds of 1, 2, 4, 8 or 16 x 65536 lanes
 constexpr size_t kSplitTailMax = 20480;
 // staged single-wave kernel below kSweepMinLanes*: cheap processors below this lane count, heavy ones (COST > 120) inside the window

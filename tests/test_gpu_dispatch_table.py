@@ -60,7 +60,7 @@ I32_FM = [
     (131073, SWEEP + "2 blocks/workgroup, XCD-contiguous]<", ODD),      # cliff: off the grid beyond 98304 lanes
     (49152, SWEEP + "1 block/workgroup]<", None),
     (32768, SWEEP + "1 block/workgroup]<", None),                       # several frames per segment
-    (32769, "stream_frame_major_staged[64 lanes/wave]<", ODD),          # cliff
+    (32769, SWEEP + "1 block/workgroup, XCD-contiguous]<", ODD),        # cliff: rows off the grid, several frames per segment up to 53248 lanes
     (24576, SWEEP + "1 block/workgroup]<", None),
     (24560, "stream_frame_major_staged[32 lanes/wave]<", None),         # below kSweepMinLanesFps
     (16384, "stream_frame_major_staged[32 lanes/wave]<", None),

@@ -75,10 +75,12 @@ def test_lane_block_of_a_wider_tensor_in_place(gpu):
     assert kernel_of(gpu).startswith("stream_frame_major_staged["), kernel_of(gpu)
     if FORCED_LW is None:
         assert "[32 lanes/wave]" in kernel_of(gpu)
-        # (round 5: from 24576 lanes up rows on the 64-byte grid take the sweep kernel with several frames per segment — fm_sweep.h;
-        # rows off it keep this kernel, 64 lanes per wave)
+        # (round 5: from 24576 lanes up the sweep kernel with several frames per segment — fm_sweep.h — on the 64-byte grid and, up to 53248 lanes,
+        # off it; 64 lanes per wave of this kernel in between)
         run_case(gpu, op, cfg, n, words, dt, rng, 32768, 40, 32772, False)
-        assert "[64 lanes/wave]" in kernel_of(gpu), kernel_of(gpu)
+        assert kernel_of(gpu).startswith("stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<"), kernel_of(gpu)
+        run_case(gpu, op, cfg, n, words, dt, rng, 20480, 40, 20484, False)
+        assert "[32 lanes/wave]" in kernel_of(gpu), kernel_of(gpu)
         run_case(gpu, op, cfg, n, words, dt, rng, 32768, 40, 32768, False)
         assert kernel_of(gpu).startswith("stream_frame_major_sweep[1 block/workgroup]<"), kernel_of(gpu)
         # the 6-section chain: a 4-section pass (COST > 120: staged only around 16384-32768 lanes) and a 2-section pass

@@ -48,7 +48,9 @@ def test_default_dispatch_takes_the_lds_kernel_on_ragged_lane_counts(gpu):
             aligned = (pitch * 4) % 64 == 0 and (off * 4) % 64 == 0
             # (round 5: rows ON the grid take the dense-sweep kernel from 16 frames up — tests/test_gpu_sweep.py; off it, these lane counts
             # (<= 98304: one round of workgroups) keep this kernel, larger ones go to the sweep kernel with the same XCD-contiguous order)
-            want = "stream_frame_major_lds[XCD-contiguous blocks]<" if not aligned else "stream_frame_major_sweep[" if frames >= 16 else "stream_frame_major_lds<"
+            # (... and so do the ones up to 53248 lanes, several frames per segment: dispatch_thresholds.h kSweepOffGridSmallMax)
+            want = ("stream_frame_major_sweep[" if lanes <= 53248 and frames >= 16 else "stream_frame_major_lds[XCD-contiguous blocks]<") if not aligned else \
+                "stream_frame_major_sweep[" if frames >= 16 else "stream_frame_major_lds<"
             assert k.startswith(want), (op, lanes, pitch, off, k)
             assert ("XCD-contiguous" in k.split("<")[0]) == (not aligned), (op, lanes, pitch, off, k)
 

@@ -14,6 +14,9 @@ from tests.test_gpu_ragged_lds_block import kernel_of, lds_cases
 
 pytestmark = pytest.mark.gpu
 ODD = " + stream_frame_major_few (lanes % 4, second stream)"
+# 24576 ... 53248 lanes on rows off the grid (round 5, dispatch_thresholds.h kSweepOffGridSmallMax): the sweep kernel with several frames per segment for 4-byte
+# outputs, the staged kernel for the rest
+SMALL = ("stream_frame_major_sweep[1 block/workgroup, XCD-contiguous]<", "stream_frame_major_staged[64 lanes/wave]<")
 
 
 def test_lane_counts_that_are_not_multiples_of_four(gpu):
@@ -26,7 +29,7 @@ def test_lane_counts_that_are_not_multiples_of_four(gpu):
               (65539, 17, 65543, 3, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (65001, 21, 65001, 0, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (8195, 50, 8195, 0, "stream_frame_major_staged[32 lanes/wave]<"),
-              (32770, 64, 32771, 1, "stream_frame_major_staged[64 lanes/wave]<"),
+              (32770, 64, 32771, 1, SMALL),
               (73731, 24, 73731, 0, "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)<"),
               (131073, 16, 131073, 0, "stream_frame_major_sweep[2 blocks/workgroup, XCD-contiguous]<")]
     for i, (lanes, frames, pitch, off, body) in enumerate(shapes):
@@ -35,7 +38,7 @@ def test_lane_counts_that_are_not_multiples_of_four(gpu):
                 continue
             FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, bool((i + j) & 1), off=off)
             k = kernel_of(gpu)
-            assert k.startswith(body) and k.endswith(ODD), (op, lanes, pitch, off, k)
+            assert k.startswith(body) and k.endswith(ODD), (op, lanes, pitch, off, k)  # (str.startswith takes a tuple of alternatives)
 
 
 def test_whole_pieces_on_rows_off_the_grid(gpu):
@@ -46,7 +49,7 @@ def test_whole_pieces_on_rows_off_the_grid(gpu):
               (65536, 20, 65544, 1, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (65000, 19, 65003, 2, "stream_frame_major_lds[XCD-contiguous blocks]<"),
               (16384, 130, 16387, 0, "stream_frame_major_staged[32 lanes/wave]<"),  # round 4: plain accesses on such rows, 64 from 25600 lanes
-              (28672, 40, 28675, 1, "stream_frame_major_staged[64 lanes/wave]<"),
+              (28672, 40, 28675, 1, SMALL),
               (4096, 257, 4099, 3, "stream_frame_major_staged[16 lanes/wave]<"),
               (69632, 18, 69633, 0, "stream_frame_major_lds + stream_frame_major_staged (remainder, second stream)<")]
     for i, (lanes, frames, pitch, off, want) in enumerate(shapes):
