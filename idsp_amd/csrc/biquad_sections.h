@@ -347,6 +347,7 @@ struct NormalI32 {
 struct NormalF32 {
     static constexpr int SWEEP_LPT = 8;
     static constexpr bool SWEEP_BIG_TWO_BARRIER = true;
+    static constexpr bool SWEEP_UNPACED = true;
     using T = float;
     static constexpr int LDS_RING = 5;   // tools/tune_lds.hip: best worst-case over four output placements
     static constexpr bool LDS_RUN = true;
@@ -443,6 +444,12 @@ template <class Sec, class = void>
 struct SecBigTwoBarrier : std::false_type {};
 template <class Sec>
 struct SecBigTwoBarrier<Sec, std::void_t<decltype(Sec::SWEEP_BIG_TWO_BARRIER)>> : std::integral_constant<bool, Sec::SWEEP_BIG_TWO_BARRIER> {};
+// sections whose full blocks the sweep kernel runs WITHOUT the `s_sleep` pacing although they are cheap: the clamped ones and `Normal` (65536 lanes: f32 DF1 clamp
+// 0.67 of the peak paced, 0.76 unpaced; f32 DF2T clamp 0.69 / 0.75; i32 DF1 clamp 0.73 / 0.75; Normal f32 0.73 / 0.75 — the unclamped ones 0.77-0.80 / 0.76)
+template <class Sec, class = void>
+struct SecUnpaced : std::integral_constant<bool, Sec::kClamp> {};
+template <class Sec>
+struct SecUnpaced<Sec, std::void_t<decltype(Sec::SWEEP_UNPACED)>> : std::integral_constant<bool, Sec::SWEEP_UNPACED || Sec::kClamp> {};
 template <class Sec, class = void>
 struct SecHasTile : std::false_type {};
 template <class Sec>
@@ -459,8 +466,9 @@ struct Chain {
     static constexpr int LDS_RING = N == 1 ? SecRing<Sec>::value : 4;  // N >= 2: tools/tune_lds.hip (worst placement 0.75-0.77 against 0.68 at 8 tiles for N = 2)
     static constexpr bool LDS_RUN = N == 1 && SecRun<Sec>::value;
     static constexpr bool LDS_ELIGIBLE = N <= SecLdsMaxN<Sec>::value;
-    static constexpr int SWEEP_MAX_LPT = N == 1 ? SecSweepLpt<Sec>::value : N == 2 ? 8 : 2;
-    static constexpr bool SWEEP_BIG_TWO_BARRIER = N == 1 && SecBigTwoBarrier<Sec>::value;  // sub-blocks per workgroup on the sweep kernel (fm_sweep.h)
+    static constexpr int SWEEP_MAX_LPT = N == 1 ? SecSweepLpt<Sec>::value : N == 2 ? 8 : 2;  // sub-blocks per workgroup on the sweep kernel (fm_sweep.h)
+    static constexpr bool SWEEP_BIG_TWO_BARRIER = N == 1 && SecBigTwoBarrier<Sec>::value;
+    static constexpr bool SWEEP_UNPACED = SecUnpaced<Sec>::value;
     using Params = ChainParams<typename Sec::Sec, N>;
     uint32_t s[N][Sec::W];
 
@@ -618,6 +626,9 @@ struct ChainByLane {
     // sub-blocks per workgroup on the sweep kernel (fm_sweep.h): every lane carries its own coefficients in registers beside its state
     static constexpr int SWEEP_MAX_LPT = N == 1 ? 8 : 2;
     static constexpr bool SWEEP_BIG_TWO_BARRIER = N == 1 && SecBigTwoBarrier<Sec>::value && std::is_same<typename Sec::T, float>::value;  // (i32 DF1 by lane: one barrier)
+    // never paced: with the coefficient registers the paced schedule is bimodal on some boxes (65536 lanes, i32 DF1 / f32 DF2T by lane: launches of 0.345 and of
+    // 0.41-0.43 ms in one process, median 0.41; unpaced 0.35-0.36 every time; other boxes 0.34 paced)
+    static constexpr bool SWEEP_UNPACED = true;
     using Params = ByLaneParams;
     uint32_t s[N][Sec::W];
     typename Sec::Sec c[N];

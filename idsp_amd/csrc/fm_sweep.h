@@ -53,8 +53,14 @@ constexpr int kSweepT = 8;     // segments per tile
 // and 0.60-0.79 by placement; 2^20 lanes 0.735-0.74 flat (two-barrier unpaced: 0.72-0.75).  CHEAP = COST <= 50: i32 DF1 (with its tile form) and the
 // f32 sections; the dither / wide / multi-section bodies have no slack to sleep in.
 constexpr int kSweepForm = 3, kSweepPace = 4;
+template <class P, class = void>
+struct SweepUnpacedOf : std::false_type {};
 template <class P>
-constexpr bool sweep_cheap() { return P::COST <= 50; }
+struct SweepUnpacedOf<P, std::void_t<decltype(P::SWEEP_UNPACED)>> : std::integral_constant<bool, P::SWEEP_UNPACED> {};
+// processors whose full blocks are bound by memory alone and take the paced schedule (and, on rows off the grid, the split requests): little
+// arithmetic per sample and not declared SWEEP_UNPACED (the clamped sections, `Normal`: biquad_sections.h)
+template <class P>
+constexpr bool sweep_cheap() { return P::COST <= 50 && !SweepUnpacedOf<P>::value; }
 // processors whose full blocks run 8 / 16 blocks per workgroup on the two-barrier schedule (launch_sweep_lpt below)
 template <class P, class = void>
 struct SweepBigTwoBarrierOf : std::false_type {};
@@ -495,7 +501,8 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
     constexpr size_t bytes = sweep_lds_bytes<P>();
     // (IDSP_DIAG=1 IDSP_SWEEP_PACE=1: narrow blocks take the full blocks' schedule too; =2: rows off the grid as well)
     static const size_t pace_more = diag_size("IDSP_SWEEP_PACE", 0);
-    const bool full = (g.bw == unsigned(kFmBlock) || pace_more >= 1) && (!xcdc || pace_more >= 2) && g.fps <= 1;  // full blocks on the 64-byte grid: bound by memory
+    static const bool no_pace = diag_env("IDSP_SWEEP_NO_PACE") != nullptr;  // IDSP_DIAG=1: nothing paced (8 / 16 blocks per workgroup: nothing on two barriers)
+    const bool full = (g.bw == unsigned(kFmBlock) || pace_more >= 1) && (!xcdc || pace_more >= 2) && g.fps <= 1 && !no_pace;  // full blocks on the 64-byte grid: bound by memory
     // Full blocks of the cheap processors up to 4 blocks per workgroup: the paced one-barrier schedule.  8 and 16 blocks per workgroup (a frame is one
     // or two whole tiles, up to sixteen chains per thread): unpaced — the sleep no longer fits the skeleton — and on the plain two-barrier schedule for
     // the processors that declare SWEEP_BIG_TWO_BARRIER (the unclamped i32 DF1, f32 DF2T and `Normal` sections: 2^20 lanes 0.72 / 0.75 / 0.66 against
