@@ -1597,9 +1597,9 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 // rows off the grid: from the lane count up where round 3's XCD-contiguous kernel would walk panels on a persistent grid (131076 dense
                 // lanes 0.56 -> 0.61, 100004 0.58 -> 0.65); below it that kernel is a single round itself and stays (65000 dense lanes 0.745)
                 static const size_t off_grid_min = diag_size("IDSP_SWEEP_OFFGRID_MIN_LANES", kLdsGridCap * size_t(kFmBlock));  // IDSP_DIAG=1
-                // ... and up to kSweepOffGridSmallMax lanes, where the alternative is the staged single-wave kernel (several frames per segment here: 40000 lanes at
+                // ... and, 4-byte outputs, up to kSweepOffGridSmallMax lanes, where the alternative is the staged single-wave kernel (several frames per segment here: 40000 lanes at
                 // pitch + 4 0.51 -> 0.72 of the peak, 32768 0.52 -> 0.61, 49152 0.59 -> 0.69; 57344: 0.69 either way)
-                const bool off_grid_ok = !grid64_only && rows_ok && (lanes > off_grid_min || lanes <= thr::kSweepOffGridSmallMax);
+                const bool off_grid_ok = !grid64_only && rows_ok && (lanes > off_grid_min || (sizeof(typename P::Out) == 4 && lanes <= thr::kSweepOffGridSmallMax));
                 if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || off_grid_ok) && lanes % 4 == 0 && lanes >= sweep_min && frames >= thr::kSweepMinFrames &&
                     sweep_takes<P>(lanes))
                     return launch_sweep<P>(prm, st, x, y, lanes, frames, xl, yl, sp, s);
