@@ -786,7 +786,12 @@ int launch_ring(uint32_t *st, const float *x, float *y, size_t lanes, size_t fra
 #define IDSP_HBF_RING 4
 #endif
         constexpr int RING = IDSP_HBF_RING;
-        constexpr size_t bytes = (size_t(RING) * kSlotW + up4(L::words)) * sizeof(float);
+        // (IDSP_DIAG=1 IDSP_HBF_LDS_PAD=n: n more bytes of LDS per wave — fewer waves per CU, to read the occupancy slope)
+        static const size_t pad = [] {
+            const char *e = diag_env("IDSP_HBF_LDS_PAD");
+            return e ? size_t(strtoul(e, nullptr, 10)) & ~size_t(15) : size_t(0);
+        }();
+        const size_t bytes = (size_t(RING) * kSlotW + up4(L::words)) * sizeof(float) + pad;
         if (ensure_dyn_lds<&hbf_dec_ring_lm<L, RING>>(bytes)) return 2;
         note_kernel("hbf_dec_ring[LaneMajor]", typeid(L).name());
         hipLaunchKernelGGL((hbf_dec_ring_lm<L, RING>), dim3(unsigned(lanes)), dim3(kW), bytes, stream, st, x, y, lanes, frames);
