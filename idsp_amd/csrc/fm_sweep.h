@@ -491,7 +491,7 @@ struct SweepMaxLptOf<P, std::void_t<decltype(P::SWEEP_MAX_LPT)>> {
 };
 // smallest lane count the sweep kernel takes: 49152, or 24576 for 4-byte outputs, where several frames share a segment (`fps`: 32768 lanes 0.69 of
 // the HBM peak against 0.56 on the staged single-wave kernel, 24576 0.52 against 0.50; at 16384 lanes the staged kernel's 36 ns per frame win, 0.46
-// against 0.42 — one computing wave per CU issues a `v_mad_i64_i32` every 10 cycles whatever the schedule)
+// against 0.42 — a `v_mad_i64_i32` occupies its SIMD for 16 cycles per 64-lane wave, five per step: 80 cycles x 4096 steps = 0.137 ms whatever the schedule)
 constexpr size_t kSweepMinLanes = thr::kSweepMinLanes, kSweepMinLanesFps = thr::kSweepMinLanesFps;
 
 template <class P, int LPT>
