@@ -38,6 +38,9 @@ int hbf_wave_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y
 int hbf_wave_int(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
                  bool lane_major, hipStream_t stream);
 // hbf_ring_dec.hip: LDS-DMA ring decimators (0 = launched, 1 = shape not covered, 2 = HIP error)
+// hbf_blk_dec.hip: register-blocked decimators (same return codes)
+int hbf_blk_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
+                bool lane_major, hipStream_t stream);
 int hbf_ring_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
                  bool lane_major, hipStream_t stream);
 
@@ -578,7 +581,12 @@ int launch_hbf(K kernel, const idsp_hbf_cascade_f32 *cfg, bool dec, void *state,
     if (ts >= 0 && reinterpret_cast<uintptr_t>(wide) % 16 == 0 && (lm ? (frames * R) % 4 == 0 : R >= 4)) {
         // decimators: the LDS-DMA ring kernels of hbf_ring.h first (LANE_MAJOR any cascade; FRAME_MAJOR /16 on whole
         // 16-lane groups), then the wave-per-lane kernels of hbf_wave.h
-        static const bool no_ring = diag_env("IDSP_HBF_NO_RING") != nullptr;
+        static const bool no_ring = diag_env("IDSP_HBF_NO_RING") != nullptr, no_blk = diag_env("IDSP_HBF_NO_BLK") != nullptr;
+        if (dec && !no_blk) {
+            const int rb = hbf_blk_dec(ts, cfg->stages, static_cast<uint32_t *>(state), x, y, lanes, frames, lm, as_stream(stream));
+            if (rb == 0) return launch_status();
+            if (rb != 1) return IDSP_EHIP;
+        }
         if (dec && !no_ring) {
             const int rr = hbf_ring_dec(ts, cfg->stages, static_cast<uint32_t *>(state), x, y, lanes, frames, lm, as_stream(stream));
             if (rr == 0) return launch_status();
