@@ -1,14 +1,14 @@
 // hbf_blk.h — half-band decimator cascades (HBF_DEC_CASCADE over HBF_TAPS / HBF_TAPS_98, src/hbf.rs:142-192,385-421),
-// register-blocked: round 6 successor of the slot-wise ring kernels of hbf_ring.h for the shapes it covers.
+// register-blocked: round 6 successor of the slot-wise LaneMajor ring kernel of round 4 (hbf_ring.h keeps the FrameMajor one).
 //
-// Why.  tools/ubench_lds_issue.hip (profiles/r06_ubench_lds_issue.txt) settled what rounds 4 and 5 argued about: LDS and
-// VALU instructions of a CU's waves DO issue side by side (16 packed multiplies + 16 `ds_read_b128` per iteration take
-// as long as the reads alone), an LDS read costs the CU's one LDS pipe time in proportion to its BYTES (b64 1.5, b128
-// 2.8 ticks per wave instruction), and a 4- or 8-byte-misaligned b64 / b128 costs 43 ticks.  Priced that way the ring
-// kernel's round (1024 raw samples of one lane) is 172 LDS ticks x 18 waves per CU against 200 VALU instructions x 4.5
-// waves per SIMD at 2.9 ticks: the LDS pipe, not issue, was the busiest unit, and most of its bytes were re-reads — every
-// thread fetched 20 raw words to produce two stage-0 outputs, and the lowest-rate stages read a 2M-word window per
-// single output.  Here every thread reads a window ONCE for four or eight neighbouring outputs:
+// Why.  tools/ubench_lds_issue.hip (profiles/r06_ubench_lds_issue.txt): LDS and VALU instructions of a CU's waves issue side
+// by side, an LDS read costs the CU's one LDS pipe time in proportion to its BYTES (b64 1.5, b128 2.8 cycles per wave
+// instruction), and a 4- or 8-byte-misaligned b64 / b128 costs 43.  The ring kernel's round (1024 raw samples of one lane) moved
+// about 50 KiB through LDS, most of it re-reads: every thread fetched 20 raw words to produce two stage-0 outputs, and the
+// lowest-rate stages read a 2M-word window per single output.  And the launch is POWER-bound (NOTES round 6: the L2 counters give
+// the same 1.3-1.4 M cycles per launch for the product, for its requests alone and for the ring kernel, at 1.56-1.66 GHz with
+// the arithmetic and 2.18 GHz without; all-zero input makes both kernels equally fast): what buys time is less energy per
+// sample.  Here every thread reads a window ONCE for four or eight neighbouring outputs — 29 KiB of LDS traffic per round:
 //
 //  * stage 0: thread t owns 16 consecutive raw samples (four 16-byte pieces) of the round and reads them plus the M
 //    pieces before them: M + 4 `ds_read_b128` for 8 outputs (ring kernel: 4 (M + 1) for 8).  The whole round (4 KiB) is
@@ -21,24 +21,24 @@
 //    per round waits B = 64 P / pairs-per-round rounds and then produces P outputs per thread from one window of
 //    2M - 1 + P words read as aligned vectors (stage 3 of /16: 13 `ds_read_b128` per 4 outputs where the ring kernel read
 //    23 `ds_read_b64` per single output).  Streams keep their history in front, padded to a multiple of P words so that
-//    both the producer's vector writes and the window reads are aligned (misaligned ones are 15 x slower, see above).
+//    both the producer's vector writes and the window reads are aligned.
 //  * arithmetic as in hbf_ring.h: symmetric sums scalar, tap multiplies and the sequential accumulation packed over pairs
 //    of neighbouring outputs; every IEEE operation and its order per output unchanged (0 ULP against the oracle).
 //  * the last stage's outputs leave as 16 bytes per thread, one contiguous KiB per wave and run.
 //
 // One code path with run-time counts: rounds past the regular ones (the last two: requests reach the end of the row, the
-// last round may be short, partially filled runs are flushed) differ only in the request form (clamped addresses,
-// `vmcnt(0)`), the predicates of the output stores and the roll distances — all wave-uniform scalars.
+// last round may be short, partially filled runs are flushed) differ only in the request form (clamped addresses), the
+// predicates of the output stores and the roll distances — all wave-uniform scalars.
+//
+// Measured and dropped (profiles/r06_exp_hbf_ab_*.jsonl, all bit-exact, A/B in one process on the same buffers): a ring of two
+// rounds (two rounds of lead: 0.886 against 0.873 ms), 8 .. 15 waves per CU (flat within 1.5 %), the four requests spread over
+// stage 0 (LaneMajor: no change), nontemporal output stores (no change), stages 2 / 3 at two outputs per thread (no change);
+// and a FrameMajor form (16 or 2 x 8 lanes per workgroup, two barriers per round instead of four): equal to the ring kernel
+// at best (0.94-0.99 against 0.95-0.96 ms) — its sixteen waves run the stages in lock step at 5.5 cycles per instruction where
+// the LaneMajor waves, free of barriers, reach 2.9 — and removed again (git: 4125bd5).
 #pragma once
 
 #include "hbf_ring.h"
-
-#ifndef IDSP_HBF_BLK_NTSTORE  // 1: the LaneMajor outputs leave as nontemporal stores
-#define IDSP_HBF_BLK_NTSTORE 0
-#endif
-#ifndef IDSP_HBF_BLK_SPREAD  // 1: the four requests of the next round one by one between the stage-0 output pairs; 0: all four before stage 0
-#define IDSP_HBF_BLK_SPREAD 0
-#endif
 
 namespace idsp {
 namespace hbfb {
@@ -60,8 +60,8 @@ static_assert(kOwn == 4, "a thread owns one 64-byte run of the round");
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
 // Cascade geometry.  PM: bit s set = stage s (>= 1) runs at four outputs per thread (runs of 256 pairs), clear = at two (runs
-// of 128 pairs: half the stream space).  LaneMajor: all four; FrameMajor (16 lanes' streams in one workgroup's LDS): stage 1 only.
-constexpr int kPmAll = 0x3e, kPmFirst = 0x02;
+// of 128 pairs: half the stream space).  The product runs all stages at four.
+constexpr int kPmAll = 0x3e;
 template <int TS, int S, int PM>
 struct BLay {
     static constexpr int stages = S;
@@ -262,14 +262,11 @@ struct Cascade {
 };
 
 // stage 0 of a thread's four own pieces: y0[q] = outputs 8 t + 2 q, 8 t + 2 q + 1 from the pieces q .. q + M0 (hbf_ring.h stage0_pair)
-// before(q) runs ahead of pair q: the kernels put one of the next round's four requests there, so that a wave's requests are
-// spread over stage 0 instead of queueing behind one another (and behind the other waves' bursts) at the texture addresser
-template <class L, class Before>
-__device__ __forceinline__ void stage0_own(const v4f *pc, v2f (&y0)[kOwn], Before &&before)
+template <class L>
+__device__ __forceinline__ void stage0_own(const v4f *pc, v2f (&y0)[kOwn])
 {
     static_for<0, kOwn>([&](auto q_) {
         constexpr int q = decltype(q_)::value;
-        before(q_);
         y0[q] = hbfr::stage0_pair<L>(&pc[q]);
     });
 }
@@ -283,8 +280,7 @@ __device__ __forceinline__ constexpr int ring_pos(int g) { return (g >> 6) * 64 
 // LDS: [history M0 pieces][ring 4 KiB][streams].  Round c: wait for its four requests, read M0 + 4 pieces, copy the
 // round's last M0 pieces to the history slots (they are the next round's pieces -M0 .. -1), request round c + 1 into the
 // ring, stage 0, then every stage whose run is complete.
-// RR: rounds the ring holds (1: the next round is requested when this one is in registers; 2: the round after next, two rounds of lead)
-template <class L, int RR>
+template <class L>
 __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *x, float *y, const size_t lanes, const size_t frames)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_blk[];
@@ -293,8 +289,7 @@ __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *
     constexpr int NP = M0 + kOwn;
     const int lid = threadIdx.x;
     const size_t lane = blockIdx.x;
-    static_assert(RR == 1 || RR == 2, "ring of one or two rounds");
-    float *const hist = smem_blk, *const ring = smem_blk + HIST, *const str = ring + RR * kSC;
+    float *const hist = smem_blk, *const ring = smem_blk + HIST, *const str = ring + kSC;
 
     // stage-0 history (even[M0-1] then odd[2 M0-1], oldest first) -> the raw positions -1, -2, ... of the history slots
     {
@@ -306,12 +301,11 @@ __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *
     cs.init(str, lid, st, lanes, lane);
 
     // word offsets (from `hist`) of the pieces 4 t - M0 .. 4 t + 3 of a round
-    int pa[RR][NP];  // [ring half the round sits in]
+    int pa[NP];
 #pragma unroll
     for (int h = 0; h < NP; h++) {
         const int g = 4 * lid - M0 + h;
-#pragma unroll
-        for (int r = 0; r < RR; r++) pa[r][h] = g >= 0 ? HIST + r * kSC + 4 * ring_pos(g) : 4 * (g + M0);
+        pa[h] = g >= 0 ? HIST + 4 * ring_pos(g) : 4 * (g + M0);
     }
 
     const size_t total = frames * size_t(R);  // raw samples of the lane
@@ -323,29 +317,30 @@ __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *
     const uint32_t voff = uint32_t(perm) * 16;
     const size_t rounds = (total + kSC - 1) / kSC;
 
-    // request of KiB k of round c; `fast`: the whole round lies inside the row
-    auto request_k = [&](auto k_, size_t c, bool fast) {
+    // requests of round c; `fast`: the whole round lies inside the row
+    auto request = [&](size_t c, bool fast) {
 #ifndef IDSP_EXP_HBF_NOLOAD
-        constexpr int k = decltype(k_)::value;
-        const uint32_t dst = ring_lds + uint32_t(c % RR) * (kSC * 4);
         if (fast) {
             const float *xc = uniform_ptr(xl + c * kSC);
-            // the instruction offset moves the global AND the LDS address (lds_dma.h)
-            glds16_si<k * 1024>(xc, voff, dst);
+            static_for<0, 4>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                // the instruction offset moves the global AND the LDS address (lds_dma.h)
+                glds16_si<k * 1024>(xc, voff, ring_lds);
+            });
         } else {
-            const size_t pc = c * (kSC / 4) + size_t(64 * k + perm);
-            glds16(xl + (pc < npieces ? pc * 4 : 0), dst + uint32_t(k) * 1024);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const size_t pc = c * (kSC / 4) + size_t(64 * k + perm);
+                glds16(xl + (pc < npieces ? pc * 4 : 0), ring_lds + uint32_t(k) * 1024);
+            }
         }
 #endif
     };
-    auto request = [&](size_t c, bool fast) { static_for<0, 4>([&](auto k_) { request_k(k_, c, fast); }); };
 
     size_t out_done = 0;  // outputs of the lane stored so far
-    // vector-memory operations issued after the requests of the round about to be consumed (q0) and of the one after it (q1):
-    // requests and stores retire in issue order, so "round c has landed" is vmcnt <= q0
-    int q0 = 0, q1 = 0;
+    int pending = 0;      // vector-memory operations issued after the latest requests
 
-#ifdef IDSP_EXP_HBF_PHASES  // where one wave's time goes: wait for data / piece reads / request issue / arithmetic (shader-clock ticks)
+#ifdef IDSP_EXP_HBF_PHASES  // where one wave's time goes: wait for data / piece reads / request issue / arithmetic (shader cycles)
     long long ph[4] = {0, 0, 0, 0}, tp = clock64();
     const long long ph_wall0 = wall_clock64(), ph_clk0 = tp;
 #define IDSP_PH(i) { const long long t_ = clock64(); ph[i] += t_ - tp; tp = t_; }
@@ -353,34 +348,21 @@ __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *
 #define IDSP_PH(i)
 #endif
     request(0, kSC <= total);
-    if (RR == 2 && rounds > 1) {
-        request(1, 2 * kSC <= total);
-        q0 = 4;
-    }
     for (size_t c = 0; c < rounds; c++) {
         const bool last = c + 1 == rounds;
         const int n = last ? int(total - c * kSC) : kSC;  // raw samples of this round
         IDSP_PH(3)
         // "my four requests have landed": they retire in issue order with the stores behind them
-        switch (q0 < 6 ? q0 : 6) {  // a smaller count than needed only waits longer
-            case 0: wait_vmcnt<0>(); break;
-            case 1: wait_vmcnt<1>(); break;
-            case 2: wait_vmcnt<2>(); break;
-            case 3: wait_vmcnt<3>(); break;
-            case 4: wait_vmcnt<4>(); break;
-            case 5: wait_vmcnt<5>(); break;
-            default: wait_vmcnt<6>(); break;
-        }
-        int q2 = 0;  // ... after the requests issued in this round
+        if (pending == 0)
+            wait_vmcnt<0>();
+        else if (pending == 1)
+            wait_vmcnt<1>();
+        else
+            wait_vmcnt<2>();
         IDSP_PH(0)
         v4f pc[NP];
-        if (RR == 1 || (c & 1) == 0) {
 #pragma unroll
-            for (int h = 0; h < NP; h++) pc[h] = *reinterpret_cast<const v4f *>(hist + pa[0][h]);
-        } else {
-#pragma unroll
-            for (int h = 0; h < NP; h++) pc[h] = *reinterpret_cast<const v4f *>(hist + pa[RR - 1][h]);
-        }
+        for (int h = 0; h < NP; h++) pc[h] = *reinterpret_cast<const v4f *>(hist + pa[h]);
         lds_wave_sync();
         IDSP_PH(1)
         if (!last) {
@@ -390,23 +372,15 @@ __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *
                 const int g = 4 * lid + i - (kSC / 4 - M0);
                 if (g >= 0) *reinterpret_cast<v4f *>(hist + 4 * g) = pc[M0 + i];
             }
+            request(c + 1, (c + 2) * kSC <= total);  // into the ring this round's pieces have just left
+            pending = 0;
         }
-        // the requests of round c + RR go into the ring half this round's pieces have just left
-        const bool req = c + RR < rounds, req_fast = (c + RR + 1) * kSC <= total;
-        if (req) q1 += 4;
-#if !IDSP_HBF_BLK_SPREAD
-        if (req) request(c + RR, req_fast);
-#endif
         IDSP_PH(2)
 #ifdef IDSP_EXP_HBF_NOSTAGES
         if (pc[M0].x == 12345.678f) yl[0] = pc[0].y;
 #else
         v2f y0[kOwn];
-        stage0_own<L>(pc, y0, [&](auto k_) {
-#if IDSP_HBF_BLK_SPREAD
-            if (req) request_k(k_, c + RR, req_fast);
-#endif
-        });
+        stage0_own<L>(pc, y0);
         if constexpr (S == 1) {
             const int nv = n / 2, i0 = 8 * lid;
             float *dst = yl + out_done + i0;
@@ -421,50 +395,37 @@ __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *
                 }
             }
             out_done += size_t(nv);
-            q1 += 2, q2 += 2;
+            pending += 2;
         } else {
             cs.round(y0, n, last, [&](auto &ov, int nv) {
                 constexpr int P = L::P(S - 1);
-                const int nv_all = nv;
                 const int i0 = P * lid;
                 float *dst = yl + out_done + i0;
+                out_done += size_t(nv);
+                pending += 1;
 #ifdef IDSP_EXP_HBF_NOSTORE  // timing only: the outputs stay in registers
                 if (ov[0] != 12345.678f) nv = 0;
 #endif
                 if (i0 + P - 1 < nv) {
-#if IDSP_HBF_BLK_NTSTORE
-                    if constexpr (P == 4)
-                        __builtin_nontemporal_store(v4f{ov[0], ov[1], ov[2], ov[3]}, reinterpret_cast<v4f *>(dst));
-                    else
-                        __builtin_nontemporal_store(v2f{ov[0], ov[1]}, reinterpret_cast<v2f *>(dst));
-#else
                     if constexpr (P == 4)
                         *reinterpret_cast<v4f *>(dst) = v4f{ov[0], ov[1], ov[2], ov[3]};
                     else
                         *reinterpret_cast<v2f *>(dst) = v2f{ov[0], ov[1]};
-#endif
                 } else {
 #pragma unroll
                     for (int p = 0; p < P; p++)
                         if (i0 + p < nv) dst[p] = ov[p];
                 }
-                out_done += size_t(nv_all);
-                q1 += 1, q2 += 1;
             });
         }
 #endif
-        if (RR == 1)
-            q0 = q2;
-        else
-            q0 = q1, q1 = q2;
     }
     lds_wave_sync();
     // state: the last raw samples of the row (stage 0) and the stream histories (stages >= 1)
     {
         constexpr int He = L::He(0), Ho = L::Ho(0);
         const int n = int(total - (rounds - 1) * kSC);
-        const int half = int((rounds - 1) % RR) * kSC;  // the ring half the last round sits in
-        auto raw_word = [&](int r) { return r >= 0 ? HIST + half + 4 * ring_pos(r >> 2) + (r & 3) : HIST + r; };
+        auto raw_word = [&](int r) { return r >= 0 ? HIST + 4 * ring_pos(r >> 2) + (r & 3) : HIST + r; };
         if (lid < He) st[size_t(lid) * lanes + lane] = __float_as_uint(hist[raw_word(n + 2 * (lid - He))]);
         if (lid < Ho) st[size_t(He + lid) * lanes + lane] = __float_as_uint(hist[raw_word(n + 2 * (lid - Ho) + 1)]);
     }
@@ -477,211 +438,34 @@ __global__ __launch_bounds__(kW) void hbf_dec_blk_lm(uint32_t *st, const float *
 #endif
 }
 
-// ============================================================================================== FRAME_MAJOR
-// x[(f*lanes + lane)*16 + k], y[f*lanes + lane]; /16 cascades (64-byte frames), 16 lanes = 16 waves per workgroup.
-// LDS: [65 rows x kFmPitch][16 x streams][tile 128 x 17].  Row r (0 .. 63) = frame r of the round, all 16 lanes: ONE request
-// (wave r % 16 issues it) moves that KiB of contiguous global memory; row -1 = the previous round's last frame.  Thread t of
-// wave w owns frame t of lane w: the four pieces at row t, column w, with the pieces of row t - 1 as history.  Rows are
-// padded by 16 bytes so that the 16 threads of a `ds_read_b128` group — one piece of 16 different rows — fall into 16
-// different bank quartets.
-// Round c: wait for the own requests, barrier A (every row has landed), store the output tile if the last stage filled it
-// in the round before, read the pieces, thread 63 copies its frame to row -1, barrier B (everybody has read: the rows may be
-// overwritten), request round c + 1, then the arithmetic of the whole round with no further barrier.  (The ring kernel had
-// four barriers per round and one slot of lead; NOTES round 4: the barriers alone were 14 %.)
-// NL = 16 or 8 lanes per workgroup.  8: a request moves a 512-byte row (the low 32 lanes of the instruction), a workgroup is 8 waves
-// and 76 KiB of LDS, so two of them share a CU and one computes while the other is in its barriers / piece reads / waits; y leaves as
-// 32-byte pieces.
-constexpr int kFmRows = kSC / 16;             // frames per round
-
-template <class L, int NL>
-__global__ __launch_bounds__(NL *kW) void hbf_dec_blk_fm(uint32_t *st, const float *x, float *y, const size_t lanes, const size_t frames)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem_blk_fm[];
-    constexpr int S = L::stages, R = L::rate, M0 = L::M(0);
-    static_assert(R == 16 && M0 <= 4 && S == 4, "64-byte frames whose stage-0 history fits the previous frame");
-    static_assert(NL == 16 || NL == 8, "lanes per workgroup");
-    constexpr int kFmLanes = NL, kFmPitch = NL * 16 + 4 /* words per row */, kFmTilePitch = NL + 1 /* conflict-free column writes */;
-    constexpr int RQ = kFmRows / NL;  // requests per wave and round
-    constexpr int NP = M0 + kOwn, PL = L::P(S - 1), TROWS = L::L(S - 1);
-    const int lid = threadIdx.x % kW, w = __builtin_amdgcn_readfirstlane(threadIdx.x / kW);
-    const size_t ngroups = lanes / kFmLanes, per = (ngroups + 7) / 8;
-    const size_t group = (blockIdx.x % 8) * per + blockIdx.x / 8;  // every XCD a contiguous eighth of the lane groups
-    if (group >= ngroups) return;
-    const size_t lane0 = group * kFmLanes, lane = lane0 + w;
-    float *const rows = smem_blk_fm + kFmPitch;  // row 0
-    float *const str = smem_blk_fm + (kFmRows + 1) * kFmPitch + w * up4(L::words);
-    float *const tile = smem_blk_fm + (kFmRows + 1) * kFmPitch + kFmLanes * up4(L::words);
-
-    // word (from `rows`) of raw sample r of this lane, r relative to the round's first sample; negative: the frame before
-    auto raw_word = [&](int r) { return (r >> 4) * kFmPitch + w * 16 + (r & 15); };
-    {
-        constexpr int He = L::He(0), Ho = L::Ho(0);
-        if (lid < He) rows[raw_word(2 * (lid - He))] = __uint_as_float(st[size_t(lid) * lanes + lane]);
-        if (lid < Ho) rows[raw_word(2 * (lid - Ho) + 1)] = __uint_as_float(st[size_t(He + lid) * lanes + lane]);
-    }
-    Cascade<L> cs;
-    cs.init(str, lid, st, lanes, lane);
-
-    int pa[NP];  // words from `rows`: the last M0 pieces of row t - 1, then the four of row t
-#pragma unroll
-    for (int h = 0; h < NP; h++) pa[h] = (h < M0 ? (lid - 1) * kFmPitch + 4 * (4 - M0 + h) : lid * kFmPitch + 4 * (h - M0)) + w * 16;
-
-    const uint32_t rows_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)rows;
-    const uint32_t voff = uint32_t(lid) * 16;
-    const size_t fpitch = lanes * size_t(R);  // floats per frame row
-    const size_t rounds = (frames + kFmRows - 1) / kFmRows;
-    // wave w requests the rows w, w + NL, w + 2 NL, ... of round c (k = 0 .. RQ - 1); frames past the end -> frame 0
-    auto request_k = [&](int k, size_t c, bool fast) {
-#ifndef IDSP_EXP_HBF_NOLOAD
-        const size_t f = c * kFmRows + size_t(NL * k + w);
-        const float *src = uniform_ptr(x + (fast || f < frames ? f : 0) * fpitch + lane0 * R);
-        if (NL == 16 || lid < NL * 4) glds16_s(src, voff, rows_lds + uint32_t((NL * k + w) * kFmPitch * 4));
-#endif
-    };
-    auto request = [&](size_t c, bool fast) {
-#pragma unroll
-        for (int k = 0; k < RQ; k++) request_k(k, c, fast);
-    };
-    // the last stage's run in the tile: wave w stores the frames RPW w .. RPW w + RPW - 1 as 4 NL-byte pieces
-    int tile_nv = 0;
-    size_t tile_base = 0, out_done = 0;
-    auto store_tile = [&]() {
-        constexpr int RPW = TROWS / kFmLanes, PPR = NL / 4;  // rows per wave, 16-byte pieces per row
-        static_assert(RPW * PPR <= kW, "one piece per thread");
-        if (lid < RPW * PPR) {
-            const int r = RPW * w + lid / PPR, j = lid % PPR;
-            if (r < tile_nv) {
-                const float *t = tile + r * kFmTilePitch + 4 * j;
-                *reinterpret_cast<v4f *>(y + (tile_base + size_t(r)) * lanes + lane0 + 4 * j) = v4f{t[0], t[1], t[2], t[3]};
-            }
-        }
-        tile_nv = 0;
-    };
-
-#ifdef IDSP_EXP_HBF_PHASES
-    long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = clock64();
-    const long long ph_wall0 = wall_clock64(), ph_clk0 = tp;
-#endif
-    request(0, kFmRows <= frames);
-    for (size_t c = 0; c < rounds; c++) {
-        const bool last = c + 1 == rounds;
-        const int n = last ? int((frames - c * kFmRows) * R) : kSC;  // raw samples of this round
-        IDSP_PH(5)
-        wait_vmcnt<0>();
-        IDSP_PH(0)
-        lds_barrier();  // A
-        IDSP_PH(1)
-        if (tile_nv > 0) store_tile();
-        v4f pc[NP];
-#pragma unroll
-        for (int h = 0; h < NP; h++) pc[h] = *reinterpret_cast<const v4f *>(rows + pa[h]);
-        lds_wave_sync();
-        if (!last && lid == kW - 1) {
-#pragma unroll
-            for (int h = 0; h < M0; h++) *reinterpret_cast<v4f *>(rows - kFmPitch + w * 16 + 4 * (4 - M0 + h)) = pc[kOwn + h];
-        }
-        IDSP_PH(2)
-        lds_barrier();  // B
-        IDSP_PH(3)
-        const bool req_fast = (c + 2) * kFmRows <= frames;
-#if !IDSP_HBF_BLK_SPREAD
-        if (!last) request(c + 1, req_fast);
-#endif
-        IDSP_PH(4)
-#ifdef IDSP_EXP_HBF_NOSTAGES
-        if (pc[M0].x == 12345.678f) y[0] = pc[0].y;
-#else
-        v2f y0[kOwn];
-        stage0_own<L>(pc, y0, [&](auto k_) {
-#if IDSP_HBF_BLK_SPREAD
-            if (!last) {
-#pragma unroll
-                for (int k = 0; k < RQ / 4; k++) request_k(decltype(k_)::value * (RQ / 4) + k, c + 1, req_fast);
-            }
-#endif
-        });
-        cs.round(y0, n, last, [&](auto &ov, int nv) {
-#pragma unroll
-            for (int p = 0; p < PL; p++) tile[(PL * lid + p) * kFmTilePitch + w] = ov[p];
-            tile_nv = nv, tile_base = out_done;
-            out_done += size_t(nv);
-        });
-#endif
-    }
-    lds_barrier();  // every wave's column of the last tile
-    if (tile_nv > 0) store_tile();
-    {
-        constexpr int He = L::He(0), Ho = L::Ho(0);
-        const int n = int((frames - (rounds - 1) * kFmRows) * R);
-        if (lid < He) st[size_t(lid) * lanes + lane] = __float_as_uint(rows[raw_word(n + 2 * (lid - He))]);
-        if (lid < Ho) st[size_t(He + lid) * lanes + lane] = __float_as_uint(rows[raw_word(n + 2 * (lid - Ho) + 1)]);
-    }
-    cs.store_state(st, lanes, lane);
-#ifdef IDSP_EXP_HBF_PHASES
-    IDSP_PH(5)
-    if (lid == 0 && (w == 0 || w == NL / 2 - 1 || w == NL - 1) && (group == 0 || group + 1 == ngroups))
-        printf("phases fm group %d wave %d: wait %lld  barrier A %lld  tile + pieces %lld  barrier B %lld  requests %lld  stages %lld ticks; %lld ticks in %lld x 10 ns\n",
-               int(group), w, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], clock64() - ph_clk0, wall_clock64() - ph_wall0);
-#endif
-}
-
 // -------------------------------------------------------------------------------------------------------- host
-#ifndef IDSP_HBF_BLK_PM
+#ifndef IDSP_HBF_BLK_PM  // experiment knob: which stages run at four outputs per thread (tools/exp_hbf_blk.sh)
 #define IDSP_HBF_BLK_PM kPmAll
-#endif
-#ifndef IDSP_HBF_BLK_RR
-#define IDSP_HBF_BLK_RR 1
-#endif
-#ifndef IDSP_HBF_BLK_PAD  // more bytes of LDS per wave than the kernel uses = fewer waves per CU (LaneMajor)
-#define IDSP_HBF_BLK_PAD 0
-#endif
-#ifndef IDSP_HBF_BLK_FM_LANES
-#define IDSP_HBF_BLK_FM_LANES 16
-#endif
-#ifndef IDSP_HBF_BLK_PM_FM
-#define IDSP_HBF_BLK_PM_FM kPmFirst
 #endif
 template <int TS, int S>
 int launch_blk(uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm, hipStream_t stream)
 {
-    if (lanes > 0x7fffffffu) return 1;
-#ifdef IDSP_HBF_BLK_OFF  // A/B harness: the ring kernels of hbf_ring.h instead
+    if (!lm) return 1;                  // FrameMajor: hbf_ring.h
+    if (lanes > 0x7fffffffu) return 1;  // one workgroup per lane in a 31-bit grid: not covered beyond, as in cic_ring_host.h
+#ifdef IDSP_HBF_BLK_OFF  // A/B harness (tools/exp_hbf_ab.py): the wave kernels of hbf_wave.h instead
     return 1;
 #endif
-    if (lm) {
-        using L = BLay<TS, S, IDSP_HBF_BLK_PM>;
-        // (IDSP_DIAG=1 IDSP_HBF_LDS_PAD=n: n more bytes of LDS per wave — fewer waves per CU, to read the occupancy slope)
-        static const size_t pad = [] {
-            const char *e = diag_env("IDSP_HBF_LDS_PAD");
-            return e ? size_t(strtoul(e, nullptr, 10)) & ~size_t(15) : size_t(0);
-        }();
-        constexpr int RR = IDSP_HBF_BLK_RR;
-        const size_t bytes = (size_t(4 * L::M(0)) + RR * kSC + up4(L::words)) * sizeof(float) + pad + IDSP_HBF_BLK_PAD;
-        if (ensure_dyn_lds<&hbf_dec_blk_lm<L, RR>>(bytes)) return 2;
-        note_kernel("hbf_dec_blk[LaneMajor]", typeid(L).name());
-        hipLaunchKernelGGL((hbf_dec_blk_lm<L, RR>), dim3(unsigned(lanes)), dim3(kW), bytes, stream, st, x, y, lanes, frames);
-        return 0;
-    }
-    if constexpr (S == 4) {
-        using L = BLay<TS, S, IDSP_HBF_BLK_PM_FM>;
-        if constexpr (L::M(0) <= 4) {
-            constexpr int NL = IDSP_HBF_BLK_FM_LANES;
-            if (lanes % NL != 0) return 1;
-            constexpr size_t bytes = (size_t(kFmRows + 1) * (NL * 16 + 4) + size_t(NL) * up4(L::words) + size_t(L::L(S - 1)) * (NL + 1)) * sizeof(float);
-            static_assert(bytes <= 160 * 1024, "one workgroup per CU");
-            if (ensure_dyn_lds<&hbf_dec_blk_fm<L, NL>>(bytes)) return 2;
-            const size_t ngroups = lanes / NL;
-            note_kernel(NL == 16 ? "hbf_dec_blk[FrameMajor]" : "hbf_dec_blk[FrameMajor, 8 lanes per workgroup]", typeid(L).name());
-            hipLaunchKernelGGL((hbf_dec_blk_fm<L, NL>), dim3(unsigned(8 * ((ngroups + 7) / 8))), dim3(NL * kW), bytes, stream, st, x, y, lanes, frames);
-            return 0;
-        }
-    }
-    return 1;
+    using L = BLay<TS, S, IDSP_HBF_BLK_PM>;
+    // (IDSP_DIAG=1 IDSP_HBF_LDS_PAD=n: n more bytes of LDS per wave — fewer waves per CU, to read the occupancy slope)
+    static const size_t pad = [] {
+        const char *e = diag_env("IDSP_HBF_LDS_PAD");
+        return e ? size_t(strtoul(e, nullptr, 10)) & ~size_t(15) : size_t(0);
+    }();
+    const size_t bytes = (size_t(4 * L::M(0)) + kSC + up4(L::words)) * sizeof(float) + pad;
+    if (ensure_dyn_lds<&hbf_dec_blk_lm<L>>(bytes)) return 2;
+    note_kernel("hbf_dec_blk[LaneMajor]", typeid(L).name());
+    hipLaunchKernelGGL((hbf_dec_blk_lm<L>), dim3(unsigned(lanes)), dim3(kW), bytes, stream, st, x, y, lanes, frames);
+    return 0;
 }
 
 }  // namespace hbfb
 
-// Returns 0 when a blocked kernel was launched, 1 when the request is not covered (the caller goes on to hbf_ring.h /
+// Returns 0 when the blocked kernel was launched, 1 when the request is not covered (the caller goes on to hbf_ring.h /
 // hbf_wave.h), 2 on a HIP error (idsp_last_error() holds the text).
 int hbf_blk_dec(int tap_set, int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames,
                 bool lane_major, hipStream_t stream);

@@ -1,6 +1,8 @@
 // hbf_ring.h — half-band decimator cascades (HBF_DEC_CASCADE over HBF_TAPS / HBF_TAPS_98, src/hbf.rs:142-192,385-421)
 // on an LDS-DMA input ring with packed-f32 arithmetic.  Round 4 replacement of hbf_wave.h's decimator kernels for the
-// shapes it covers (they stay as the fallback, and the interpolators stay there).
+// shapes it covers (they stay as the fallback, and the interpolators stay there).  Round 6: the LANE_MAJOR kernel of this
+// file gave way to the register-blocked one of hbf_blk.h (which reuses the stage-0 body from here); the FRAME_MAJOR /16
+// kernel stays (the blocked FrameMajor form measured equal at best, hbf_blk.h).
 //
 // Why: the round-3 kernel was co-limited three ways at C3 (/16, 16384 lanes x 65536 samples) — per 1024 input samples a
 // wave issued ~285 essential f32 VALU operations at the ~4.2 cycles this chip takes per non-packed f32 operation and
@@ -8,8 +10,7 @@
 // 46-word window with 46 `ds_read_b32`), and its input went through 32 VGPRs of double buffer.  Here:
 //
 //  * input: `global_load_lds_dwordx4` into a ring of four 1 KiB slots per lane (one request per wave and slot, three
-//    to four in flight), no VGPR staging.  LANE_MAJOR: every wave streams its own contiguous row.  FRAME_MAJOR (/16):
-//    16 lanes per workgroup; wave w's request moves frame 16 q + w of ALL 16 lanes = 1 KiB of contiguous global memory
+//    to four in flight), no VGPR staging.  FRAME_MAJOR (/16): 16 lanes per workgroup; wave w's request moves frame 16 q + w of ALL 16 lanes = 1 KiB of contiguous global memory
 //    into row 16 q + w of a [64 frames][16 lanes x 64 B + 64 B pad] tile; one LDS barrier per slot hands the rows over.
 //  * stage 0 reads the raw interleaved [even, odd] samples straight from the ring (no split into two streams): thread
 //    t of slot q owns 16-byte piece t (2 outputs) and reads pieces t - M .. t; consecutive threads read consecutive
@@ -393,215 +394,6 @@ struct WaveCascade {
 template <int S>
 constexpr int store_step() { return S == 2 ? kSlots - 1 : S - 3; }
 
-// =============================================================================================== LANE_MAJOR
-// x[(lane*frames + f)*R + k], y[lane*frames + f].  One wave per lane, no barriers.
-// LDS: [ring RING x 1 KiB][streams].  The data of slot step g = 4 c + q (round c, step q) lives in ring slot g % RING.
-// Step g: wait for its request, read the pieces (its slot and the tail of the slot before), request the data of step
-// g - 1 + RING into the slot before — its last reader has just finished — then stage 0 and the stages scheduled
-// behind this step.  A request is issued RING - 1 steps before it is needed; younger than it when its wait comes: the
-// RING - 2 requests in between and the stores of those RING - 1 steps.
-// RING = 4: 18 waves per CU with three requests each in flight; RING = 8: 12 waves with seven (the wave count is LDS-bound).
-template <class L, int RING>
-__global__ __launch_bounds__(kW) void hbf_dec_ring_lm(uint32_t *st, const float *x, float *y, const size_t lanes,
-                                                       const size_t frames)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem_lm[];
-    using WC = WaveCascade<L>;
-    static_assert(RING == 4 || RING == 8, "ring of one or two rounds");
-    constexpr int S = L::stages, R = L::rate, M0 = L::M(0);
-    constexpr int NOUT = kSC / R;          // outputs per round
-    constexpr int RW = RING * kSlotW;      // ring words
-    constexpr int LEAD = RING / kSlots;    // rounds of settled queue a FAST round needs on either side
-    const int lid = threadIdx.x;
-    const size_t lane = blockIdx.x;
-#ifdef IDSP_EXP_HBF_CLK
-    const long long clk_s0 = clock64(), clk_r0 = wall_clock64();  // shader-clock cycles against the 100 MHz counter
-#endif
-    float *ring = smem_lm, *str = smem_lm + RW;
-    WC wc;
-    wc.init(str, lid);
-
-    // stage-0 history -> the ring's tail (raw positions -1, -2, ... wrap to the end of the last slot)
-    {
-        constexpr int He = L::He(0), Ho = L::Ho(0);
-        if (lid < He) ring[RW + 2 * (lid - He)] = __uint_as_float(st[size_t(lid) * lanes + lane]);
-        if (lid < Ho) ring[RW + 2 * (lid - Ho) + 1] = __uint_as_float(st[size_t(He + lid) * lanes + lane]);
-    }
-    wc.load_state(st, lanes, lane);
-
-    // piece addresses (words): pa[i] = piece t - M0 + i relative to its slot; in ring slot 0 the negative ones wrap
-    int pa[M0 + 1], pa0[M0 + 1];
-#pragma unroll
-    for (int i = 0; i <= M0; i++) {
-        const int g = lid - M0 + i;
-        pa[i] = 4 * g;
-        pa0[i] = 4 * (g < 0 ? g + RW / 4 : g);
-    }
-
-    const size_t total = frames * size_t(R);  // raw samples of the lane
-    const size_t npieces = total / 4;          // whole 16-byte pieces (the dispatcher guarantees total % 4 == 0)
-    const float *xl = x + lane * total;
-    float *yl = y + lane * frames;
-    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)ring;  // LDS byte address of the ring
-    const uint32_t voff = uint32_t(lid) * 16;
-    // SAFE request of slot step g: piece 64 g + t, clamped to piece 0 of the row past the end
-    auto request_safe = [&](size_t g) {
-        const size_t pc = g * (kSlotW / 4) + size_t(lid);
-        const float *src = xl + (pc < npieces ? pc * 4 : 0);
-#ifndef IDSP_EXP_HBF_NOLOAD
-        glds16(src, ring_lds + uint32_t(g % RING) * (kSlotW * 4));
-#endif
-    };
-    const size_t rounds = (total + kSC - 1) / kSC;
-
-    // the last stage s of round `c` (nout outputs; PRED: not a whole round)
-    auto last_stage = [&](auto s_, auto pred_, size_t c, int nout) {
-        constexpr int s = decltype(s_)::value, P = L::P(s), NL = L::N(s);
-        constexpr bool PRED = decltype(pred_)::value;
-        float ov[P];
-        wc.template stage<s>([&](auto p_, float v) { ov[decltype(p_)::value] = v; });
-        const int i0 = P * lid;
-        float *dst = yl + c * NOUT + i0;
-        if constexpr (P == 4) {
-            if (!PRED || i0 + 3 < nout)
-                *reinterpret_cast<v4f *>(dst) = v4f{ov[0], ov[1], ov[2], ov[3]};
-            else
-                for (int p = 0; p < 4; p++)
-                    if (i0 + p < nout) dst[p] = ov[p];
-        } else if constexpr (P == 2) {
-            if (!PRED || i0 + 1 < nout)
-                *reinterpret_cast<v2f *>(dst) = v2f{ov[0], ov[1]};
-            else if (i0 < nout)
-                dst[0] = ov[0];
-        } else {
-            if ((NL >= kW || i0 < NL) && (!PRED || i0 < nout)) dst[0] = ov[0];
-        }
-    };
-    // the stages scheduled behind slot step q of round c (n raw samples; SAFE: n may be short)
-    auto stages_after = [&](auto q_, auto safe_, size_t c, int n) {
-        constexpr int q = decltype(q_)::value;
-        constexpr bool SAFE = decltype(safe_)::value;
-        static_for<1, S>([&](auto s_) {
-            constexpr int s = decltype(s_)::value;
-            if constexpr (WC::step_of(s) == q) {
-                if constexpr (!WC::lagging(s)) {
-                    if constexpr (s + 1 == S)
-                        last_stage(s_, safe_, c, n / R);
-                    else
-                        wc.template stage<s>([](auto, float) {});
-                    wc.template roll<s, !SAFE>(n);
-                } else {
-                    if (c != 0) {  // the previous round: always a whole one
-                        if constexpr (s + 1 == S)
-                            last_stage(s_, std::false_type{}, c - 1, NOUT);
-                        else
-                            wc.template stage<s>([](auto, float) {});
-                        wc.template roll<s, true>(kSC);
-                    }
-                }
-            }
-        });
-    };
-
-    // PAR: which round-sized part of the ring this round's slots are ((c * 4) % RING) / 4
-    auto round = [&](auto safe_, auto par_, size_t c) {
-        constexpr bool SAFE = decltype(safe_)::value;
-        constexpr int PAR = decltype(par_)::value;
-        const bool last = SAFE && c + 1 == rounds;
-        const int n = last ? int(total - c * kSC) : kSC;  // raw samples of this round
-        const float *xc = uniform_ptr(xl + c * kSC);       // the round's 4 KiB (FAST requests)
-        static_for<0, kSlots>([&](auto q_) {
-            constexpr int q = decltype(q_)::value;
-            constexpr int SLOT = PAR * kSlots + q;  // ring slot of this step
-            if constexpr (SAFE) {
-                wait_vmcnt<0>();
-            } else {
-                // stores in the RING - 1 steps before this one: all of them (S = 1); else one per round, and every step of a
-                // round but this one is among those steps RING / 4 times, this one RING / 4 - 1 times
-                constexpr int stores = S == 1 ? RING - 1 : LEAD - (q == store_step<S>() ? 1 : 0);
-                wait_vmcnt<RING - 2 + stores>();
-            }
-            v4f pc[M0 + 1];
-#pragma unroll
-            for (int i = 0; i <= M0; i++) pc[i] = *reinterpret_cast<const v4f *>(ring + (SLOT == 0 ? pa0[i] : pa[i] + SLOT * kSlotW));
-            lds_wave_sync();
-            if constexpr (SAFE) {
-                // stage-0 state of the call = the last raw samples before `n`: take them while the slot before is intact
-                if (last && q == (n - 1) / kSlotW) {
-                    constexpr int He = L::He(0), Ho = L::Ho(0);
-                    const int pos = PAR * kSC + n;
-                    if (lid < He) st[size_t(lid) * lanes + lane] = __float_as_uint(ring[(pos + 2 * (lid - He) + RW) % RW]);
-                    if (lid < Ho) st[size_t(He + lid) * lanes + lane] = __float_as_uint(ring[(pos + 2 * (lid - Ho) + 1 + RW) % RW]);
-                    lds_wave_sync();
-                }
-                request_safe(c * kSlots + q + RING - 1);
-            } else {
-#ifndef IDSP_EXP_HBF_NOLOAD
-                // data of step g = 4 c + q - 1 + RING: slot k = g % 4 of round c + g / 4 ... into ring slot g % RING.  The
-                // instruction offset (k KiB) moves the global AND the LDS address, so M0 carries only the round part.
-                constexpr int G = q - 1 + RING, K = G % kSlots, DR = G / kSlots;          // relative to round c
-                constexpr int TPAR = (PAR + DR) % (RING / kSlots);                      // ring part of the target round
-                glds16_si<K * kSlotW * 4>(xc + DR * kSC, voff, ring_lds + TPAR * kSC * 4);
-#endif
-            }
-#ifdef IDSP_EXP_HBF_NOSTAGES
-            if (pc[M0].x == 12345.678f) yl[0] = pc[0].y;
-#else
-            const v2f y0 = stage0_pair<L>(pc);
-            if constexpr (S == 1) {
-                const int i = q * (kSlotW / 2) + 2 * lid;
-                float *dst = yl + c * NOUT + i;
-                if (!SAFE || i + 1 < n / 2)
-                    *reinterpret_cast<v2f *>(dst) = y0;
-                else if (i < n / 2)
-                    dst[0] = y0.x;
-            } else {
-                wc.template put_stage0_tid<q>(y0);
-            }
-            stages_after(q_, safe_, c, n);
-#endif
-        });
-    };
-    for (int g = 0; g < RING - 1; g++) request_safe(size_t(g));
-    for (size_t c = 0; c < rounds; c++) {
-        // SAFE: the queue behind this round is not the regular one yet (first rounds: the store of "the round before" is
-        // missing), or its requests reach the end of the data
-        const bool safe = c < size_t(LEAD + 1) || c + LEAD + 1 >= rounds;
-        if (RING == 8 && (c & 1)) {
-            if (safe)
-                round(std::true_type{}, std::integral_constant<int, RING == 8 ? 1 : 0>{}, c);
-            else
-                round(std::false_type{}, std::integral_constant<int, RING == 8 ? 1 : 0>{}, c);
-        } else {
-            if (safe)
-                round(std::true_type{}, std::integral_constant<int, 0>{}, c);
-            else
-                round(std::false_type{}, std::integral_constant<int, 0>{}, c);
-        }
-    }
-#ifndef IDSP_EXP_HBF_NOSTAGES
-    // epilogue: the lagging stages of the last round
-    {
-        const int n = int(total - (rounds - 1) * kSC);
-        static_for<2, S>([&](auto s_) {
-            constexpr int s = decltype(s_)::value;
-            if constexpr (s + 1 == S)
-                last_stage(s_, std::true_type{}, rounds - 1, n / R);
-            else
-                wc.template stage<s>([](auto, float) {});
-            wc.template roll<s, false>(n);
-        });
-    }
-#endif
-    lds_wave_sync();
-    wait_vmcnt<0>();  // the requests past the end of the data are still landing: they must not outlive the wave's LDS
-    wc.store_state(st, lanes, lane);
-#ifdef IDSP_EXP_HBF_CLK
-    if (lid == 0 && (lane == 0 || lane == lanes / 2 || lane + 1 == lanes))
-        printf("clk lm lane %d: %lld shader cycles in %lld x 10 ns\n", int(lane), clock64() - clk_s0, wall_clock64() - clk_r0);
-#endif
-}
-
 // ============================================================================================== FRAME_MAJOR
 // x[(f*lanes + lane)*16 + k], y[f*lanes + lane]; /16 cascades (64-byte frames), 16 lanes = 16 waves per workgroup.
 // LDS: [ring 64 rows x kFmPitch][16 x streams][tile 64 x 17].  Ring row 16 q + r = frame r of slot q, all 16 lanes (wave r
@@ -778,25 +570,7 @@ template <int TS, int S>
 int launch_ring(uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm, hipStream_t stream)
 {
     using L = Lay<TS, S>;
-    if (lanes > 0x7fffffffu) return 1;  // one workgroup per lane (LaneMajor) in a 31-bit grid: not covered beyond, as in cic_ring_host.h
-    if (lm) {
-        // ring of 4 slots (18 waves per CU, three requests each in flight); 8 slots (12 waves, seven each) measured slower at C3:
-        // 0.955 against 0.892 ms, the arithmetic alone (no requests) 0.643 against 0.567 — the occupancy matters more than the depth
-#ifndef IDSP_HBF_RING
-#define IDSP_HBF_RING 4
-#endif
-        constexpr int RING = IDSP_HBF_RING;
-        // (IDSP_DIAG=1 IDSP_HBF_LDS_PAD=n: n more bytes of LDS per wave — fewer waves per CU, to read the occupancy slope)
-        static const size_t pad = [] {
-            const char *e = diag_env("IDSP_HBF_LDS_PAD");
-            return e ? size_t(strtoul(e, nullptr, 10)) & ~size_t(15) : size_t(0);
-        }();
-        const size_t bytes = (size_t(RING) * kSlotW + up4(L::words)) * sizeof(float) + pad;
-        if (ensure_dyn_lds<&hbf_dec_ring_lm<L, RING>>(bytes)) return 2;
-        note_kernel("hbf_dec_ring[LaneMajor]", typeid(L).name());
-        hipLaunchKernelGGL((hbf_dec_ring_lm<L, RING>), dim3(unsigned(lanes)), dim3(kW), bytes, stream, st, x, y, lanes, frames);
-        return 0;
-    }
+    if (lm) return 1;  // LaneMajor: the register-blocked kernel of hbf_blk.h (round 6)
     if constexpr (L::rate == 16 && L::M(0) <= 4) {
         if (lanes % kFmLanes != 0) return 1;
         constexpr size_t bytes = size_t(kFmRows) * kFmPitch + (size_t(kFmLanes) * up4(L::words) + size_t(kSC / L::rate) * kFmTilePitch) * sizeof(float);

@@ -1,4 +1,4 @@
-// hbf_ring_dec.hip — instantiates the LDS-DMA ring decimator cascades of hbf_ring.h.
+// hbf_ring_dec.hip — instantiates the LDS-DMA ring decimator cascades of hbf_ring.h (FrameMajor /16).
 #include "hbf_ring.h"
 
 namespace idsp {
@@ -6,14 +6,7 @@ namespace {
 template <int TS>
 int launch_s(int stages, uint32_t *st, const float *x, float *y, size_t lanes, size_t frames, bool lm, hipStream_t stream)
 {
-    switch (stages) {
-        case 1: return hbfr::launch_ring<TS, 1>(st, x, y, lanes, frames, lm, stream);
-        case 2: return hbfr::launch_ring<TS, 2>(st, x, y, lanes, frames, lm, stream);
-        case 3: return hbfr::launch_ring<TS, 3>(st, x, y, lanes, frames, lm, stream);
-        case 4: return hbfr::launch_ring<TS, 4>(st, x, y, lanes, frames, lm, stream);
-        case 5: return hbfr::launch_ring<TS, 5>(st, x, y, lanes, frames, lm, stream);
-        default: return 1;
-    }
+    return stages == 4 ? hbfr::launch_ring<TS, 4>(st, x, y, lanes, frames, lm, stream) : 1;
 }
 }  // namespace
 

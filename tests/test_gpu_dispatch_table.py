@@ -98,7 +98,7 @@ def test_c3_and_c4(gpu):
     assert gpu.fn["hbf_dec_cascade"](0, 4, C.byref(cfgs)) == 0
     words = gpu.fn["hbf_dec_state_words"](C.byref(cfgs))
     lanes, frames = 16384, 128
-    for layout, want in ((FM, "hbf_dec_ring[FrameMajor]"), (LM, "hbf_dec_ring[LaneMajor]")):
+    for layout, want in ((FM, "hbf_dec_ring[FrameMajor]"), (LM, "hbf_dec_blk[LaneMajor]")):
         x = torch.zeros(lanes * frames * 16, dtype=torch.float32, device=DEV)
         y = torch.full((lanes * frames,), 3.0, dtype=torch.float32, device=DEV)
         st = torch.zeros((words, lanes), dtype=torch.int32, device=DEV)

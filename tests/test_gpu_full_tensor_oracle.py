@@ -71,7 +71,7 @@ def test_c3_every_output_against_the_oracle(gpu):
     got = yd.cpu().numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(H.ulp_diff_f32(got, want).max())
     assert np.array_equal(sd.cpu().numpy().view(np.uint32), st)
-    assert gpu.fn["last_kernel"]().decode().startswith("hbf_dec_ring")
+    assert gpu.fn["last_kernel"]().decode().startswith("hbf_dec_blk[LaneMajor]")
     # the same tensor FRAME_MAJOR ([frame][lane][R] chunks): every output again
     xf = xd.view(lanes, frames, R).permute(1, 0, 2).contiguous()
     del xd

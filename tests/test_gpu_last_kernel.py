@@ -35,7 +35,7 @@ def test_every_family_reports_its_kernel(gpu):
     xf = torch.zeros(lanes * 16 * 16, dtype=torch.float32, device=DEV)
     yf = torch.empty(lanes * 16, dtype=torch.float32, device=DEV)
     sth = torch.zeros((118, lanes), dtype=torch.int32, device=DEV)
-    assert gpu.cfgcall("hbf_dec_f32", hc, sth, xf, yf, lanes, 16, H.LM) == 0 and name().startswith("hbf_dec_ring[LaneMajor]<")
+    assert gpu.cfgcall("hbf_dec_f32", hc, sth, xf, yf, lanes, 16, H.LM) == 0 and name().startswith("hbf_dec_blk[LaneMajor]<")
     assert gpu.cfgcall("hbf_dec_f32", hc, sth, xf, yf, lanes, 16, H.FM) == 0 and name().startswith("hbf_dec_ring[FrameMajor]<")
     hc.taps[0][0] += 1e-3  # not a built-in tap set any more
     assert gpu.cfgcall("hbf_dec_f32", hc, sth, xf, yf, lanes, 16, H.LM) == 0 and name().startswith("hbf_dec_kernel (generic")

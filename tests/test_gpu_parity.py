@@ -298,7 +298,9 @@ def hbf_shapes(stages):
             (4, 1), (4, ch + 3), (8, 130), (12, 2 * ch + 5), (20, 70),  # whole 4-lane workgroups: FM block kernel
             # whole 16-lane groups: the FM ring kernel (/16); rounds of 1024 input samples: one, ragged, the first / last two (SAFE) and FAST ones
             (64, 3 * (1024 >> stages) + 1), (16, 1), (16, (1024 >> stages) - 1), (48, 2 * (1024 >> stages) + 5), (16, 7 * (1024 >> stages) + 3),
-            (3, 9 * (1024 >> stages)), (2, 6 * (1024 >> stages) + 4)]  # LM ring kernel through FAST rounds
+            # LM blocked kernel (hbf_blk.h): stage s >= 2 runs every 2^(s-1) rounds of 1024 input samples — whole runs, a flushed
+            # partial run behind them, two runs of the deepest stage (/32: 8 rounds) and a ragged tail
+            (3, 9 * (1024 >> stages)), (2, 6 * (1024 >> stages) + 4), (2, 17 * (1024 >> stages) + 2)]
 
 
 @pytest.mark.parametrize("tap_set,stages", [(c[1], c[2]) for c in HBF_CASES])

@@ -6,7 +6,7 @@
 #   bash tools/exp_hbf_blk.sh build ; gpurun -- 'bash tools/exp_hbf_blk.sh run'
 set -u
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
-VARIANTS=${VARIANTS:-"NOSTAGES:-DIDSP_EXP_HBF_NOSTAGES NOLOAD:-DIDSP_EXP_HBF_NOLOAD PM0a:-DIDSP_HBF_BLK_PM=0x0a PM02:-DIDSP_HBF_BLK_PM=0x02 PHASES:-DIDSP_EXP_HBF_PHASES"}
+VARIANTS=${VARIANTS:-"NOSTAGES:-DIDSP_EXP_HBF_NOSTAGES NOLOAD:-DIDSP_EXP_HBF_NOLOAD NOSTORE:-DIDSP_EXP_HBF_NOSTORE PHASES:-DIDSP_EXP_HBF_PHASES PM0a:-DIDSP_HBF_BLK_PM=0x0a PM02:-DIDSP_HBF_BLK_PM=0x02 WAVE:-DIDSP_HBF_BLK_OFF"}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero -fwrapv -Wall -Wno-unused-function -Wno-pass-failed -Iinclude"
 D=build/exp_hbf_blk
 if [ "${1:-run}" = build ]; then

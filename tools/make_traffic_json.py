@@ -15,7 +15,7 @@ RUNS = {
     "c5": ("c5", "stream_frame_major_sweep[", "python bench.py --config c5 --no-cpu --steps 20 --warmup 5"),
     "c5_inplace": ("c5_inplace", "stream_frame_major_sweep[", "python bench.py --config c5 --inplace --no-cpu --steps 20 --warmup 5"),
     "c3": ("c3", "hbf_dec_ring[FrameMajor]", "python bench.py --config c3 --no-cpu --steps 20 --warmup 5"),
-    "c3_lanemajor": ("c3_lane", "hbf_dec_ring[LaneMajor]", "python bench.py --config c3 --layout lane --no-cpu --steps 20 --warmup 5"),
+    "c3_lanemajor": ("c3_lane", "hbf_dec_blk[LaneMajor]", "python bench.py --config c3 --layout lane --no-cpu --steps 20 --warmup 5"),
     "c4": ("c4", "lockin_waves_kernel", "python bench.py --config c4 --no-cpu --steps 20 --warmup 5"),
     "c4_lanemajor": ("c4_lane", "lockin_waves_kernel", "python bench.py --config c4 --layout lane --no-cpu --steps 20 --warmup 5"),
 }
