@@ -312,6 +312,7 @@ class HipEngine:
         torch.cuda.set_device(local_rank % n)
         return local_rank % n, n
 
+    GUARD = True  # rank_main runs tools/perf_guard.py behind the configurations (GPU only)
     INPLACE = True  # this engine runs the `y == x` sub-objects (SplitInplace::inplace, dsp-process/src/process.rs:135-142)
 
     def __init__(self, cfg_name: str, cfg: dict, lane_lo: int, lanes: int, frames: int, layout: str, rank: int,
@@ -440,6 +441,24 @@ class HipEngine:
         self.sync()
         return [a.elapsed_time(b) for a, b in ev]
 
+    def copy_rate(self, k: int = 20):
+        """GB/s (read + written bytes) of `idsp_device_copy` over this configuration's own x -> y footprint, same run, same
+        buffers, same stream: what a plain copy reaches on this box ("also report vs measured copy-kernel bandwidth
+        on the box").  y is clobbered: call before verify().  None in place (one buffer) or where y is not x's size."""
+        if self.inplace or self.x.numel() * self.x.element_size() != self.y.numel() * self.y.element_size():
+            return None
+        nbytes = self.x.numel() * self.x.element_size()
+        args = (C.c_void_p(self.y.data_ptr()), C.c_void_p(self.x.data_ptr()), nbytes, C.c_void_p(self.stream.cuda_stream))
+        for _ in range(3):
+            self.call("device_copy", *args)
+        a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        a.record(self.stream)
+        for _ in range(k):
+            self.call("device_copy", *args)
+        b.record(self.stream)
+        self.sync()
+        return 2.0 * nbytes * k / (a.elapsed_time(b) * 1e-3) / 1e9
+
     def verify(self, sample_lanes: int = 0):
         """Zero the state, run one step, return [sum of y's words, sum of the state words] as wrapping i64 —
         a function of (configuration, input) only, whatever was timed before.  With `sample_lanes`, also the
@@ -523,6 +542,20 @@ def host_cpu_budget(affinity_cpus: int):
     return threads, quota
 
 
+def host_cpu_model():
+    """(model name, logical CPUs of the host) from /proc/cpuinfo — SURVEY 8(d): "report nproc, CPU model"."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
 def cpu_baseline(cfg_name: str, cfg: dict, x_host=None, layout: str = "frame", seconds_budget: float = 14.0):
     """Time the CPU oracle (kind "port") on the host cores of this box.
 
@@ -604,8 +637,10 @@ def cpu_baseline(cfg_name: str, cfg: dict, x_host=None, layout: str = "frame", s
                      "parallel_efficiency": round(all_rate / (one_rate * cores), 3), "passes": [all_reps, one_reps]}
     best_layout = max(res, key=lambda k: res[k]["all_cores"])
     best = res[best_layout]
+    cpu_model, nproc = host_cpu_model()
     return {
         "value": best["all_cores"], "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model, "nproc": nproc,
         "host_cpus": affinity_cpus, "cgroup_cpu_quota": quota,
         "single_thread_value": max(res[k]["one_thread"] for k in res),
         "layout_of_value": best_layout, "by_layout": res,
@@ -636,14 +671,31 @@ def committed_traffic(config: str, kernel: str):
         return None, None
 
 
+def committed_issue(config: str, kernel: str):
+    """The second roof of the kernels that are not memory-bound (C3, C4), from the committed SQ / TCC passes of this same command
+    (profiles/bench_<config>_traffic.json, key "issue", written by tools/make_traffic_json.py): how busy the busiest issue unit
+    is — SQ_ACTIVE_INST_{VALU, LDS} x 4 / (SIMDs or CUs) / kernel cycles — and the clock the L2 ran at (TCC_BUSY / duration: these
+    launches are power-bound in clock, profiles/NOTES.md round 6).  From file, like `traffic`; None when the kernel differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"bench_{config}_traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("kernel_prefix") and not kernel.startswith(tj["kernel_prefix"]):
+            return None
+        return tj.get("issue")
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, untimed, kernel, total_lanes, inplace=False):
     samples_all = total_lanes * frames * cfg.get("samples_per_frame", 1)  # (input) samples per step over all ranks
     alg_bytes = algorithmic_bytes(cfg, lanes_rank, frames)
     med = statistics.median(kern_ms) if kern_ms else 0.0
     achieved = alg_bytes / (med * 1e-3) / 1e9 if med > 0 else 0.0
-    traffic, traffic_src = (committed_traffic(cfg_name + ("_inplace" if inplace else "" if args.layout == "frame" else "_lane"), kernel)
-                            if not args.lanes else (None, None))
-    return {
+    file_key = cfg_name + ("_inplace" if inplace else "" if args.layout == "frame" else "_lane")
+    traffic, traffic_src = committed_traffic(file_key, kernel) if not args.lanes else (None, None)
+    issue = committed_issue(file_key, kernel) if not args.lanes else None
+    ms_step = elapsed / max(args.steps, 1) * 1e3
+    line = {
         "metric": cfg["metric"],
         "value": round(samples_all * args.steps / elapsed / 1e6, 1),
         "unit": "Msamples/s",
@@ -670,19 +722,28 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": kernel, "kernel_ms": round(med, 4),
             "kernel_ms_stat": "average launch duration: one HIP-event pair on the launch stream around the K timed launches, / K (rank 0)",
+            # the same bytes over the wall-clock step time (`ms_per_step`, what `value` is built from): launch gaps included
+            "frac_of_ms_per_step": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_step > 0 else None,
             "algorithmic_bytes": alg_bytes,
         },
     }
+    if issue:
+        line["roofline"]["issue"] = issue
+    return line
 
 
 def summary_of(line: dict, head: str) -> dict:
-    """{config: [driver-timed ms per step, roofline fraction of the HIP-event launch average, integrity match]} for the head
-    line and every sub-object — compact (a few hundred characters) and the LAST key of the line."""
+    """{config: [wall-clock ms per step, its roofline fraction, HIP-event ms per launch, its roofline fraction (= roofline.frac),
+    integrity match]} for the head line and every sub-object — every fraction beside the time it was computed from; compact and the
+    LAST key of the line."""
     def entry(o):
         integ = o.get("integrity") or {}
-        return [o["ms_per_step"], o["roofline"]["frac"], integ.get("match")]
+        r = o["roofline"]
+        return [o["ms_per_step"], r.get("frac_of_ms_per_step"), r["kernel_ms"], r["frac"], integ.get("match")]
 
     out = {head: entry(line)}
+    if isinstance(line.get("perf_guard"), dict):
+        out["perf_guard_ok"] = line["perf_guard"].get("ok")
     for name in ("c3", "c4", "c5"):
         if name in line:
             out[name] = entry(line[name])
@@ -765,6 +826,7 @@ def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
     med_us = int(round(statistics.median(per_launch) * 1e3)) if per_launch else 0
+    copy_gbs = engine.copy_rate() if (rank == 0 and hasattr(engine, "copy_rate")) else None
     sample = C5_CPU_LANES if cfg_name == "c5" and world == 1 and lanes_rank > C5_CPU_LANES else 0
     sums = engine.verify(sample)
     y_sum_all = allreduce_checksum(sums[0], device=rdev)  # the 8-byte checksum all-reduce
@@ -774,6 +836,11 @@ def run_config(cfg_name, args, engine_factory, dist, rank, world, local, backend
     a = argparse.Namespace(**{**vars(args), "steps": steps, "warmup": warmup, "settle_ms": settle_ms,
                               "lanes": lanes_override, "frames": frames_override})
     line = report(cfg_name, cfg, a, world, lanes_rank, frames, elapsed_max, kern_ms, untimed, engine.kernel_name(), total_lanes, inplace)
+    if copy_gbs:
+        line["roofline"]["copy_gbs"] = round(copy_gbs, 1)
+        line["roofline"]["copy_note"] = ("idsp_device_copy (16 B per thread, nontemporal, a chunk per workgroup) x -> y of this configuration, 20 launches "
+                                         "between one event pair, same run / buffers / stream; read + written bytes")
+        line["roofline"]["frac_of_copy"] = round(line["roofline"]["achieved"] / copy_gbs, 4)
     if per_launch:
         line["roofline"]["per_launch_ms"] = {"median": round(statistics.median(per_launch), 4), "min": round(min(per_launch), 4),
                                              "launches": len(per_launch), "note": "separate event pair per launch, after the timed region"}
@@ -907,6 +974,25 @@ def rank_main(args, engine_factory=HipEngine):
             line["cpu_baseline"] = cb
         else:
             line["cpu_baseline"] = None
+        if world == 1 and args.config == "c2" and not getattr(args, "no_guard", False) and not (args.lanes or args.frames) and getattr(engine_factory, "GUARD", False):
+            # performance guard (tools/perf_guard.py): the shapes whose rate rides on the paced sweep schedule, against committed floors
+            from tools import perf_guard
+
+            have = {"c2": line["roofline"]["frac"]}
+            if "c5" in line:
+                have["c5"] = line["c5"]["roofline"]["frac"]
+            if "c2" in (line.get("inplace") or {}):
+                have["c2_inplace"] = line["inplace"]["c2"]["roofline"]["frac"]
+            try:
+                line["perf_guard"] = perf_guard.run(have)
+            except Exception as e:  # noqa: BLE001  (the guard must never cost the line)
+                line["perf_guard"] = {"ok": None, "error": repr(e)}
+        head_copy = line["roofline"].get("copy_gbs")
+        if head_copy:
+            # every other configuration against the SAME yardstick: the plain copy of the head line's footprint, measured in this run
+            for o in [line.get(k) for k in ("c3", "c4", "c5")] + list((line.get("lane_major") or {}).values()) + list((line.get("inplace") or {}).values()):
+                if o and "frac_of_copy" not in o["roofline"]:
+                    o["roofline"]["frac_of_head_copy"] = round(o["roofline"]["achieved"] / head_copy, 4)
         line["summary"] = summary_of(line, args.config)  # LAST key: the stored tail of a long line still carries every config
         print(json.dumps(line), flush=True)
     if dist:
@@ -930,6 +1016,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-lane-major", action="store_true", help="skip the LaneMajor sub-objects (C2, C3, C4) of the default run")
     ap.add_argument("--inplace", action="store_true", help="run the configuration itself in place (y == x; profiling runs of the in-place mode)")
     ap.add_argument("--no-inplace", action="store_true", help="skip the in-place (y == x) sub-objects (C2, C5) of the default run")
+    ap.add_argument("--no-guard", action="store_true", help="skip the perf_guard object (tools/perf_guard.py) of the default run")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 (HbfDec /16) sub-object of the default run")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (lock-in) sub-object of the default run")
     ap.add_argument("--c5-lanes", type=int, default=0, help="total lanes of the C5 sub-object (diagnostics; default 2^20)")

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3  # IDSP_ABI_VERSION of include/idsp_hip.h
+ABI_VERSION = 4  # IDSP_ABI_VERSION of include/idsp_hip.h
 
 IDSP_OK = 0
 IDSP_EINVAL = -1
@@ -273,6 +273,7 @@ UTILS = {
     "device_memset": (_I, [_P, _I, _SZ, _P]),
     "device_h2d": (_I, [_P, _P, _SZ, _P]),
     "device_d2h": (_I, [_P, _P, _SZ, _P]),
+    "device_copy": (_I, [_P, _P, _SZ, _P]),
     "stream_sync": (_I, [_P]),
     "device_sync": (_I, []),
     # single-process lane split over several devices

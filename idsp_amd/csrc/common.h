@@ -110,6 +110,8 @@ inline SideStream *side_stream(hipStream_t caller)
 void note_kernel(const char *kernel, const char *detail = nullptr);
 // a second kernel the same call ran beside it (appended to the text; cleared by the next note_kernel())
 void note_kernel_also(const char *also);
+// the name the most recent note_kernel() on this thread recorded (a static string; NULL before the first launch)
+const char *noted_kernel();
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

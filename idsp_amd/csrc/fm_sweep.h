@@ -519,7 +519,12 @@ int launch_sweep_lpt(const typename P::Params &prm, uint32_t *st, const typename
         }
     } else if constexpr (SweepBigTwoBarrierOf<P>::value) {
         static const bool xcdc_two = diag_env("IDSP_SWEEP_XCDC_TWO_BARRIER") != nullptr;  // IDSP_DIAG=1: rows off the grid on the two-barrier schedule too
-        if (full || (xcdc_two && g.bw == unsigned(kFmBlock) && g.fps <= 1)) {
+        // In place (y == x) with a clone sub-block (a sub-block wholly beyond the data re-requests sub-block 0's rows to keep the request count
+        // static, e.g. 983296 or 1000000 lanes at 16 blocks per workgroup): on the two-barrier schedule the store of tile i goes out while the
+        // clone's request of the same x rows may still be in flight, and nothing orders the two.  Never observed (the request is six tile periods
+        // old by then), but not guaranteed: such launches take the one-barrier schedule below, which waits for the next tile before it stores.
+        const bool clone_in_place = static_cast<const void *>(x) == static_cast<const void *>(y) && size_t(g.grid) * size_t(LPT) * g.bw * g.rounds != lanes;
+        if ((full || (xcdc_two && g.bw == unsigned(kFmBlock) && g.fps <= 1)) && !clone_in_place) {
             if (int rc = ensure_dyn_lds<&stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0>>(bytes)) return rc;
             hipLaunchKernelGGL((stream_frame_major_sweep<P, LPT, kSweepNB, 0, 0>), dim3(g.grid), dim3(kFmBlock), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp, g.bw,
                                g.rounds, g.round_lanes, xcdc, g.fps);

@@ -323,17 +323,26 @@ struct WaveCascade {
     __device__ __forceinline__ void put_stage0_tid(v2f yv) const
     {
         static_assert(S >= 2, "a one-stage cascade stores stage 0 directly");
+        // M0 carries the wave's LDS base here, and in the FrameMajor kernel that base lies above 64 KiB (the streams start behind a
+        // 69632-byte ring): the form relies on the DS add-TID address being M0 + offset + 4 * lane with ALL of M0's bits, as gfx950 does it
+        // (the C3 FrameMajor parity tests compare every output through this path); GFX9-era documents describe M0[15:0] for these
+        // instructions, so any other target takes the plain stores.
+#if !defined(__gfx950__)
+        put_stage0(Q, yv);
+#else
         if constexpr (L::dual(1)) {
             put_stage0(Q, yv);
         } else {
             constexpr int offe = (L::offE(1) + L::He(1) + Q * (kSlotW / 4)) * 4, offo = (L::offO(1) + L::Ho(1) + Q * (kSlotW / 4)) * 4;
             static_assert(offe >= 0 && offo < 65536, "16-bit instruction offsets");
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%4\n\tds_write_addtid_b32 %2 offset:%5\n\ts_mov_b32 m0, %0"
+            // (trailing s_nop: a compiler-placed M0 reader right behind the statement would sit in the s_mov-to-M0 hazard window)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%4\n\tds_write_addtid_b32 %2 offset:%5\n\ts_mov_b32 m0, %0\n\ts_nop 0"
                          : "=&s"(keep)
                          : "v"(yv.x), "v"(yv.y), "s"(__builtin_amdgcn_readfirstlane(str_lds)), "i"(offe), "i"(offo)
                          : "memory");
         }
+#endif
     }
     __device__ __forceinline__ void put_stage0(int q, v2f yv) const
     {

@@ -1556,15 +1556,22 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             // (round 5: only when the whole rounds are 1, 2, 4, 8 or 16 times 65536 lanes — FULL 256-lane blocks on the sweep kernel; three
             // or five rounds would be narrow blocks themselves, and the call is one sweep over all its lanes instead)
             const size_t head_rounds = head / (size_t(256) * kFmBlock);
-            if (head && tail && tail <= kSplitTailMax && (head_rounds & (head_rounds - 1)) == 0 && head_rounds <= 16 && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() && rows_ok &&
+            // ... a restriction of the SWEEP kernel's geometry: a processor it does not take at `head` lanes (SWEEP_MAX_LPT 2 or 4: cascades, chains of
+            // three sections and more) keeps round 3's split for any number of whole rounds (3 x 65536 + 8192 lanes of a 3-section chain: 0.65 against
+            // 0.57 as one launch with a ragged last round, profiles/r03_exp_split_streams.jsonl)
+            bool head_on_sweep = false;
+            if constexpr (LdsEligibleOf<P>::value) head_on_sweep = head != 0 && sweep_takes<P>(head);
+            const bool rounds_ok = !head_on_sweep || ((head_rounds & (head_rounds - 1)) == 0 && head_rounds <= 16);
+            if (head && tail && tail <= kSplitTailMax && rounds_ok && lanes % 4 == 0 && frames >= 16 && LdsEligibleOf<P>::value && !diag_on() && rows_ok &&
                 xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
                 if (SideStream *ss = side_stream(s)) {
                     IDSP_HIP_TRY(hipEventRecord(ss->fork, s));
                     IDSP_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
                     int rc = launch_stream<P>(prm, st, x, y, head, frames, layout, s, Pitch{xl, yl}, sp);
-                    // (rows on the 64-byte grid: the whole rounds went to the dense-sweep kernel, fm_sweep.h)
-                    const bool head_swept = (reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * 4) % 64 == 0 && (yl * 4) % 64 == 0) ||
-                                            head > kLdsGridCap * size_t(kFmBlock);
+                    // which kernel the whole rounds went to: the name that launch recorded (the dense-sweep kernel of fm_sweep.h, or the LDS-DMA
+                    // panel walk for the processors / shapes the sweep does not take)
+                    const char *const head_name = noted_kernel();
+                    const bool head_swept = head_name && std::strncmp(head_name, "stream_frame_major_sweep", 24) == 0;
                     if (rc == IDSP_OK)
                         rc = launch_stream<P>(shift_lanes(prm, head, sizeof(typename P::In)), st + head, x + head, y + head, tail, frames, layout, ss->stream,
                                               Pitch{xl, yl}, sp);

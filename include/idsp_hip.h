@@ -53,10 +53,11 @@ extern "C" {
 
 /* 1: round-1 surface.  2: + the `_pitch` twins, idsp_multi_*, idsp_last_kernel, idsp_device_sync,
  * idsp_multi_last_block; dispatch switches honoured only with IDSP_DIAG=1.  3: + `Lockin<C>` with biquad arms and
- * the external-LO forms (idsp_lockin_*_biquad*, *_lo_*), the f64 half-band / FIR entries.  Versions only ADD symbols:
+ * the external-LO forms (idsp_lockin_*_biquad*, *_lo_*), the f64 half-band / FIR entries.  4: + idsp_device_copy.
+ * Versions only ADD symbols:
  * a host binding refuses a library whose idsp_version() is LOWER than the version it was generated from and accepts
  * any higher one (the rule of idsp_amd/_lib.py, __graft_entry__.py and rust/idsp-hip). */
-#define IDSP_ABI_VERSION 3
+#define IDSP_ABI_VERSION 4
 
 typedef enum idsp_status {
     IDSP_OK = 0,
@@ -104,6 +105,11 @@ int idsp_device_free(void *ptr);
 int idsp_device_memset(void *ptr, int value, size_t bytes, void *stream);
 int idsp_device_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int idsp_device_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+/* Device-to-device copy of non-overlapping buffers by a streaming kernel (16 bytes per thread, nontemporal, one contiguous
+ * chunk per workgroup), asynchronous on `stream`: `copy_from_slice` for a host that owns device buffers, and the yardstick
+ * bench.py prints beside the filter kernels (`copy_gbs`: what a plain copy of the same footprint reaches on this box in the
+ * same run).  Any alignment and size; the bulk moves 16-byte aligned when dst and src are congruent mod 16. */
+int idsp_device_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int idsp_stream_sync(void *stream);
 /* Wait for ALL work of the current device, whatever stream it was launched on (hipDeviceSynchronize) — what a
  * host must call before reading results back on another stream than the one it launched on: the idsp_multi

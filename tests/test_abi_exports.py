@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     fn, lib = load()
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/idsp_hip.h but not exported"
-    assert fn["version"]() == _abi.ABI_VERSION == 3
+    assert fn["version"]() == _abi.ABI_VERSION == 4
     assert isinstance(fn["last_error"](), bytes)
 
 

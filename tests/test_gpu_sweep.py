@@ -53,6 +53,22 @@ def test_default_dispatch_full_size_lane_counts(gpu):
                 assert k.startswith(f"stream_frame_major_sweep[{blocks} block"), (op, lanes, k)
 
 
+def test_in_place_with_clone_sub_blocks_at_16_blocks_per_workgroup(gpu):
+    """983296 lanes = 15 x 65536 + 256: full 256-lane blocks, sixteen per workgroup, and the last workgroups' sixteenth sub-block is a clone
+    of their first (it re-requests those x rows).  With y == x the two-barrier schedule of the unclamped i32 DF1 / f32 DF2T sections would store
+    a tile while the clone's request of the same rows may be in flight (round-5 advice): such launches take the one-barrier schedule.  Every
+    output and the state against the oracle, in place and out of place, several tile periods of frames."""
+    if FORCED:
+        pytest.skip("forced small-shape run")
+    rng = np.random.default_rng(504)
+    for op, cfg, n, words, dt in sweep_cases(rng):
+        if op not in ("biquad_i32_df1", "biquad_f32_df2t") or n != 1:
+            continue
+        for inplace in (True, False):
+            FMS.run_case(gpu, op, cfg, n, words, dt, rng, 983296, 70, 983296, inplace)
+            assert kernel_of(gpu).startswith("stream_frame_major_sweep[16 block"), kernel_of(gpu)
+
+
 def test_lane_counts_a_little_above_whole_rounds_split(gpu):
     """65552 lanes = 65536 on the sweep kernel + 16 beside them on a second stream (lane_stream.h: one sweep of half-empty blocks is
     slower); rows stay on the 64-byte grid."""
