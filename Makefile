@@ -74,7 +74,11 @@ build/test_coeff: tests/cpp/test_coeff.cpp include/idsp_hip.hpp include/idsp_hip
 check-scratch: $(LIB)
 	python3 tools/check_scratch.py --lib $(LIB)
 
+# no kernel may reach memory through flat_* instructions (tools/check_flat.py, round 6)
+check-flat: $(LIB)
+	python3 tools/check_flat.py --lib $(LIB)
+
 clean:
 	rm -f $(HIP_OBJS) $(HIP_OBJS:.o=.d) $(LIB) $(ORACLE) $(ORACLE_NAT)
 
-.PHONY: all lib oracle oracle-native clean check-scratch
+.PHONY: all lib oracle oracle-native clean check-scratch check-flat

@@ -157,6 +157,40 @@ __device__ __forceinline__ T *uniform_ptr(T *q)
     const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(u)), hi = __builtin_amdgcn_readfirstlane(uint32_t(u >> 32));
     return reinterpret_cast<T *>((uint64_t(hi) << 32) | lo);
 }
+// 16-byte global accesses at `wave-uniform base + 32-bit thread offset` in the GLOBAL address space.  A pointer rebuilt from
+// integers (uniform_ptr above) is a generic one, and hipcc then emits `flat_load / flat_store`: those count on lgkmcnt as well
+// as on vmcnt — a 4-bit counter on gfx9, so a wave cannot have more than 15 of them in flight, and every `s_waitcnt lgkmcnt`
+// of its LDS traffic waits for them too (round 6: both staged stream kernels ran on flat accesses).  With the address space
+// named the same access is `global_load_dwordx4 v, v_off, s[base:base+1]`: vmcnt only, no 64-bit VALU address arithmetic.
+template <class V, bool NT>
+__device__ __forceinline__ V global_ld(const void *ubase, uint32_t voff)
+{
+#ifdef IDSP_EXP_FLAT  // A/B: the generic pointer of rounds 2-5 (flat_load)
+    const auto *q = reinterpret_cast<const V *>(uniform_ptr(static_cast<const char *>(ubase)) + size_t(voff));
+#else
+    const auto *g = reinterpret_cast<const __attribute__((address_space(1))) char *>(reinterpret_cast<uintptr_t>(uniform_ptr(static_cast<const char *>(ubase))));
+    const auto *q = reinterpret_cast<const __attribute__((address_space(1))) V *>(g + voff);
+#endif
+    if constexpr (NT)
+        return __builtin_nontemporal_load(q);
+    else
+        return *q;
+}
+template <class V, bool NT>
+__device__ __forceinline__ void global_st(void *ubase, uint32_t voff, V v)
+{
+#ifdef IDSP_EXP_FLAT
+    auto *q = reinterpret_cast<V *>(uniform_ptr(static_cast<char *>(ubase)) + size_t(voff));
+#else
+    auto *g = reinterpret_cast<__attribute__((address_space(1))) char *>(reinterpret_cast<uintptr_t>(uniform_ptr(static_cast<char *>(ubase))));
+    auto *q = reinterpret_cast<__attribute__((address_space(1))) V *>(g + voff);
+#endif
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, q);
+    else
+        *q = v;
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the ABI lets one
 // process switch devices (idsp_device_set), and the attribute is per device.
 // The kernel is a template ARGUMENT (not a function parameter) so that the flag below is one per kernel: kernels of

@@ -143,25 +143,42 @@ __device__ __forceinline__ void to_words(const T &v, uint32_t *w)
 // streamed-once data: nontemporal loads/stores (struct outputs go out as a 2-word vector).
 // NT = false for arithmetic-bound processors, where the longer nontemporal load latency
 // showed up as a slowdown (8-section cascade) instead of a bandwidth gain.
+// (Both name the GLOBAL address space: a pointer rebuilt from a wave-uniform integer base is a generic one otherwise and the access a
+// `flat_*` instruction, which counts on lgkmcnt beside vmcnt — tools/check_flat.py keeps the library free of them.)
+// a 4-, 8- or 16-byte object as a vector of words (class types have no copy operations in a named address space)
+template <int BYTES>
+struct WordsOf;
+template <>
+struct WordsOf<4> {
+    using type = uint32_t;
+};
+template <>
+struct WordsOf<8> {
+    typedef uint32_t type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct WordsOf<16> {
+    typedef uint32_t type __attribute__((ext_vector_type(4)));
+};
 template <bool NT, class T>
 __device__ __forceinline__ T nt_load(const T *p)
 {
+    using W = typename WordsOf<int(sizeof(T))>::type;
+    const auto *g = reinterpret_cast<const __attribute__((address_space(1))) W *>(reinterpret_cast<uintptr_t>(p));
     if constexpr (NT)
-        return __builtin_nontemporal_load(p);
+        return __builtin_bit_cast(T, __builtin_nontemporal_load(g));
     else
-        return *p;
+        return __builtin_bit_cast(T, *g);
 }
 template <bool NT, class T>
 __device__ __forceinline__ void nt_store(T *p, const T &v)
 {
-    if constexpr (!NT) {
-        *p = v;
-    } else if constexpr (sizeof(T) == 4) {
-        __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), reinterpret_cast<uint32_t *>(p));
-    } else {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2 *>(p));
-    }
+    using W = typename WordsOf<int(sizeof(T))>::type;
+    auto *g = reinterpret_cast<__attribute__((address_space(1))) W *>(reinterpret_cast<uintptr_t>(p));
+    if constexpr (NT)
+        __builtin_nontemporal_store(__builtin_bit_cast(W, v), g);
+    else
+        *g = __builtin_bit_cast(W, v);
 }
 
 constexpr int kWave = 64;
@@ -894,7 +911,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
             for (int j = 0; j < NII; j++) {
                 const int pc = mpci ^ (NII % 16 == 0 ? j & 15 : (mqi + j) & 15);  // mqi is a multiple of NII: a constant when 16 | NII
                 if ((decltype(whole)::value || size_t(mqi + j) < nrows) && (decltype(full)::value || pc < nq * IW) && IDSP_EXP_LM_LD_ON)
-                    stage[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + j * xrowb) + size_t(xoff + uint32_t(pc * 16))));
+                    stage[j] = global_ld<u32x4, true>(src + j * xrowb, xoff + uint32_t(pc * 16));
             }
         }
     };
@@ -988,7 +1005,7 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
             const int pc = mpco ^ (NIO % 16 == 0 ? j & 15 : (mqo + j) & 15);
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot_out + j * 1024 + lid * 16);
             if ((decltype(whole)::value || size_t(mqo + j) < nrows) && (decltype(full)::value || pc < nq * OW) && IDSP_EXP_LM_ST_ON)
-                __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(uniform_ptr(dst + j * yrowb) + size_t(yoff + uint32_t(pc * 16))));
+                global_st<u32x4, true>(dst + j * yrowb, yoff + uint32_t(pc * 16), v4);
             if (j % 8 == 7) asm volatile("" ::: "memory");  // at most 8 pieces between LDS and the store (the staged tile holds PI)
         }
     };
@@ -1121,8 +1138,7 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
 #pragma unroll
         for (int j = 0; j < NI; j++)
             if (mine && (decltype(full)::value || j * RPI + mrow < nf))
-                stage[j] = decltype(nt)::value ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(uniform_ptr(src + size_t(j * RPI) * xrowb) + size_t(xoff)))
-                                               : *reinterpret_cast<const u32x4 *>(uniform_ptr(src + size_t(j * RPI) * xrowb) + size_t(xoff));
+                stage[j] = global_ld<u32x4, decltype(nt)::value>(src + size_t(j * RPI) * xrowb, xoff);
     };
     // Rows off the 64-byte grid (xcd_contiguous & 2): the 128-byte lines at both ends of a wave's row piece are shared with the
     // neighbouring waves, and with nontemporal accesses each of the two fetches them from memory and writes its part back alone;
@@ -1191,11 +1207,7 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
         for (int j = 0; j < NI; j++) {
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
             if (mine && (decltype(full)::value || j * RPI + mrow < nf)) {
-                u32x4 *dp = reinterpret_cast<u32x4 *>(uniform_ptr(dst + size_t(j * RPI) * yrowb) + size_t(yoff));
-                if constexpr (decltype(nt)::value)
-                    __builtin_nontemporal_store(v4, dp);
-                else
-                    *dp = v4;
+                global_st<u32x4, decltype(nt)::value>(dst + size_t(j * RPI) * yrowb, yoff, v4);
             }
             if (j % 8 == 7) asm volatile("" ::: "memory");
         }

@@ -30,6 +30,10 @@ ALLOWED = [
     # LaneMajor Cic decimator: a 4-tile register ring that spills 0.6-1.4 KB per thread; rings of 3 or 2 tiles without
     # spills measured slower at 16384 lanes (profiles/NOTES.md §7), left as it is
     (r"cic_dec_lm_kernel", "Cic LaneMajor decimator register ring (measured faster than the spill-free forms)"),
+    # external-LO lock-in with [Lowpass<2>; 4] arms on the LaneMajor staged kernel, 64 lanes per wave (the form from 49152 lanes up, where the
+    # launch is memory-bound): 46 VGPRs spill since the staged kernels' accesses name the global address space (round 6, tools/check_flat.py);
+    # the 32- and 16-lane forms and every other lock-in processor stay in registers
+    (r"stream_lane_major_staged.*LockinLoProcILi2ELi4EEELi64E", "68 B per thread since the staged kernels left flat accesses (round 6)"),
 ]
 
 

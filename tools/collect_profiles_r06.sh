@@ -23,15 +23,16 @@ T="timeout ${PASS_TIMEOUT:-240}"
 SQ2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM"
 run() {  # name, command...
   local n=$1; shift
-  $T rocprofv3 --kernel-trace --stats -d $O/$n/trace -o p -- "$@" > $O/$n.trace.log 2>&1
-  $T rocprofv3 --pmc FETCH_SIZE -d $O/$n/fetch -o p -- "$@" > $O/$n.fetch.log 2>&1
-  $T rocprofv3 --pmc WRITE_SIZE -d $O/$n/write -o p -- "$@" > $O/$n.write.log 2>&1
-  $T rocprofv3 --pmc $SQ -d $O/$n/sq -o p -- "$@" > $O/$n.sq.log 2>&1
-  $T rocprofv3 --pmc $SQ2 -d $O/$n/sq2 -o p -- "$@" > $O/$n.sq2.log 2>&1
-  $T rocprofv3 --pmc $TCC -d $O/$n/tcc -o p -- "$@" > $O/$n.tcc.log 2>&1
-  python tools/rocpd_summary.py stats $(find $O/$n/trace -name '*results.db' | head -1) > $O/${n}_kernel_stats.csv
-  python tools/rocpd_summary.py pmc $(find $O/$n/fetch $O/$n/write $O/$n/sq $O/$n/sq2 $O/$n/tcc -name '*results.db') > $O/${n}_pmc.csv
-  grep -h "^{" $O/$n.trace.log | tail -12 > $O/${n}_lines_under_rocprof.jsonl
+  has() { echo " ${PASSES:-trace fetch write sq sq2 tcc} " | grep -q " $1 "; }  # PASSES="sq tcc": a subset (diagnosis runs)
+  has trace && $T rocprofv3 --kernel-trace --stats -d $O/$n/trace -o p -- "$@" > $O/$n.trace.log 2>&1
+  has fetch && $T rocprofv3 --pmc FETCH_SIZE -d $O/$n/fetch -o p -- "$@" > $O/$n.fetch.log 2>&1
+  has write && $T rocprofv3 --pmc WRITE_SIZE -d $O/$n/write -o p -- "$@" > $O/$n.write.log 2>&1
+  has sq && $T rocprofv3 --pmc $SQ -d $O/$n/sq -o p -- "$@" > $O/$n.sq.log 2>&1
+  has sq2 && $T rocprofv3 --pmc $SQ2 -d $O/$n/sq2 -o p -- "$@" > $O/$n.sq2.log 2>&1
+  has tcc && $T rocprofv3 --pmc $TCC -d $O/$n/tcc -o p -- "$@" > $O/$n.tcc.log 2>&1
+  has trace && python tools/rocpd_summary.py stats $(find $O/$n/trace -name '*results.db' | head -1) > $O/${n}_kernel_stats.csv
+  python tools/rocpd_summary.py pmc $(find $O/$n -name '*results.db' -not -path '*/trace/*') > $O/${n}_pmc.csv
+  has trace && grep -h "^{" $O/$n.trace.log | tail -12 > $O/${n}_lines_under_rocprof.jsonl
   rm -rf $O/$n  # the sqlite databases are large; the summaries are what gets committed
 }
 WHAT=${2:-all}
@@ -51,6 +52,10 @@ want c4 && run c4 python bench.py --config c4 --no-cpu --steps 20 --warmup 5
 want c4lm && run c4_lanemajor python bench.py --config c4 --layout lane --no-cpu --steps 20 --warmup 5
 # the Cic kernels at 16384 lanes x 4096 chunks of 16 (tools/perf_configs.py --only cic: one shape per kernel name)
 want cic && run cic python tools/perf_configs.py --only cic --iters 20
+# SURVEY 8(f) surfaces far below the HBM roof: issue-roof passes (tools/issue_roof.py)
+want readouts && run readouts python tools/perf_configs.py --only readouts --iters 10
+# ... and the small lane counts of the biquads
+want small && run small python tools/perf_configs.py --only ragged --iters 10
 # the LaneMajor fm_disc role kernel at 65536 lanes x 4096 frames
 want fmlm && run fm_disc_lanemajor python tools/perf_configs.py --only fmlm --iters 20
-for n in c2 c2_driverflags c2_inplace c2_lanemajor c5 c5_inplace c5_shard8 c3 c3_lanemajor c4 c4_lanemajor cic fm_disc_lanemajor; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done
+for n in c2 c2_driverflags c2_inplace c2_lanemajor c5 c5_inplace c5_shard8 c3 c3_lanemajor c4 c4_lanemajor cic fm_disc_lanemajor readouts; do [ -f $O/${n}_kernel_stats.csv ] || continue; echo "== $n"; head -4 $O/${n}_kernel_stats.csv | cut -c1-220; grep -E "FETCH_SIZE|WRITE_SIZE" $O/${n}_pmc.csv | head -6 | cut -c1-220; done

@@ -3,7 +3,7 @@
 (profiles/rNN_<run>_pmc.csv, tools/collect_profiles_rNN.sh): HBM bytes per launch of the dominant kernel = FETCH_SIZE x 2
 (gfx950: 128-byte requests tallied at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB.  Round 6: also the second roof
 bench.py prints as `roofline.issue` — how busy the busiest issue unit is, SQ_ACTIVE_INST_{VALU, LDS} (quad-cycles summed over the
-waves) x 4 / (1024 SIMDs resp. 256 CUs) / GRBM_GUI_ACTIVE — and the clock the launch ran at (TCC_BUSY_avr / dispatch duration:
+waves) x 4 / (1024 SIMDs resp. 256 CUs) / (GRBM_GUI_ACTIVE / 8: the counter is summed over the XCDs) — and the clock the launch ran at (TCC_BUSY_avr / dispatch duration:
 the L2 runs on the shader clock, and these launches are power-bound in clock, profiles/NOTES.md round 6).
     python tools/make_traffic_json.py r06"""
 import csv, json, os, sys
@@ -42,12 +42,12 @@ for run, (key, prefix, cmd) in RUNS.items():
     }
     c = {r["counter"]: (float(r["avg_value"]), float(r["avg_dispatch_us"])) for r in allrows if r["kernel"] == fetch["kernel"]}
     if all(k in c for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE")):
-        cyc = c["GRBM_GUI_ACTIVE"][0]
+        cyc = c["GRBM_GUI_ACTIVE"][0] / 8.0  # the counter comes summed over the eight XCDs (C2: 6.61 M for a 342 us launch = 8 x 2.42 GHz)
         valu, lds = c["SQ_ACTIVE_INST_VALU"][0] * 4 / 1024 / cyc, c["SQ_ACTIVE_INST_LDS"][0] * 4 / 256 / cyc
         issue = {
             "unit": "busiest of VALU issue (per SIMD) / LDS issue (per CU)", "busy_frac": round(max(valu, lds), 4),
             "valu_busy_frac": round(valu, 4), "lds_busy_frac": round(lds, 4), "kernel_cycles": int(cyc),
-            "formula": "SQ_ACTIVE_INST_{VALU,LDS} x 4 / (1024 SIMDs | 256 CUs) / GRBM_GUI_ACTIVE",
+            "formula": "SQ_ACTIVE_INST_{VALU,LDS} x 4 / (1024 SIMDs | 256 CUs) / (GRBM_GUI_ACTIVE / 8 XCDs)",
             "source": f"profiles/{tag}_{run}_pmc.csv",
         }
         if "TCC_BUSY_avr" in c:

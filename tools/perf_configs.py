@@ -386,6 +386,10 @@ def main():
             biquad("biquad_i32_df1", torch.int32, 4, lanes, 4096, FM, 1, it, "ragged")
         for lanes in (65000, 65537, 100000):
             biquad("biquad_i32_df1", torch.int32, 4, lanes, 4096, LM, 1, it, "ragged")
+        # the f32 sections at the small lane counts (round 6: where the i32 DF1 sits on one wave's chain of five v_mad_i64_i32)
+        for lanes in (8192, 16384, 32768):
+            biquad("biquad_f32_df1", torch.float32, 4, lanes, 4096, FM, 1, it, "ragged")
+            biquad("biquad_f32_df2t", torch.float32, 2, lanes, 4096, FM, 1, it, "ragged")
     if sel and "lanesweep" in sel:  # where does the one-workgroup-per-block launch lose to the persistent grid? (IDSP_DIAG=1 IDSP_LDS_GRID=0 forces the former)
         for blocks in (256, 288, 320, 352, 384, 416, 448, 480, 512, 576, 640, 768):
             biquad("biquad_i32_df1", torch.int32, 4, blocks * 256, 4096, FM, 1, it, "lanesweep")
@@ -484,6 +488,16 @@ def main():
         dds(65536, 4096, FM, it, "dds")
         cossin(1 << 27, it, "cossin")
         atan2(1 << 27, it, "atan2")
+    if sel and "readouts" in sel:  # SURVEY 8(f) surfaces far below the HBM roof: one shape per kernel (issue-roof passes, tools/issue_roof.py)
+        lockin(2, 2, 32768, 4096, FM, it, "f", "arg")
+        lockin(2, 2, 32768, 4096, FM, it, "f", "iq+atan2")
+        lockin(2, 2, 4096, 4096, FM, it, "f")
+        fm_disc(65536, 4096, LM, it, "f")
+        fm_disc(65536, 4096, FM, it, "f")
+        wdf(65536, 4096, FM, it, "f")
+        biquad("cascade_i32_df1", torch.int32, 4, 65536, 4096, FM, 8, it, "f")
+        biquad("biquad_i32_wide", torch.int32, 6, 65536, 4096, FM, 4, it, "f")
+        hbf("int", 4, 16384, 4096, FM, max(3, it // 3), "f")
     if want("lockinc"):  # `Lockin<C>` with biquad arms at the C4 shape (thread-per-lane stream kernels)
         for layout in (FM, LM):
             lockin_generic("phase", 1, 32768, 4096, layout, it, "C4g")
