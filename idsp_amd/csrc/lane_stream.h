@@ -1246,6 +1246,142 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
     if (active) p.store(prm, st, slanes, lane0 + lid);
 }
 
+// ------------------------------------------- FRAME_MAJOR, few lanes: one wave computes, one wave moves (round 6)
+// Below ~24576 lanes a FrameMajor launch is a race against ONE wave's serial chain: 4096 frames x (39.5 cycles for the i32 DF1
+// step at one wave per SIMD, tools/ubench_df1_step.hip) = 0.069 ms, where stream_frame_major_staged needs 0.139 ms at 16384 lanes
+// and the f32 sections, whose chain is no longer, 0.157: the rest is its skeleton — the same in-order wave issues the tile's 32
+// loads, hands them to LDS, walks its column, re-reads the tile and issues 32 stores — and a section that only copies takes 0.11 ms
+// in it.  Here the two halves run side by side: a workgroup is TWO waves over LW = 32 lanes; wave 1 (the mover) brings tile k + 1 in
+// by `global_load_lds_dwordx4` (8 row pieces of 128 bytes per request, straight into the tile: no staging registers) and takes
+// tile k - 1 out (`ds_read_b128` + 16-byte stores) while wave 0 walks its column of tile k; two 32 KiB tiles, ONE barrier per
+// tile: at barrier k the mover has waited for tile k's requests and the compute wave has finished tile k - 1.  The compute wave's
+// loop holds nothing but LDS reads (two frames per instruction), the processor's steps and LDS writes.
+template <class P>
+__global__ __launch_bounds__(2 * kWave) void stream_frame_major_pair(
+    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
+    const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes)
+{
+    using In = typename P::In;
+    using Out = typename P::Out;
+    static_assert(FmStagedOf<P>::value && sizeof(In) == 4 && sizeof(Out) == 4, "one 4-byte input and output per lane and frame");
+    constexpr int LW = 32;
+    constexpr int RB = LW * 4;                      // bytes of a row piece (one frame of the workgroup's lanes)
+    constexpr int TF = kFmStagedTile / RB;          // frames per tile
+    constexpr int PPR = RB / 16;                    // 16-byte pieces per row piece
+    constexpr int RPI = kWave / PPR;                // rows one instruction covers
+    constexpr int NI = kFmStagedTile / 1024;        // instructions per tile
+    constexpr int NS = 16;                          // frames per compute chunk
+    static_assert(TF % NS == 0 && NI * RPI == TF, "tile shape");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    char *const slots = reinterpret_cast<char *>(smem);       // two tiles
+    uint32_t *ptab = smem + 2 * kFmStagedTile / 4;            // [P::LDS_WORDS]
+    const int lid = threadIdx.x % kWave;
+    const bool mover = __builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave)) != 0;
+    const size_t lane0 = size_t(blockIdx.x) * LW;
+    const size_t nrows = lanes - lane0 < size_t(LW) ? lanes - lane0 : size_t(LW);  // lanes of this workgroup (a multiple of 4)
+    const size_t ntiles = (frames + TF - 1) / TF;
+    const int ntail = int(frames - (ntiles - 1) * TF);  // frames of the last tile (1 .. TF)
+
+    if (mover) {
+        // in instruction j: row j RPI + mrow of the tile, piece mpc of the row piece
+        const size_t xrowb = xl * sizeof(In), yrowb = yl * sizeof(Out);
+        const int mrow = lid / PPR, mpc = lid % PPR;
+        const bool mine = size_t(mpc) * 16 < nrows * sizeof(In);  // this thread's piece lies inside the workgroup's lanes
+        const char *const xbase = reinterpret_cast<const char *>(x) + lane0 * sizeof(In);
+        char *const ybase = reinterpret_cast<char *>(y) + lane0 * sizeof(Out);
+        const uint32_t xoff = uint32_t(mrow) * uint32_t(xrowb) + uint32_t(mpc) * 16, yoff = uint32_t(mrow) * uint32_t(yrowb) + uint32_t(mpc) * 16;
+        const uint32_t slots_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)slots;
+        auto load = [&](size_t k) __attribute__((always_inline)) {
+            const char *src = xbase + k * TF * xrowb;
+            const int nf = k + 1 == ntiles ? ntail : TF;
+            const uint32_t dst = slots_lds + uint32_t(k & 1) * kFmStagedTile;
+#pragma unroll
+            for (int j = 0; j < NI; j++)
+                if (mine && j * RPI + mrow < nf) glds16_s(uniform_ptr(src + size_t(j * RPI) * xrowb), xoff, dst + j * 1024);
+        };
+        auto store = [&](size_t k) __attribute__((always_inline)) {
+            char *dst = ybase + k * TF * yrowb;
+            const int nf = k + 1 == ntiles ? ntail : TF;
+            const char *slot = slots + (k & 1) * kFmStagedTile;
+#pragma unroll
+            for (int j = 0; j < NI; j++) {
+                const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
+                if (mine && j * RPI + mrow < nf) global_st<u32x4, true>(dst + size_t(j * RPI) * yrowb, yoff, v4);
+                if (j % 8 == 7) asm volatile("" ::: "memory");
+            }
+        };
+        load(0);
+        for (size_t k = 0; k < ntiles; k++) {
+            wait_vmcnt<0>();  // tile k has landed (and the stores of tile k - 2 are done)
+            lds_barrier();    // barrier k: the compute wave has finished tile k - 1
+            if (k >= 1) {
+                store(k - 1);
+                lds_wave_sync();  // its LDS reads are done: the tile may be overwritten
+            }
+            if (k + 1 < ntiles) load(k + 1);
+        }
+        lds_barrier();  // barrier ntiles: the last tile is computed
+        store(ntiles - 1);
+        return;
+    }
+
+    // ---- compute wave
+    const bool active = size_t(lid) < nrows;
+    P p;
+    if constexpr (P::LDS_WORDS > 0) {
+        P::fill_shared(ptab, lid, kWave);
+        lds_wave_sync();
+        p.set_shared(ptab);
+    }
+    if (active) p.load(prm, st, slanes, lane0 + lid);
+    auto one = [&](uint32_t w) __attribute__((always_inline)) {
+        uint32_t ww[1] = {w};
+        to_words<Out>(p.step(prm, words_to<In>(ww)), ww);
+        return ww[0];
+    };
+    for (size_t k = 0; k < ntiles; k++) {
+        lds_barrier();  // barrier k: tile k has landed
+        uint32_t *const col = reinterpret_cast<uint32_t *>(slots + (k & 1) * kFmStagedTile) + lid;  // frame f at col[f LW]
+        if (!active) continue;
+        if (k + 1 == ntiles && ntail != TF) {
+            for (int f = 0; f < ntail; f++) col[f * LW] = one(col[f * LW]);
+        } else if constexpr (MaxU<P>::value < 24) {
+            for (int f = 0; f < TF; f++) col[f * LW] = one(col[f * LW]);  // a large body: keep the loop rolled
+        } else {
+            // chunks of NS frames: the next chunk's LDS reads are issued before the current chunk's arithmetic
+            uint32_t cur[NS], nxt[NS];
+#pragma unroll
+            for (int c = 0; c < NS; c++) cur[c] = col[c * LW];
+#pragma unroll 1
+            for (int g = 0; g < TF / NS; g++) {
+                if (g + 1 < TF / NS) {
+#pragma unroll
+                    for (int c = 0; c < NS; c++) nxt[c] = col[((g + 1) * NS + c) * LW];
+                }
+                if constexpr (HasTileOf<P>::value) {
+                    In xin[NS];
+                    Out yo[NS];
+#pragma unroll
+                    for (int c = 0; c < NS; c++) xin[c] = __builtin_bit_cast(In, cur[c]);
+                    tile_of<P, 1, NS>(prm, &p, xin, yo);
+#pragma unroll
+                    for (int c = 0; c < NS; c++) col[(g * NS + c) * LW] = __builtin_bit_cast(uint32_t, yo[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NS; c++) col[(g * NS + c) * LW] = one(cur[c]);
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < NS; c++) cur[c] = nxt[c];
+            }
+        }
+    }
+    lds_barrier();  // barrier ntiles
+    if (active) p.store(prm, st, slanes, lane0 + lid);
+}
+
 // ------------------------------------------------------------- FRAME_MAJOR, two waves per 64 lanes
 // A serial chain of sections split over TWO waves (round 3).  A VALU-bound processor at one wave per SIMD — 65536 lanes are
 // 1024 waves — runs at the issue rate of a single wave, and for the i32 sections that is one v_mad_i64_i32 per ~10 cycles
@@ -1622,6 +1758,22 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || off_grid_ok) && lanes % 4 == 0 && lanes >= sweep_min && frames >= thr::kSweepMinFrames &&
                     sweep_takes<P>(lanes))
                     return launch_sweep<P>(prm, st, x, y, lanes, frames, xl, yl, sp, s);
+            }
+        }
+        if constexpr (FmStagedOf<P>::value && P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4 && P::COST <= thr::kPairMaxCost) {
+            // Few lanes, long calls, cheap single sections: one wave computes, one wave moves (stream_frame_major_pair above).
+            // (IDSP_DIAG=1 IDSP_NO_FM_PAIR=1: the staged single-wave kernel; IDSP_FM_PAIR_MAX_LANES=n: another upper lane count)
+            static const bool no_pair = diag_env("IDSP_NO_FM_PAIR") != nullptr;
+            static const size_t pair_max = diag_size("IDSP_FM_PAIR_MAX_LANES", thr::kPairMaxLanes);
+            // rows on the 64-byte grid only: off it the staged kernel's plain accesses and XCD-contiguous order (round 4) win — 16384 lanes of a 16385-lane
+            // tensor 0.315 ms here against 0.186 there
+            const bool grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * 4) % 64 == 0 && (yl * 4) % 64 == 0;
+            if (!no_pair && lanes <= pair_max && frames >= thr::kPairMinFrames && lanes % 4 == 0 && grid64 && xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
+                constexpr size_t bytes = 2 * size_t(kFmStagedTile) + size_t(P::LDS_WORDS) * 4;
+                if (int rc = ensure_dyn_lds<&stream_frame_major_pair<P>>(bytes)) return rc;
+                note_kernel("stream_frame_major_pair[compute + mover wave per 32 lanes]", typeid(P).name());
+                hipLaunchKernelGGL((stream_frame_major_pair<P>), dim3(unsigned((lanes + 31) / 32)), dim3(2 * kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp);
+                return launch_status();
             }
         }
         if constexpr (FmStagedOf<P>::value) {

@@ -64,7 +64,13 @@ def test_every_biquad_entry_on_the_staged_kernel(gpu):
                 run_case(gpu, op, cfg, n, words, dt, rng, lanes, frames, pitch, inplace)
                 k = kernel_of(gpu)
                 # (chains of more than 4 sections run as passes of up to 4: the name is that of the last, short pass)
-                assert k.startswith("stream_frame_major_staged[") == (frames >= 16), (op, n, lanes, frames, k)
+                # round 6: from 512 frames the cheap 4-byte processors take the compute + mover pair kernel (tests/test_gpu_frame_major_pair.py)
+                from tests.test_gpu_frame_major_pair import PAIR, takes
+
+                if frames >= 512 and pitch % 16 == 0 and FORCED_LW is None and takes(op, n, dt) is not False:
+                    assert k.startswith(PAIR) or (takes(op, n, dt) is None and k.startswith("stream_frame_major_staged[")), (op, n, lanes, frames, k)
+                else:
+                    assert k.startswith("stream_frame_major_staged[") == (frames >= 16), (op, n, lanes, frames, k)
 
 
 def test_lane_block_of_a_wider_tensor_in_place(gpu):
@@ -129,7 +135,7 @@ def test_every_lanes_per_wave_form_on_the_ragged_shapes(gpu, lw):
     if FORCED_LW:
         pytest.skip("already inside a forced run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, IDSP_DIAG="1", IDSP_FM_LANES_PER_WAVE=lw)
+    env = dict(os.environ, IDSP_DIAG="1", IDSP_FM_LANES_PER_WAVE=lw, IDSP_NO_FM_PAIR="1")  # (the pair kernel would take the long shapes)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "every_biquad or lane_block"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

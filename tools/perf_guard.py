@@ -9,7 +9,8 @@ up as `ok: false` in bench.py's line (`perf_guard`) instead of as a silent 5 %.
 bench.py passes the fractions it has already measured (C2, C2 in place, C5) and this module times the rest.
 
 Shapes (FrameMajor x 4096 frames): C2 = i32 DF1 65536 lanes; C2 in place; C5 = f32 DF2T 2^20 lanes; C5's 8-GPU shard = f32 DF2T
-131072 lanes; i32 DF1 at 131072 / 100000 / 32768 lanes (full blocks two per workgroup; narrow blocks; several frames per segment).
+131072 lanes; i32 DF1 at 131072 / 100000 / 32768 lanes (full blocks two per workgroup; narrow blocks; several frames per segment) and at
+16384 lanes (the compute + mover pair kernel).
 Reference loop nest replaced: dsp-process/src/compose.rs:468-494 over process.rs:122-141."""
 from __future__ import annotations
 
@@ -34,6 +35,7 @@ SHAPES = {
     "i32_131072": ("biquad_i32_df1", "int32", 4, 131072, 4096, False),
     "i32_100000": ("biquad_i32_df1", "int32", 4, 100000, 4096, False),
     "i32_32768": ("biquad_i32_df1", "int32", 4, 32768, 4096, False),
+    "i32_16384": ("biquad_i32_df1", "int32", 4, 16384, 4096, False),  # the compute + mover pair kernel (lane_stream.h)
 }
 
 
@@ -100,9 +102,15 @@ def measure(name: str, launches: int = 30):
     stream = torch.cuda.current_stream()
     args = (C.byref(rec), 1, C.c_void_p(st.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), lanes, frames, _abi.FRAME_MAJOR,
             C.c_void_p(stream.cuda_stream))
-    for _ in range(8):
-        call(entry, *args)
-    torch.cuda.synchronize()
+    import time
+
+    t0 = time.perf_counter()
+    while True:  # warm up by time, not by count: the first launches after an idle gap run at a lower clock (bench.py settles for 250 ms too)
+        for _ in range(8):
+            call(entry, *args)
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 > 0.25:
+            break
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(stream)
     for _ in range(launches):
