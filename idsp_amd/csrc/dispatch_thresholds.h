@@ -41,9 +41,6 @@ constexpr size_t kDuoMinLanes = 40960, kDuo4MaxLanes = 98304;
 // staged kernel, lanes per wave: 64 from here, 32 from here (or COST > 120), else 16
 constexpr size_t kLmStaged64Lanes = 49152, kLmStaged32Lanes = 24576;
 
-// compute + mover pair kernel (stream_lane_major_pair, round 6): cheap 4-byte sections, lane range and smallest call (two tiles of 128 frames)
-constexpr size_t kLmPairMinLanes = size_t(1) << 40, kLmPairMaxLanes = size_t(1) << 40, kLmPairMinFrames = 256;  // (off until measured: IDSP_LM_PAIR_MIN_LANES)
-
 // ---- start-up stagger of the line-wise LaneMajor kernels (lockin_waves.h, dds.hip; MI355X in SPX mode only: stagger_tuned_device()) --
 constexpr unsigned kStaggerMinWorkgroups = 512;                     // launches of at least two workgroups per CU
 constexpr size_t kStaggerMinFrames = 2048, kStaggerMaxFrames = 8192;  // long enough to pay, short enough not to drift apart anyway

@@ -1053,160 +1053,6 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     }
 }
 
-// ------------------------------------------- LANE_MAJOR: one wave computes, one wave moves (round 6)
-// The LaneMajor twin of stream_frame_major_pair (below): stream_lane_major_staged runs at the plain-copy rate of the box (C2: 0.71 of the
-// HBM peak, 0.98-1.03 x `idsp_device_copy`) with ONE wave per SIMD that loads a tile into 32 staging registers, hands it to LDS, walks
-// its rows, re-reads the tile and stores it — memory and chain in turns, 224 VGPRs.  Here a workgroup is two waves over 64 lanes and
-// two 32 KiB tiles (64 rows x 512-byte runs): the mover wave requests tile k + 1 by `global_load_lds_dwordx4` (two rows' runs per
-// instruction, the pieces permuted on the global side exactly as the staged kernel permutes them, so the slot layout and the
-// owner's conflict-free reads are the same) and stores tile k - 1 while the compute wave walks tile k.  One barrier per tile.
-template <class P>
-__global__ __launch_bounds__(2 * kWave) void stream_lane_major_pair(
-    const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
-    const size_t lanes, const size_t frames, const size_t xl, const size_t yl)
-{
-    using In = typename P::In;
-    using Out = typename P::Out;
-    static_assert(LmStagedOf<P>::value && P::HAS_IN && sizeof(In) == 4 && sizeof(Out) == 4 && BatchOf<P>::value == 1, "one 4-byte input and output per lane and frame");
-    constexpr int LW = kWave, RB = kLmRun;          // lanes per workgroup, bytes per lane and tile
-    constexpr int TF = RB / 4;                      // frames per tile
-    using SD = LmSide<RB, LW>;
-    constexpr int PCS = SD::PCS, NI = SD::NI;       // pieces per lane and tile; instructions per tile
-    constexpr int NS = 16;                          // samples per compute chunk (4 pieces)
-    static_assert(NI % 16 == 0, "the piece permutation is a constant per instruction");
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    char *const slots = reinterpret_cast<char *>(smem);                // two tiles of LW x RB bytes
-    uint32_t *ptab = smem + 2 * LW * RB / 4;                           // [P::LDS_WORDS]
-    const int lid = threadIdx.x % kWave;
-    const bool mover = __builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave)) != 0;
-    const size_t lane0 = size_t(blockIdx.x) * LW;
-    const size_t nrows = lanes - lane0 < size_t(LW) ? lanes - lane0 : size_t(LW);
-    const size_t nquads = frames / 4;                                  // whole groups of 4 samples (16-byte pieces) of every row
-    const size_t ntiles = (nquads * 4 + TF - 1) / TF;                  // tiles of whole pieces (the last frames % 4 samples: compute wave, below)
-    const int nq_last = int(nquads - (ntiles ? ntiles - 1 : 0) * (TF / 4));  // pieces per lane of the last tile (1 .. TF / 4)
-    const size_t xrowb = xl * sizeof(In), yrowb = yl * sizeof(Out);    // bytes between lanes
-
-    if (mover) {
-        if (ntiles == 0) return;
-        // in instruction j: lane mq + j of the tile, piece mpc ^ (j % 16) of its run (LmSide)
-        const int mq = (lid / PCS) * NI, mpc = lid % PCS;
-        const char *const xbase = reinterpret_cast<const char *>(x) + lane0 * xrowb;
-        char *const ybase = reinterpret_cast<char *>(y) + lane0 * yrowb;
-        const uint32_t xoff = uint32_t(mq) * uint32_t(xrowb), yoff = uint32_t(mq) * uint32_t(yrowb);
-        const uint32_t slots_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)slots;
-        auto load = [&](size_t k) __attribute__((always_inline)) {
-            const char *src = xbase + k * size_t(RB);
-            const int nq = k + 1 == ntiles ? nq_last : TF / 4;
-            const uint32_t dst = slots_lds + uint32_t(k & 1) * (LW * RB);
-#pragma unroll
-            for (int j = 0; j < NI; j++) {
-                const int pc = mpc ^ (j & 15);
-                if (size_t(mq + j) < nrows && pc < nq) glds16_s(uniform_ptr(src + j * xrowb), xoff + uint32_t(pc * 16), dst + j * 1024);
-            }
-        };
-        auto store = [&](size_t k) __attribute__((always_inline)) {
-            char *dst = ybase + k * size_t(RB);
-            const int nq = k + 1 == ntiles ? nq_last : TF / 4;
-            const char *slot = slots + (k & 1) * (LW * RB);
-#pragma unroll
-            for (int j = 0; j < NI; j++) {
-                const int pc = mpc ^ (j & 15);
-                const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
-                if (size_t(mq + j) < nrows && pc < nq) global_st<u32x4, true>(dst + j * yrowb, yoff + uint32_t(pc * 16), v4);
-                if (j % 8 == 7) asm volatile("" ::: "memory");
-            }
-        };
-        load(0);
-        for (size_t k = 0; k < ntiles; k++) {
-            wait_vmcnt<0>();  // tile k has landed (and the stores of tile k - 2 are done)
-            lds_barrier();    // barrier k: the compute wave has finished tile k - 1
-            if (k >= 1) {
-                store(k - 1);
-                lds_wave_sync();  // its LDS reads are done: the tile may be overwritten
-            }
-            if (k + 1 < ntiles) load(k + 1);
-        }
-        lds_barrier();  // barrier ntiles: the last tile is computed
-        store(ntiles - 1);
-        return;
-    }
-
-    // ---- compute wave: thread = lane
-    const bool active = size_t(lid) < nrows;
-    P p;
-    if constexpr (P::LDS_WORDS > 0) {
-        P::fill_shared(ptab, lid, kWave);
-        lds_wave_sync();
-        p.set_shared(ptab);
-    }
-    if (active) p.load(prm, st, lanes, lane0 + lid);
-    // slot row of this thread's lane and the byte offset of its piece k = own ^ (16 k)  (LmSide)
-    const uint32_t own = uint32_t((lid % NI) * SD::G + lid / NI) * RB + uint32_t(lid & 15) * 16;
-    for (size_t k = 0; k < ntiles; k++) {
-        lds_barrier();  // barrier k: tile k has landed
-        if (!active) continue;
-        char *const slot = slots + (k & 1) * (LW * RB);
-        auto in_piece = [&](int q) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4 *>(slot + (own ^ uint32_t(q * 16))); };
-        auto out_piece = [&](int q, const u32x4 &v) __attribute__((always_inline)) { *reinterpret_cast<u32x4 *>(slot + (own ^ uint32_t(q * 16))) = v; };
-        auto quad = [&](const u32x4 &in) __attribute__((always_inline)) {
-            u32x4 out;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                uint32_t w[1] = {in[b]};
-                to_words<Out>(p.step(prm, words_to<In>(w)), w);
-                out[b] = w[0];
-            }
-            return out;
-        };
-        const int nq = k + 1 == ntiles ? nq_last : TF / 4;
-        if (nq != TF / 4 || MaxU<P>::value < 24) {
-            for (int q = 0; q < nq; q++) out_piece(q, quad(in_piece(q)));  // partial tile, or a large body: keep the loop rolled
-        } else {
-            // chunks of NS samples: the next chunk's LDS reads are issued before the current chunk's arithmetic
-            constexpr int NCH = TF / NS, CP = NS / 4;
-            u32x4 cur[CP], nxt[CP];
-#pragma unroll
-            for (int c = 0; c < CP; c++) cur[c] = in_piece(c);
-#pragma unroll 1
-            for (int g = 0; g < NCH; g++) {
-                if (g + 1 < NCH) {
-#pragma unroll
-                    for (int c = 0; c < CP; c++) nxt[c] = in_piece((g + 1) * CP + c);
-                }
-                u32x4 out[CP];
-                if constexpr (HasTileOf<P>::value) {
-                    In xin[NS];
-                    Out yo[NS];
-#pragma unroll
-                    for (int q = 0; q < NS; q++) xin[q] = __builtin_bit_cast(In, uint32_t(cur[q / 4][q % 4]));
-                    tile_of<P, 1, NS>(prm, &p, xin, yo);
-#pragma unroll
-                    for (int q = 0; q < CP; q++)
-                        out[q] = u32x4{__builtin_bit_cast(uint32_t, yo[4 * q]), __builtin_bit_cast(uint32_t, yo[4 * q + 1]), __builtin_bit_cast(uint32_t, yo[4 * q + 2]),
-                                       __builtin_bit_cast(uint32_t, yo[4 * q + 3])};
-                } else {
-#pragma unroll
-                    for (int q = 0; q < CP; q++) out[q] = quad(cur[q]);
-                }
-#pragma unroll
-                for (int c = 0; c < CP; c++) out_piece(g * CP + c, out[c]);
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int c = 0; c < CP; c++) cur[c] = nxt[c];
-            }
-        }
-    }
-    if (ntiles) lds_barrier();  // barrier ntiles
-    if (active) {  // the last frames % 4 samples of this lane's own row
-        const In *xr = x + (lane0 + lid) * xl;
-        Out *yr = y + (lane0 + lid) * yl;
-        for (size_t f = nquads * 4; f < frames; f++) yr[f] = step1(p, prm, xr[f]);
-        p.store(prm, st, lanes, lane0 + lid);
-    }
-}
-
 // ------------------------------------------- FRAME_MAJOR, few lanes (staged)
 // Below ~49152 lanes the FrameMajor kernels above stop being bandwidth-bound: a lane is a serial chain, the LDS-DMA
 // kernel pays two workgroup barriers per 8 frames and the register-window kernel a global-load wait per frame, and both
@@ -1772,19 +1618,6 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
             const bool x_ok = !P::HAS_IN || (reinterpret_cast<uintptr_t>(x) % 16 == 0 && (xl * isz) % 16 == 0 && xl * isz < (size_t(1) << 26));
             if (!no_staged && frames * wide >= size_t(kLmRun) / 4 && x_ok && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
                 (yl * osz) % 16 == 0 && yl * osz < (size_t(1) << 26)) {
-                if constexpr (P::HAS_IN && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4 && BatchOf<P>::value == 1 && P::COST <= thr::kPairMaxCost) {
-                    // one wave computes, one wave moves (stream_lane_major_pair above)
-                    // (IDSP_DIAG=1 IDSP_NO_LM_PAIR=1: the staged kernel; IDSP_LM_PAIR_MIN_LANES / _MAX_LANES: other limits)
-                    static const bool no_lm_pair = diag_env("IDSP_NO_LM_PAIR") != nullptr;
-                    static const size_t lmp_min = diag_size("IDSP_LM_PAIR_MIN_LANES", thr::kLmPairMinLanes), lmp_max = diag_size("IDSP_LM_PAIR_MAX_LANES", thr::kLmPairMaxLanes);
-                    if (!no_lm_pair && lanes >= lmp_min && lanes <= lmp_max && frames >= thr::kLmPairMinFrames) {
-                        constexpr size_t bytes = 2 * size_t(kWave) * kLmRun + size_t(P::LDS_WORDS) * 4;
-                        if (int rc = ensure_dyn_lds<&stream_lane_major_pair<P>>(bytes)) return rc;
-                        note_kernel("stream_lane_major_pair[compute + mover wave per 64 lanes]", typeid(P).name());
-                        hipLaunchKernelGGL((stream_lane_major_pair<P>), dim3(unsigned((lanes + kWave - 1) / kWave)), dim3(2 * kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl);
-                        return launch_status();
-                    }
-                }
                 // lanes per wave: 64 when that already gives every SIMD a wave, else 32 or 16 (tools/tune_lm.hip;
                 // IDSP_DIAG=1 IDSP_LM_LANES_PER_WAVE = 64 / 32 / 16 forces one)
                 static const size_t forced_lw = diag_size("IDSP_LM_LANES_PER_WAVE", 0);
