@@ -27,10 +27,10 @@ constexpr size_t kSplitTailMax = 20480;
 constexpr size_t kStagedMaxLanes = 49152, kStagedHeavyMinLanes = 12288, kStagedHeavyMaxLanes = 40960;
 // ... lanes per wave: 64 from here (rows on / off the 64-byte grid), 32 from here, else 16
 constexpr size_t kStaged64Lanes = 24576, kStaged64LanesOffGrid = 25600, kStaged32Lanes = 8192;
-// compute + mover pair kernel (stream_frame_major_pair, round 6): cheap sections (COST <= kPairMaxCost) UP TO this lane count — 512 workgroups of 32 lanes,
-// two per CU (64 KiB of LDS each): 20480 lanes would be a second generation, 0.194 against 0.166 ms on the staged kernel — from this many frames (two tiles;
-// 512 frames 0.0174 against 0.0194 ms at 16384 lanes, 4096 frames 0.108 against 0.137: profiles/r06_exp_fm_pair.txt)
-constexpr size_t kPairMaxLanes = 16384, kPairMinFrames = 512;
+// compute + mover pair kernel (stream_frame_major_pair, round 6): cheap sections (COST <= kPairMaxCost) UP TO this lane count — 768 workgroups of 32 lanes and
+// 32 KiB of LDS, three per CU, ahead of the sweep kernel's several-frames-per-segment form (24576 lanes 0.175 against 0.192 ms; 28672 lanes would be a second
+// generation: 0.217 against 0.194) — from this many frames (four tiles; 512 frames 0.0174 against 0.0194 ms at 16384 lanes: profiles/r06_exp_fm_pair.txt)
+constexpr size_t kPairMaxLanes = 24576, kPairMinFrames = 512;
 constexpr int kPairMaxCost = 60;
 // smallest launch (in 64-lane waves) of the round-3 LDS-DMA kernel
 constexpr size_t kLdsMinWaves = 256;

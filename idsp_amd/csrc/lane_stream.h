@@ -1253,10 +1253,11 @@ __global__ __launch_bounds__(kWave) void stream_frame_major_staged(
 // loads, hands them to LDS, walks its column, re-reads the tile and issues 32 stores — and a section that only copies takes 0.11 ms
 // in it.  Here the two halves run side by side: a workgroup is TWO waves over LW = 32 lanes; wave 1 (the mover) brings tile k + 1 in
 // by `global_load_lds_dwordx4` (8 row pieces of 128 bytes per request, straight into the tile: no staging registers) and takes
-// tile k - 1 out (`ds_read_b128` + 16-byte stores) while wave 0 walks its column of tile k; two 32 KiB tiles, ONE barrier per
-// tile: at barrier k the mover has waited for tile k's requests and the compute wave has finished tile k - 1.  The compute wave's
+// tile k - 1 out (`ds_read_b128` + 16-byte stores) while wave 0 walks its column of tile k; two 16 KiB tiles (128 frames), ONE barrier
+// per tile: at barrier k the mover has waited for tile k's requests and the compute wave has finished tile k - 1.  The compute wave's
 // loop holds nothing but LDS reads (two frames per instruction), the processor's steps and LDS writes.
-template <class P>
+constexpr int kFmPairTile = 16384;  // bytes per tile: 128 frames x 32 lanes (32 KiB tiles: 16384 lanes 0.108 against 0.102 ms, and only two workgroups per CU)
+template <class P, int TB = kFmPairTile>
 __global__ __launch_bounds__(2 * kWave) void stream_frame_major_pair(
     const typename P::Params prm, uint32_t *st, const typename P::In *x, typename P::Out *y,
     const size_t lanes, const size_t frames, const size_t xl, const size_t yl, const size_t slanes)
@@ -1266,17 +1267,17 @@ __global__ __launch_bounds__(2 * kWave) void stream_frame_major_pair(
     static_assert(FmStagedOf<P>::value && sizeof(In) == 4 && sizeof(Out) == 4, "one 4-byte input and output per lane and frame");
     constexpr int LW = 32;
     constexpr int RB = LW * 4;                      // bytes of a row piece (one frame of the workgroup's lanes)
-    constexpr int TF = kFmStagedTile / RB;          // frames per tile
+    constexpr int TF = TB / RB;                     // frames per tile
     constexpr int PPR = RB / 16;                    // 16-byte pieces per row piece
     constexpr int RPI = kWave / PPR;                // rows one instruction covers
-    constexpr int NI = kFmStagedTile / 1024;        // instructions per tile
+    constexpr int NI = TB / 1024;                   // instructions per tile
     constexpr int NS = 16;                          // frames per compute chunk
     static_assert(TF % NS == 0 && NI * RPI == TF, "tile shape");
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     char *const slots = reinterpret_cast<char *>(smem);       // two tiles
-    uint32_t *ptab = smem + 2 * kFmStagedTile / 4;            // [P::LDS_WORDS]
+    uint32_t *ptab = smem + 2 * TB / 4;                       // [P::LDS_WORDS]
     const int lid = threadIdx.x % kWave;
     const bool mover = __builtin_amdgcn_readfirstlane(int(threadIdx.x / kWave)) != 0;
     const size_t lane0 = size_t(blockIdx.x) * LW;
@@ -1296,7 +1297,7 @@ __global__ __launch_bounds__(2 * kWave) void stream_frame_major_pair(
         auto load = [&](size_t k) __attribute__((always_inline)) {
             const char *src = xbase + k * TF * xrowb;
             const int nf = k + 1 == ntiles ? ntail : TF;
-            const uint32_t dst = slots_lds + uint32_t(k & 1) * kFmStagedTile;
+            const uint32_t dst = slots_lds + uint32_t(k & 1) * TB;
 #pragma unroll
             for (int j = 0; j < NI; j++)
                 if (mine && j * RPI + mrow < nf) glds16_s(uniform_ptr(src + size_t(j * RPI) * xrowb), xoff, dst + j * 1024);
@@ -1304,7 +1305,7 @@ __global__ __launch_bounds__(2 * kWave) void stream_frame_major_pair(
         auto store = [&](size_t k) __attribute__((always_inline)) {
             char *dst = ybase + k * TF * yrowb;
             const int nf = k + 1 == ntiles ? ntail : TF;
-            const char *slot = slots + (k & 1) * kFmStagedTile;
+            const char *slot = slots + (k & 1) * TB;
 #pragma unroll
             for (int j = 0; j < NI; j++) {
                 const u32x4 v4 = *reinterpret_cast<const u32x4 *>(slot + j * 1024 + lid * 16);
@@ -1343,7 +1344,7 @@ __global__ __launch_bounds__(2 * kWave) void stream_frame_major_pair(
     };
     for (size_t k = 0; k < ntiles; k++) {
         lds_barrier();  // barrier k: tile k has landed
-        uint32_t *const col = reinterpret_cast<uint32_t *>(slots + (k & 1) * kFmStagedTile) + lid;  // frame f at col[f LW]
+        uint32_t *const col = reinterpret_cast<uint32_t *>(slots + (k & 1) * TB) + lid;  // frame f at col[f LW]
         if (!active) continue;
         if (k + 1 == ntiles && ntail != TF) {
             for (int f = 0; f < ntail; f++) col[f * LW] = one(col[f * LW]);
@@ -1598,6 +1599,14 @@ inline Params shift_lanes(Params p, size_t first, size_t elem)
 // 73728 lanes 0.58 -> 0.69 of the HBM peak with an 8192-lane remainder, 81920 0.59 -> 0.63 with 16384, no gain from 24576 up)
 constexpr size_t kSplitTailMax = thr::kSplitTailMax;
 
+// set while launch_stream launches the remainder of a "whole rounds + remainder" split on the second stream: that launch keeps the staged kernel
+// (beside the sweep kernel's whole rounds the pair kernel's remainder costs 6-10 %: 69632 lanes 0.413 -> 0.454 ms, profiles/r06_exp_fm_pair.txt)
+inline bool &split_remainder_flag()
+{
+    static thread_local bool f = false;
+    return f;
+}
+
 template <class P>
 int launch_stream(const typename P::Params &prm, void *state, const typename P::In *x,
                   typename P::Out *y, size_t lanes, size_t frames, int layout, hipStream_t s, Pitch pitch = {}, size_t state_pitch = 0)
@@ -1720,9 +1729,12 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     // panel walk for the processors / shapes the sweep does not take)
                     const char *const head_name = noted_kernel();
                     const bool head_swept = head_name && std::strncmp(head_name, "stream_frame_major_sweep", 24) == 0;
-                    if (rc == IDSP_OK)
+                    if (rc == IDSP_OK) {
+                        split_remainder_flag() = true;
                         rc = launch_stream<P>(shift_lanes(prm, head, sizeof(typename P::In)), st + head, x + head, y + head, tail, frames, layout, ss->stream,
                                               Pitch{xl, yl}, sp);
+                        split_remainder_flag() = false;
+                    }
                     // join even after a failed launch: the caller's stream must not run ahead of whatever the side stream holds
                     IDSP_HIP_TRY(hipEventRecord(ss->join, ss->stream));
                     IDSP_HIP_TRY(hipStreamWaitEvent(s, ss->join, 0));
@@ -1732,6 +1744,22 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                                     typeid(P).name());
                     return rc;
                 }
+            }
+        }
+        if constexpr (FmStagedOf<P>::value && P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4 && P::COST <= thr::kPairMaxCost) {
+            // Few lanes, long calls, cheap single sections: one wave computes, one wave moves (stream_frame_major_pair above).
+            // (IDSP_DIAG=1 IDSP_NO_FM_PAIR=1: the staged single-wave kernel; IDSP_FM_PAIR_MAX_LANES=n: another upper lane count)
+            static const bool no_pair = diag_env("IDSP_NO_FM_PAIR") != nullptr;
+            static const size_t pair_max = diag_size("IDSP_FM_PAIR_MAX_LANES", thr::kPairMaxLanes);
+            // rows on the 64-byte grid only: off it the staged kernel's plain accesses and XCD-contiguous order (round 4) win — 16384 lanes of a 16385-lane
+            // tensor 0.315 ms here against 0.186 there
+            const bool grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * 4) % 64 == 0 && (yl * 4) % 64 == 0;
+            if (!no_pair && !split_remainder_flag() && lanes <= pair_max && frames >= thr::kPairMinFrames && lanes % 4 == 0 && grid64 && xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
+                constexpr size_t bytes = 2 * size_t(kFmPairTile) + size_t(P::LDS_WORDS) * 4;
+                if (int rc = ensure_dyn_lds<&stream_frame_major_pair<P>>(bytes)) return rc;
+                note_kernel("stream_frame_major_pair[compute + mover wave per 32 lanes]", typeid(P).name());
+                hipLaunchKernelGGL((stream_frame_major_pair<P>), dim3(unsigned((lanes + 31) / 32)), dim3(2 * kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp);
+                return launch_status();
             }
         }
         if constexpr (P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4) {
@@ -1758,22 +1786,6 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                 if (!no_sweep && !cost_forced_ && !no_lds_ && (on_grid64 || off_grid_ok) && lanes % 4 == 0 && lanes >= sweep_min && frames >= thr::kSweepMinFrames &&
                     sweep_takes<P>(lanes))
                     return launch_sweep<P>(prm, st, x, y, lanes, frames, xl, yl, sp, s);
-            }
-        }
-        if constexpr (FmStagedOf<P>::value && P::HAS_IN && P::IN_DIV == 1 && sizeof(typename P::In) == 4 && sizeof(typename P::Out) == 4 && P::COST <= thr::kPairMaxCost) {
-            // Few lanes, long calls, cheap single sections: one wave computes, one wave moves (stream_frame_major_pair above).
-            // (IDSP_DIAG=1 IDSP_NO_FM_PAIR=1: the staged single-wave kernel; IDSP_FM_PAIR_MAX_LANES=n: another upper lane count)
-            static const bool no_pair = diag_env("IDSP_NO_FM_PAIR") != nullptr;
-            static const size_t pair_max = diag_size("IDSP_FM_PAIR_MAX_LANES", thr::kPairMaxLanes);
-            // rows on the 64-byte grid only: off it the staged kernel's plain accesses and XCD-contiguous order (round 4) win — 16384 lanes of a 16385-lane
-            // tensor 0.315 ms here against 0.186 there
-            const bool grid64 = reinterpret_cast<uintptr_t>(x) % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 64 == 0 && (xl * 4) % 64 == 0 && (yl * 4) % 64 == 0;
-            if (!no_pair && lanes <= pair_max && frames >= thr::kPairMinFrames && lanes % 4 == 0 && grid64 && xl * 4 < (size_t(1) << 28) && yl * 4 < (size_t(1) << 28)) {
-                constexpr size_t bytes = 2 * size_t(kFmStagedTile) + size_t(P::LDS_WORDS) * 4;
-                if (int rc = ensure_dyn_lds<&stream_frame_major_pair<P>>(bytes)) return rc;
-                note_kernel("stream_frame_major_pair[compute + mover wave per 32 lanes]", typeid(P).name());
-                hipLaunchKernelGGL((stream_frame_major_pair<P>), dim3(unsigned((lanes + 31) / 32)), dim3(2 * kWave), bytes, s, prm, st, x, y, lanes, frames, xl, yl, sp);
-                return launch_status();
             }
         }
         if constexpr (FmStagedOf<P>::value) {

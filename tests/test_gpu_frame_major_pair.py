@@ -1,7 +1,7 @@
-"""FRAME_MAJOR at up to 16384 lanes and from 512 frames: the compute + mover pair kernel (`stream_frame_major_pair`,
+"""FRAME_MAJOR at up to 24576 lanes and from 512 frames: the compute + mover pair kernel (`stream_frame_major_pair`,
 idsp_amd/csrc/lane_stream.h, round 6 — one wave walks its 32 lanes' columns of a tile while the other brings the next tile in by
 LDS-DMA and takes the previous one out).  Every 4-byte biquad-family entry the kernel takes (cheap sections), lane counts that leave a
-partial last workgroup, frame counts around the 256-frame tiles (whole tiles, a short last tile, one frame more than two tiles), padded
+partial last workgroup, frame counts around the 128-frame tiles (whole tiles, a short last tile, one frame more than four tiles), padded
 rows, a lane block of a wider tensor, out of place and in place, against the oracle bit for bit (outputs, written-back state, untouched
 neighbours); the kernel taken is asserted through `idsp_last_kernel()`.  Anything it does not take (long chains, 8-byte samples, rows
 off the 16-byte grid, more lanes, fewer frames) must still land on the kernels of rounds 2-5 with the same result.
@@ -56,12 +56,16 @@ def test_every_cheap_biquad_entry_on_the_pair_kernel(gpu):
 
 
 def test_limits_of_the_pair_kernel(gpu):
-    """one lane more than 512 workgroups, one frame fewer than two tiles, rows off the 16-byte / 64-byte grid: the kernels of rounds 2-5"""
+    """one 16-lane group more than 768 workgroups, one frame fewer than four tiles, rows off the 16-byte / 64-byte grid: the kernels of rounds 2-5"""
     rng = np.random.default_rng(602)
     op, cfg, n, words, dt = [c for c in cases(rng) if c[0] == "biquad_i32_df1" and c[2] == 1][0]
     FMS.run_case(gpu, op, cfg, n, words, dt, rng, 16384, 512, 16384, False)
     assert kernel_of(gpu).startswith(PAIR), kernel_of(gpu)
-    FMS.run_case(gpu, op, cfg, n, words, dt, rng, 16388, 512, 16388, False)
+    FMS.run_case(gpu, op, cfg, n, words, dt, rng, 24576, 512, 24576, True)
+    assert kernel_of(gpu).startswith(PAIR), kernel_of(gpu)
+    FMS.run_case(gpu, op, cfg, n, words, dt, rng, 24592, 512, 24592, False)
+    assert kernel_of(gpu).startswith("stream_frame_major_sweep["), kernel_of(gpu)
+    FMS.run_case(gpu, op, cfg, n, words, dt, rng, 16388, 512, 16388, False)  # rows off the 64-byte grid
     assert kernel_of(gpu).startswith("stream_frame_major_staged["), kernel_of(gpu)
     FMS.run_case(gpu, op, cfg, n, words, dt, rng, 16384, 511, 16384, False)
     assert kernel_of(gpu).startswith("stream_frame_major_staged["), kernel_of(gpu)
@@ -100,3 +104,13 @@ def test_chunked_calls_continue_the_stream(gpu):
         torch.cuda.synchronize()
         assert np.array_equal(yd.cpu().numpy().view(np.uint8), want.view(np.uint8)), op
         assert np.array_equal(sg.cpu().numpy().view(np.uint32), so), op
+
+
+def test_remainder_of_a_long_call_beside_the_whole_rounds(gpu):
+    """65536 + 2064 lanes x 600 frames: the whole round on the sweep kernel, the 2064 lanes beside it (second stream, lane_stream.h) stay on the STAGED kernel even
+    in a long call — beside the sweep kernel the pair kernel's remainder costs 6-10 % — every output and the state against the oracle."""
+    rng = np.random.default_rng(604)
+    op, cfg, n, words, dt = [c for c in cases(rng) if c[0] == "biquad_i32_df1" and c[2] == 1][0]
+    lanes = 65536 + 2064
+    FMS.run_case(gpu, op, cfg, n, words, dt, rng, lanes, 600, lanes, False)
+    assert kernel_of(gpu).startswith("stream_frame_major_sweep + stream_frame_major_staged (remainder, second stream)<"), kernel_of(gpu)
