@@ -163,6 +163,12 @@ struct WordsOf<16> {
 template <bool NT, class T>
 __device__ __forceinline__ T nt_load(const T *p)
 {
+#ifdef IDSP_EXP_GENERIC_NT  // A/B: the generic-pointer form of rounds 1-5
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+#endif
     using W = typename WordsOf<int(sizeof(T))>::type;
     const auto *g = reinterpret_cast<const __attribute__((address_space(1))) W *>(reinterpret_cast<uintptr_t>(p));
     if constexpr (NT)
@@ -173,6 +179,17 @@ __device__ __forceinline__ T nt_load(const T *p)
 template <bool NT, class T>
 __device__ __forceinline__ void nt_store(T *p, const T &v)
 {
+#ifdef IDSP_EXP_GENERIC_NT
+    if constexpr (!NT) {
+        *p = v;
+    } else if constexpr (sizeof(T) == 4) {
+        __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), reinterpret_cast<uint32_t *>(p));
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2 *>(p));
+    }
+    return;
+#endif
     using W = typename WordsOf<int(sizeof(T))>::type;
     auto *g = reinterpret_cast<__attribute__((address_space(1))) W *>(reinterpret_cast<uintptr_t>(p));
     if constexpr (NT)
