@@ -142,6 +142,26 @@ def algorithmic_bytes(cfg: dict, lanes: int, frames: int) -> int:
     return lanes * frames * cfg.get("bytes_per_frame", cfg.get("bytes_per_sample", 8)) + 2 * cfg["state_words"] * 4 * lanes
 
 
+# Read / write rates of a bare skeleton of nontemporal 16-byte loads / stores, 1024 waves (tools/ubench_cu_ceiling.hip, one box, committed:
+# profiles/r06_ubench_cu_ceiling.txt): reads and writes share the HBM bus, and a copy runs as the sum of its directions.
+READ_GBS_FILE, WRITE_GBS_FILE = 6900.0, 5450.0
+WRITTEN_BYTES_PER_FRAME = {"c2": 4, "c3": 4, "c4": 8, "c5": 4}  # of `bytes_per_frame` / `bytes_per_sample`: the rest is read
+
+
+def by_direction(cfg_name: str, cfg: dict, lanes: int, frames: int, kernel_ms: float):
+    """The configuration's read and written bytes at the rates reads and writes reach each on their own: read time + write time, and the
+    measured launch against it.  From file (a microbenchmark of another run), labelled so; the live yardstick of the line is `copy_gbs`."""
+    w = WRITTEN_BYTES_PER_FRAME.get(cfg_name)
+    if w is None or kernel_ms <= 0:
+        return None
+    total = cfg.get("bytes_per_frame", cfg.get("bytes_per_sample", 8))
+    state = cfg["state_words"] * 4 * lanes
+    rd, wr = lanes * frames * (total - w) + state, lanes * frames * w + state
+    ms = (rd / READ_GBS_FILE + wr / WRITE_GBS_FILE) / 1e6
+    return {"read_bytes": rd, "written_bytes": wr, "read_gbs": READ_GBS_FILE, "write_gbs": WRITE_GBS_FILE, "sum_of_directions_ms": round(ms, 4),
+            "kernel_ms_over_it": round(kernel_ms / ms, 4), "source": "profiles/r06_ubench_cu_ceiling.txt (tools/ubench_cu_ceiling.hip, committed, another run)"}
+
+
 def wrap64(v: int) -> int:
     """v modulo 2^64 as a signed 64-bit value (what a wrapping i64 sum holds)."""
     v &= MASK64
@@ -729,6 +749,9 @@ def report(cfg_name, cfg, args, world, lanes_rank, frames, elapsed, kern_ms, unt
     }
     if issue:
         line["roofline"]["issue"] = issue
+    bd = by_direction(cfg_name, cfg, lanes_rank, frames, med)
+    if bd:
+        line["roofline"]["by_direction"] = bd
     return line
 
 
