@@ -21,13 +21,14 @@ ap.add_argument("--frames", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--op", default="biquad_i32_df1")
+ap.add_argument("--inplace", action="store_true", help="y == x")
 a = ap.parse_args()
 fn, _ = load()
 dev = torch.device("cuda", 0)
 big = max(a.lanes)
 f32 = "f32" in a.op
 x = (torch.randn(big * a.frames, device=dev) if f32 else torch.randint(-(1 << 24), 1 << 24, (big * a.frames,), dtype=torch.int32, device=dev))
-y = torch.empty_like(x)
+y = x if a.inplace else torch.empty_like(x)
 st = torch.zeros(8 * big, dtype=torch.int32, device=dev)
 layout = 1 if a.layout == "lm" else 0
 sos = (C.c_double * 6)(2.4e-4, 4.8e-4, 2.4e-4, 1.0, -1.955, 0.956)
@@ -56,5 +57,5 @@ for lanes in a.lanes:
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / a.iters)
     med = statistics.median(ts)
-    print(json.dumps({"op": a.op, "layout": a.layout, "lanes": lanes, "frames": a.frames, "ms": round(med, 4), "frac_hbm_peak": round(8 * lanes * a.frames / (med * 1e-3) / 8e12, 4),
+    print(json.dumps({"op": a.op, "inplace": a.inplace, "layout": a.layout, "lanes": lanes, "frames": a.frames, "ms": round(med, 4), "frac_hbm_peak": round(8 * lanes * a.frames / (med * 1e-3) / 8e12, 4),
                       "kernel": name.split("<")[0]}), flush=True)
