@@ -125,3 +125,27 @@ def test_weak_and_strong_job_shards():
         assert [lo for lo, _ in strong] == [r * ((1 << 20) // world) for r in range(world)]
         weak = [bench.job_shard(bench.CONFIGS["c2"], r, world) for r in range(world)]
         assert all(n == 65536 for _, n in weak)
+
+
+def test_by_direction_roof_adds_up():
+    """`roofline.by_direction` (bench.py): read + written bytes = the algorithmic bytes of the line; read time + write time at the committed skeleton
+    rates (profiles/r06_ubench_cu_ceiling.txt); SURVEY 8(d) bytes per unit: biquads 4 + 4, HbfDec /16 64 + 4 per output frame, lock-in 4 + 8."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    want_written = {"c2": 4, "c3": 4, "c4": 8, "c5": 4}
+    for name, w in want_written.items():
+        cfg = bench.CONFIGS[name]
+        lanes, frames = cfg["lanes"], cfg["frames"]
+        bd = bench.by_direction(name, cfg, lanes, frames, 1.0)
+        assert bd["read_bytes"] + bd["written_bytes"] == bench.algorithmic_bytes(cfg, lanes, frames), name
+        assert bd["written_bytes"] == lanes * frames * w + cfg["state_words"] * 4 * lanes, name
+        ms = (bd["read_bytes"] / bd["read_gbs"] + bd["written_bytes"] / bd["write_gbs"]) / 1e6
+        assert abs(bd["sum_of_directions_ms"] - ms) < 1e-3 and abs(bd["kernel_ms_over_it"] - 1.0 / ms) < 1e-3, name
+    assert bench.by_direction("c2", bench.CONFIGS["c2"], 65536, 4096, 0.0) is None
+    # the committed rates are those of the microbenchmark's 1024-wave dense lines
+    txt = open(os.path.join(ROOT, "profiles", "r06_ubench_cu_ceiling.txt")).read()
+    rows = [json.loads(l) for l in txt.splitlines() if l.startswith("{")]
+    rd = [r["TB/s"] for r in rows if r["pattern"] == "dense" and r["mode"] == "read" and r["waves"] == 1024 and r["slot_us"] == 0]
+    wr = [r["TB/s"] for r in rows if r["pattern"] == "dense" and r["mode"] == "write" and r["waves"] == 1024 and r["slot_us"] == 0 and r.get("store", "nt x4") == "nt x4"]
+    assert rd and wr and abs(rd[0] * 1e3 - bench.READ_GBS_FILE) < 150 and abs(wr[0] * 1e3 - bench.WRITE_GBS_FILE) < 150
