@@ -860,8 +860,10 @@ __global__ __launch_bounds__(kWave) void stream_lane_major_staged(
     // loads in one burst and its 32 stores in another, and all waves do so at the same time — a CU's memory pipe then serves a load burst
     // and a store burst one after the other (round 4: the kernel runs as the SUM of its directions).  Workgroups with an odd
     // (blockIdx >> shift) start `skew` ticks late, so that half the waves of a CU store while the other half load.
-    if (skew && ((blockIdx.x >> skew_shift) & 1u)) {
-        const long long d = skew, t0 = wall_clock64();
+    // (round 6: `skew_shift` bits 8.. = number of phases, 0 = two: workgroup b of the first 1024 waits ((b >> shift) % phases) x skew ticks)
+    const unsigned skew_ph = skew && blockIdx.x < 1024u ? (blockIdx.x >> (skew_shift & 31u)) % ((skew_shift >> 8) ? (skew_shift >> 8) : 2u) : 0u;
+    if (skew_ph) {
+        const long long d = (long long)(skew) * skew_ph, t0 = wall_clock64();
         for (long long spins = d / 8 + 16; spins > 0 && wall_clock64() - t0 < d; spins--) __builtin_amdgcn_s_sleep(8);
     }
     using In = typename P::In;
@@ -1663,7 +1665,8 @@ int launch_stream(const typename P::Params &prm, void *state, const typename P::
                     if (int rc = ensure_dyn_lds<&stream_lane_major_staged<P, LW, LB>>(bytes)) return rc;
                     note_kernel(LW == 64 ? "stream_lane_major_staged" : LW == 32 ? "stream_lane_major_staged[32 lanes/wave]" : "stream_lane_major_staged[16 lanes/wave]",
                                 typeid(P).name());
-                    static const unsigned lm_skew = unsigned(diag_size("IDSP_LM_SKEW", 0)), lm_skew_shift = unsigned(diag_size("IDSP_LM_SKEW_SHIFT", 8)) & 31u;
+                    static const unsigned lm_skew = unsigned(diag_size("IDSP_LM_SKEW", 0)),
+                                          lm_skew_shift = (unsigned(diag_size("IDSP_LM_SKEW_SHIFT", 8)) & 31u) | ((unsigned(diag_size("IDSP_LM_SKEW_MOD", 2)) & 255u) << 8);
                     hipLaunchKernelGGL((stream_lane_major_staged<P, LW, LB>), dim3(unsigned((lanes + LW - 1) / LW)), dim3(kWave), bytes, s, prm, st, x, y,
                                        lanes, frames, xl, yl, lm_skew, lm_skew_shift);
                     return launch_status();
