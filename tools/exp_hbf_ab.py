@@ -53,6 +53,19 @@ def entry(name):
 
 
 runs = {n: entry(n) for n in a.names}
+# every variant from the same zero state: outputs and written-back state must equal the first one's bit for bit (a variant that differs is reported, not timed as a result)
+ref = None
+for n, r in runs.items():
+    st.zero_()
+    y.zero_()
+    assert r() == 0
+    torch.cuda.synchronize()
+    got = (y.clone(), st.clone())
+    if ref is None:
+        ref = got
+    else:
+        same = bool(torch.equal(got[0].view(torch.int32), ref[0].view(torch.int32))) and bool(torch.equal(got[1], ref[1]))
+        print(json.dumps({"variant": n, "bit_exact_with": a.names[0], "same": same}), flush=True)
 for r in runs.values():  # warm-up: clocks, code objects
     for _ in range(20):
         assert r() == 0
